@@ -1,0 +1,109 @@
+"""Seeded synthetic scenes and cameras of the shapes the reference's trainers feed to render().
+
+No dataset is reachable from the build or GPU boxes (HOI4D / EPIC-KITCHENS are Google-Drive
+downloads, /root/reference/README.md:8,30), so every benchmark and parity case runs on the
+instance family S(N, H, W, seed) defined in SURVEY.md section 8d.
+
+Camera matrices follow the reference's conventions exactly:
+  * projection_matrix      <- getProjectionMatrix, /root/reference/utils/graphics_utils.py:51-71
+  * world_view_transform   <- W2V transposed,      /root/reference/scene/cameras.py:67
+  * full_proj_transform    <- W2V^T @ P^T,          /root/reference/scene/cameras.py:68-69
+  * camera_center          <- inverse(W2V^T)[3,:3], /root/reference/scene/cameras.py:70
+  * znear = 0.01, zfar = 100                        /root/reference/scene/cameras.py:61-62
+"""
+import math
+
+import numpy as np
+import torch
+
+ZNEAR, ZFAR = 0.01, 100.0
+N_FRAMES = 300                      # frames per HOI4D video, /root/reference/README.md:36
+SCENE_CENTRE = np.array([0.0, 0.0, 6.0])
+
+
+def projection_matrix(znear, zfar, fovx, fovy):
+    """Perspective matrix P (column-vector form; the renderer consumes P^T)."""
+    tx, ty = math.tan(fovx / 2), math.tan(fovy / 2)
+    top, right = ty * znear, tx * znear
+    bottom, left = -top, -right
+    P = torch.zeros(4, 4)
+    P[0, 0] = 2.0 * znear / (right - left)
+    P[1, 1] = 2.0 * znear / (top - bottom)
+    P[0, 2] = (right + left) / (right - left)
+    P[1, 2] = (top + bottom) / (top - bottom)
+    P[3, 2] = 1.0
+    P[2, 2] = zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+def world_to_view(R, t):
+    """4x4 world->view from the reference's (R, T) pair: rotation block is R^T, translation t."""
+    Rt = np.zeros((4, 4))
+    Rt[:3, :3] = np.asarray(R).transpose()
+    Rt[:3, 3] = np.asarray(t)
+    Rt[3, 3] = 1.0
+    return np.float32(Rt)
+
+
+class SynthCamera:
+    """Duck-typed stand-in for scene.cameras.Camera: the seven attributes render() reads
+    (/root/reference/gaussian_renderer/__init__.py:35-48)."""
+
+    def __init__(self, w2v, H, W, fovx, fovy, device="cpu"):
+        self.image_height, self.image_width = int(H), int(W)
+        self.FoVx, self.FoVy = float(fovx), float(fovy)
+        self.world_view_transform = torch.tensor(np.float32(w2v)).transpose(0, 1).contiguous().to(device)
+        self.projection_matrix = projection_matrix(ZNEAR, ZFAR, fovx, fovy).transpose(0, 1).to(device)
+        self.full_proj_transform = (self.world_view_transform.unsqueeze(0)
+                                    .bmm(self.projection_matrix.unsqueeze(0))).squeeze(0).contiguous()
+        self.camera_center = self.world_view_transform.inverse()[3, :3].contiguous()
+
+
+def fov_pair(H, W, fovx_deg=60.0):
+    fovx = math.radians(fovx_deg)
+    return fovx, 2.0 * math.atan(math.tan(fovx / 2) * H / W)
+
+
+def make_camera(k, H, W, device="cpu", fovx_deg=60.0):
+    """Frame k of the synthetic 300-frame orbit: yaw 10 deg*sin, pitch 5 deg*cos about (0,0,6)."""
+    fovx, fovy = fov_pair(H, W, fovx_deg)
+    ph = 2.0 * math.pi * (k % N_FRAMES) / N_FRAMES
+    yaw, pitch = math.radians(10.0) * math.sin(ph), math.radians(5.0) * (math.cos(ph) - 1.0)
+    cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    Rot = Rx @ Ry
+    w2v = np.eye(4)
+    w2v[:3, :3] = Rot
+    w2v[:3, 3] = SCENE_CENTRE - Rot @ SCENE_CENTRE      # frame 0 (yaw = pitch = 0) is the world frame
+    return SynthCamera(w2v, H, W, fovx, fovy, device)
+
+
+def make_scene(N, H, W, seed=0, sh_degree=0, fovx_deg=60.0):
+    """S(N,H,W,seed): raw (pre-activation) parameters as float32 numpy arrays, the layout
+    scene.gaussian_model.GaussianModel stores (/root/reference/scene/gaussian_model.py:125-165)."""
+    rng = np.random.default_rng(seed)
+    fovx, _ = fov_pair(H, W, fovx_deg)
+    a = 0.9 * 6.0 * math.tan(fovx / 2)
+    xyz = np.stack([rng.uniform(-a, a, N), rng.uniform(-a * H / W, a * H / W, N), rng.uniform(2.0, 10.0, N)], 1)
+    log_scale = rng.normal(math.log(0.02), 0.5, (N, 3))
+    quat = rng.normal(0.0, 1.0, (N, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    opacity_logit = rng.normal(0.0, 1.5, (N, 1))
+    M = (sh_degree + 1) ** 2
+    features = rng.normal(0.0, 1.0, (N, M, 3))
+    if M > 1:
+        features[:, 1:] *= 0.2
+    f32 = np.float32
+    return dict(xyz=xyz.astype(f32), log_scale=log_scale.astype(f32), quat=quat.astype(f32),
+                opacity_logit=opacity_logit.astype(f32), features=features.astype(f32))
+
+
+def perturb_student(scene, seed=1):
+    """Student = teacher with xyz += N(0, 0.01^2), f_dc += N(0, 0.1^2)."""
+    rng = np.random.default_rng(1000 + seed)
+    out = {k: v.copy() for k, v in scene.items()}
+    out["xyz"] += rng.normal(0, 0.01, out["xyz"].shape).astype(np.float32)
+    out["features"][:, :1] += rng.normal(0, 0.1, out["features"][:, :1].shape).astype(np.float32)
+    return out
