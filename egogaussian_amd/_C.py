@@ -1,0 +1,158 @@
+"""`_C` namespace of the drop-in `diff_gaussian_rasterization` package, backed by libegs_raster.so.
+
+Mirrors the pybind functions of the upstream CUDA extension the reference imports at
+/root/reference/gaussian_renderer/__init__.py:14 (names, argument order and return tuples as listed in
+SURVEY.md section 8b): rasterize_gaussians, rasterize_gaussians_backward, mark_visible.  "Absent" optional
+inputs are zero-length tensors, exactly as upstream passes them.
+
+Tensors must live on a HIP device (torch device type "cuda" on ROCm).  There is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _lib
+
+
+def _ptr(t):
+    return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the MI355X rasterizer runs on HIP devices only (no CPU fallback)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _opt(t):
+    """zero-length tensor -> None"""
+    return None if t is None or t.numel() == 0 else t
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """-> (num_rendered, color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer)"""
+    L = _lib.load()
+    means3D = _f32c(means3D, "means3D")
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    dev = means3D.device
+    P, H, W = means3D.shape[0], int(image_height), int(image_width)
+    background, opacity = _f32c(background, "background"), _f32c(opacity, "opacity")
+    viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
+    colors, scales, rotations = _opt(_f32c(colors, "colors")), _opt(_f32c(scales, "scales")), _opt(_f32c(rotations, "rotations"))
+    cov3D_precomp, sh = _opt(_f32c(cov3D_precomp, "cov3D_precomp")), _opt(_f32c(sh, "sh"))
+    M = 0 if sh is None else sh.shape[1]
+    with torch.cuda.device(dev):
+        opts = dict(device=dev, dtype=torch.float32)
+        out_color = torch.empty((3, H, W), **opts)
+        out_depth = torch.empty((1, H, W), **opts)
+        out_alpha = torch.empty((1, H, W), **opts)
+        radii = torch.empty((P,), device=dev, dtype=torch.int32)
+        geom = torch.empty((L.egs_geom_bytes(P),), device=dev, dtype=torch.uint8)
+        img = torch.empty((L.egs_image_bytes(W, H),), device=dev, dtype=torch.uint8)
+        R = C.c_int64(0)
+        if P != 0:
+            _lib.check(L.egs_forward_geometry(
+                P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
+                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+                _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom),
+                C.byref(R), _stream(), int(bool(debug))))
+        binning = torch.empty((L.egs_binning_bytes(R.value, W, H),), device=dev, dtype=torch.uint8)
+        _lib.check(L.egs_forward_render(P, R.value, _ptr(background), W, H, _ptr(geom), _ptr(binning), _ptr(img),
+                                        _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), _stream(), int(bool(debug))))
+    return int(R.value), out_color, out_depth, out_alpha, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
+                                 dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alpha,
+                                 debug):
+    """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
+           dL_dscales[P,3], dL_drotations[P,4])"""
+    L = _lib.load()
+    means3D = _f32c(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = dL_dout_color.shape[-2], dL_dout_color.shape[-1]
+    background = _f32c(background, "background")
+    viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
+    colors, scales, rotations = _opt(_f32c(colors, "colors")), _opt(_f32c(scales, "scales")), _opt(_f32c(rotations, "rotations"))
+    cov3D_precomp, sh = _opt(_f32c(cov3D_precomp, "cov3D_precomp")), _opt(_f32c(sh, "sh"))
+    g_color = _f32c(dL_dout_color, "dL_dout_color")
+    g_depth = _opt(_f32c(dL_dout_depth, "dL_dout_depth"))
+    g_alpha = _opt(_f32c(dL_dout_alpha, "dL_dout_alpha"))
+    M = 0 if sh is None else sh.shape[1]
+    with torch.cuda.device(dev):
+        e = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+        dmeans2D, dcolors, dopacity, dmeans3D, dcov3D = e(P, 3), e(P, 3), e(P, 1), e(P, 3), e(P, 6)
+        dsh = e(P, M, 3) if sh is not None else e(0, 0, 3)
+        own_cov = cov3D_precomp is None
+        dscales = e(P, 3) if own_cov else torch.zeros((P, 3), device=dev)
+        drots = e(P, 4) if own_cov else torch.zeros((P, 4), device=dev)
+        if P != 0:
+            scratch = torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
+            _lib.check(L.egs_backward(
+                P, int(degree), M, int(R), _ptr(background), _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
+                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+                _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
+                _ptr(imageBuffer), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(dmeans2D), _ptr(dcolors),
+                _ptr(dopacity), _ptr(dmeans3D), _ptr(dcov3D), _ptr(dsh), _ptr(dscales) if own_cov else None,
+                _ptr(drots) if own_cov else None, _ptr(scratch), _stream(), int(bool(debug))))
+    return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """-> bool[P]: Gaussians in front of the near plane (view.z > 0.2)."""
+    L = _lib.load()
+    means3D = _f32c(means3D, "means3D")
+    P = means3D.shape[0]
+    present = torch.zeros((P,), device=means3D.device, dtype=torch.uint8)
+    if P:
+        with torch.cuda.device(means3D.device):
+            _lib.check(L.egs_mark_visible(P, _ptr(means3D), _ptr(_f32c(viewmatrix, "viewmatrix")),
+                                          _ptr(_f32c(projmatrix, "projmatrix")), _ptr(present), _stream()))
+    return present.bool()
+
+
+# spellings of the C++ symbols behind the pybind names (BASELINE.json refers to `_C.RasterizeGaussians`)
+RasterizeGaussians = RasterizeGaussiansCUDA = rasterize_gaussians
+RasterizeGaussiansBackward = RasterizeGaussiansBackwardCUDA = rasterize_gaussians_backward
+markVisible = mark_visible
+
+
+# ---- debugging / test helpers: typed views into the opaque byte buffers ------------------------------
+def geom_views(geom, P):
+    lay = _lib.GeomLayout()
+    _lib.check(_lib.load().egs_get_geom_layout(P, C.byref(lay)))
+    v = lambda off, n, dt: geom[off:off + n].view(dt)
+    return dict(rec=v(lay.rec, P * 48, torch.float32).view(P, 12), rect=v(lay.rect, P * 8, torch.int32).view(P, 2),
+                offsets=v(lay.offsets, P * 4, torch.int32), clamped=geom[lay.clamped:lay.clamped + P])
+
+
+def binning_views(binning, R, W, H):
+    lay = _lib.BinningLayout()
+    _lib.check(_lib.load().egs_get_binning_layout(R, W, H, C.byref(lay)))
+    ko, vo = (lay.keys_b, lay.vals_b) if lay.sorted_in_b else (lay.keys_a, lay.vals_a)
+    uo, wo = (lay.keys_a, lay.vals_a) if lay.sorted_in_b else (lay.keys_b, lay.vals_b)
+    return dict(keys=binning[ko:ko + R * 8].view(torch.int64), point_list=binning[vo:vo + R * 4].view(torch.int32),
+                scratch_keys=binning[uo:uo + R * 8].view(torch.int64), scratch_vals=binning[wo:wo + R * 4].view(torch.int32),
+                key_bits=lay.key_bits, passes=lay.passes)
+
+
+def image_views(img, W, H):
+    lay = _lib.ImageLayout()
+    _lib.check(_lib.load().egs_get_image_layout(W, H, C.byref(lay)))
+    nt = ((W + 15) // 16) * ((H + 15) // 16)
+    return dict(ranges=img[lay.ranges:lay.ranges + nt * 8].view(torch.int32).view(nt, 2),
+                final_T=img[lay.final_T:lay.final_T + H * W * 4].view(torch.float32).view(H, W),
+                n_contrib=img[lay.n_contrib:lay.n_contrib + H * W * 4].view(torch.int32).view(H, W))

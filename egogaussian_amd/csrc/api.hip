@@ -1,0 +1,223 @@
+// api.hip -- the C ABI of libegs_raster.so (declared in include/egs_raster.h): argument checks, carving
+// of the three caller-owned byte buffers, and the launch sequence on the caller's stream.
+// Replaces the pybind `_C` entry points of the upstream extension bound at
+// /root/reference/gaussian_renderer/__init__.py:14.
+#include "egs_common.h"
+#include <string.h>
+
+namespace {
+
+struct GeomLayout { egs_geom_layout o; size_t bytes; };
+struct BinLayout { egs_binning_layout o; size_t bytes; };
+struct ImgLayout { egs_image_layout o; size_t bytes; };
+
+GeomLayout geom_layout(int P) {
+    GeomLayout L; size_t off = 0; const size_t n = (size_t)(P > 0 ? P : 0);
+    L.o.rec = off;          off = egs_align(off + n * sizeof(float4) * EGS_SPLAT_REC_F4);
+    L.o.rect = off;         off = egs_align(off + n * sizeof(uint2));
+    L.o.offsets = off;      off = egs_align(off + n * sizeof(uint32_t));
+    L.o.clamped = off;      off = egs_align(off + n);
+    L.o.scan_scratch = off; off = egs_align(off + egs_scan_scratch_elems(n) * sizeof(uint32_t));
+    L.o.total = off;        off = egs_align(off + sizeof(uint64_t));
+    L.bytes = off; return L;
+}
+BinLayout bin_layout(int64_t R, int W, int H) {
+    BinLayout L; size_t off = 0; const size_t n = (size_t)(R > 0 ? R : 0);
+    const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
+    L.o.key_bits = egs_key_bits_for_tiles(gx * gy);
+    L.o.passes = (L.o.key_bits + EGS_SORT_BITS - 1) / EGS_SORT_BITS;
+    L.o.sorted_in_b = L.o.passes & 1;
+    const size_t nblocks = (n + EGS_SORT_KPB - 1) / EGS_SORT_KPB;
+    L.o.keys_a = off; off = egs_align(off + n * sizeof(uint64_t));
+    L.o.keys_b = off; off = egs_align(off + n * sizeof(uint64_t));
+    L.o.vals_a = off; off = egs_align(off + n * sizeof(uint32_t));
+    L.o.vals_b = off; off = egs_align(off + n * sizeof(uint32_t));
+    L.o.hist = off;   off = egs_align(off + nblocks * EGS_SORT_BINS * sizeof(uint32_t));
+    L.o.spine = off;  off = egs_align(off + egs_scan_scratch_elems(nblocks * EGS_SORT_BINS) * sizeof(uint32_t));
+    L.bytes = off; return L;
+}
+ImgLayout img_layout(int W, int H) {
+    ImgLayout L; size_t off = 0;
+    const size_t gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE, px = (size_t)W * H;
+    L.o.ranges = off;    off = egs_align(off + gx * gy * sizeof(uint2));
+    L.o.final_T = off;   off = egs_align(off + px * sizeof(float));
+    L.o.n_contrib = off; off = egs_align(off + px * sizeof(uint32_t));
+    L.bytes = off; return L;
+}
+EgsGeomPtrs geom_ptrs(void* buf, int P) {
+    const GeomLayout L = geom_layout(P); char* b = (char*)buf; EgsGeomPtrs g;
+    g.rec = (float4*)(b + L.o.rec); g.rect = (uint2*)(b + L.o.rect); g.offsets = (uint32_t*)(b + L.o.offsets);
+    g.clamped = (uint8_t*)(b + L.o.clamped); g.scan_scratch = (uint32_t*)(b + L.o.scan_scratch);
+    g.total = (uint64_t*)(b + L.o.total); return g;
+}
+EgsBinPtrs bin_ptrs(void* buf, int64_t R, int W, int H) {
+    const BinLayout L = bin_layout(R, W, H); char* b = (char*)buf; EgsBinPtrs p;
+    p.keys_a = (uint64_t*)(b + L.o.keys_a); p.keys_b = (uint64_t*)(b + L.o.keys_b);
+    p.vals_a = (uint32_t*)(b + L.o.vals_a); p.vals_b = (uint32_t*)(b + L.o.vals_b);
+    p.hist = (uint32_t*)(b + L.o.hist); p.spine = (uint32_t*)(b + L.o.spine);
+    p.sorted_in_b = L.o.sorted_in_b; p.key_bits = L.o.key_bits; p.passes = L.o.passes; return p;
+}
+EgsImgPtrs img_ptrs(void* buf, int W, int H) {
+    const ImgLayout L = img_layout(W, H); char* b = (char*)buf; EgsImgPtrs p;
+    p.ranges = (uint2*)(b + L.o.ranges); p.final_T = (float*)(b + L.o.final_T);
+    p.n_contrib = (uint32_t*)(b + L.o.n_contrib); return p;
+}
+
+int check_dims(int P, int W, int H) {
+    if (P < 0 || W <= 0 || H <= 0) return EGS_ERR_ARG;
+    if (W > 65535 || H > 65535) return EGS_ERR_RANGE;
+    return 0;
+}
+int check_modes(const float* shs, const float* colors, const float* scales, const float* rots, const float* cov) {
+    if ((shs != nullptr) == (colors != nullptr)) return EGS_ERR_MODE;
+    const bool sr = scales != nullptr && rots != nullptr;
+    if ((scales != nullptr) != (rots != nullptr)) return EGS_ERR_MODE;
+    if (sr == (cov != nullptr)) return EGS_ERR_MODE;
+    return 0;
+}
+
+#define EGS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+#define EGS_SYNC_IF_DEBUG(s) do { if (debug) { EGS_TRY(hipStreamSynchronize(s)); EGS_TRY(hipGetLastError()); } } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int egs_abi_version(void) { return EGS_ABI_VERSION; }
+
+const char* egs_error_string(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case EGS_ERR_ARG: return "egs: invalid argument (null pointer or negative size)";
+        case EGS_ERR_MODE: return "egs: provide exactly one of {shs, colors_precomp} and exactly one of {cov3D_precomp, (scales, rotations)}";
+        case EGS_ERR_RANGE: return "egs: size outside the supported range";
+        case EGS_ERR_NO_DEVICE: return "egs: no usable HIP device";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "egs: unknown error";
+    }
+}
+
+int egs_device_info(char* name, int name_len, char* arch, int arch_len, int* compute_units) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return EGS_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    EGS_TRY(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len > 0) { strncpy(name, prop.name, (size_t)name_len - 1); name[name_len - 1] = 0; }
+    if (arch && arch_len > 0) { strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1); arch[arch_len - 1] = 0; }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    return 0;
+}
+
+size_t egs_geom_bytes(int P) { return geom_layout(P).bytes; }
+size_t egs_binning_bytes(int64_t R, int width, int height) { return bin_layout(R, width, height).bytes; }
+size_t egs_image_bytes(int width, int height) { return img_layout(width, height).bytes; }
+size_t egs_backward_scratch_bytes(int P) { return egs_align((size_t)(P > 0 ? P : 0) * EGS_GRAD_STRIDE * sizeof(float)); }
+
+int egs_get_geom_layout(int P, egs_geom_layout* out) { if (!out || P < 0) return EGS_ERR_ARG; *out = geom_layout(P).o; return 0; }
+int egs_get_binning_layout(int64_t R, int width, int height, egs_binning_layout* out) {
+    if (!out || R < 0 || width <= 0 || height <= 0) return EGS_ERR_ARG;
+    *out = bin_layout(R, width, height).o; return 0;
+}
+int egs_get_image_layout(int width, int height, egs_image_layout* out) {
+    if (!out || width <= 0 || height <= 0) return EGS_ERR_ARG;
+    *out = img_layout(width, height).o; return 0;
+}
+
+int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs,
+                         const float* colors_precomp, const float* opacities, const float* scales,
+                         float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         const float* viewmatrix, const float* projmatrix, const float* campos, int width, int height,
+                         float tan_fovx, float tan_fovy, int prefiltered, int32_t* radii, void* geom_buffer,
+                         int64_t* num_rendered, void* stream, int debug) {
+    (void)prefiltered;
+    int rc = check_dims(P, width, height); if (rc) return rc;
+    if (!num_rendered) return EGS_ERR_ARG;
+    *num_rendered = 0;
+    if (P == 0) return 0;
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer) return EGS_ERR_ARG;
+    rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp); if (rc) return rc;
+    if (shs && (sh_degree < 0 || sh_degree > EGS_MAX_SH_DEGREE || sh_coeffs < (sh_degree + 1) * (sh_degree + 1))) return EGS_ERR_RANGE;
+    hipStream_t s = (hipStream_t)stream;
+    EgsGeomPtrs g = geom_ptrs(geom_buffer, P);
+    EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
+    EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                                  rotations, cov3D_precomp, cam, radii, g, s));
+    EGS_SYNC_IF_DEBUG(s);
+    EGS_TRY(egs_launch_scan_u32(g.offsets, g.offsets, (size_t)P, 1, g.scan_scratch, g.total, s));
+    EGS_SYNC_IF_DEBUG(s);
+    uint64_t R = 0;
+    EGS_TRY(hipMemcpyAsync(&R, g.total, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    EGS_TRY(hipStreamSynchronize(s));
+    if (R >= (1ull << 31)) return EGS_ERR_RANGE;
+    *num_rendered = (int64_t)R;
+    return 0;
+}
+
+int egs_forward_render(int P, int64_t R, const float* background, int width, int height, const void* geom_buffer,
+                       void* binning_buffer, void* image_buffer, float* out_color, float* out_depth, float* out_alpha,
+                       void* stream, int debug) {
+    int rc = check_dims(P, width, height); if (rc) return rc;
+    if (R < 0 || R >= (1ll << 31)) return EGS_ERR_RANGE;
+    if (!background || !image_buffer || !out_color || !out_depth || !out_alpha) return EGS_ERR_ARG;
+    if (P > 0 && !geom_buffer) return EGS_ERR_ARG;
+    if (R > 0 && !binning_buffer) return EGS_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
+    EgsBinPtrs b = bin_ptrs(binning_buffer, R, width, height);
+    EgsImgPtrs im = img_ptrs(image_buffer, width, height);
+    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, s, debug));
+    const uint32_t* point_list = b.sorted_in_b ? b.vals_b : b.vals_a;
+    EGS_TRY(egs_launch_render_forward(width, height, background, g, point_list, im, out_color, out_depth, out_alpha, s));
+    EGS_SYNC_IF_DEBUG(s);
+    return 0;
+}
+
+int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* background, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, int width, int height, float tan_fovx, float tan_fovy, const int32_t* radii,
+                 const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                 const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
+                 float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscales, float* dL_drotations, void* scratch, void* stream, int debug) {
+    int rc = check_dims(P, width, height); if (rc) return rc;
+    if (P == 0) return 0;
+    if (R < 0 || R >= (1ll << 31)) return EGS_ERR_RANGE;
+    if (!background || !means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer ||
+        !dL_dout_color || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !scratch)
+        return EGS_ERR_ARG;
+    if (R > 0 && !binning_buffer) return EGS_ERR_ARG;
+    rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp); if (rc) return rc;
+    if (shs && !dL_dsh) return EGS_ERR_ARG;
+    if (!cov3D_precomp && (!dL_dscales || !dL_drotations)) return EGS_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
+    EgsBinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), R, width, height);
+    EgsImgPtrs im = img_ptrs(const_cast<void*>(image_buffer), width, height);
+    float* grad_acc = (float*)scratch;
+    EGS_TRY(hipMemsetAsync(grad_acc, 0, (size_t)P * EGS_GRAD_STRIDE * sizeof(float), s));
+    if (R > 0) {
+        const uint32_t* point_list = b.sorted_in_b ? b.vals_b : b.vals_a;
+        EGS_TRY(egs_launch_render_backward(width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth,
+                                           dL_dout_alpha, grad_acc, s));
+        EGS_SYNC_IF_DEBUG(s);
+    }
+    EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
+    EGS_TRY(egs_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, shs, scales, scale_modifier, rotations,
+                                           cov3D_precomp, cam, radii, g, grad_acc, colors_precomp != nullptr, dL_dmeans2D,
+                                           dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
+                                           dL_drotations, s));
+    EGS_SYNC_IF_DEBUG(s);
+    return 0;
+}
+
+int egs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream) {
+    (void)projmatrix;
+    if (P < 0) return EGS_ERR_ARG;
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present) return EGS_ERR_ARG;
+    EGS_TRY(egs_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// blend_common.h -- pieces shared by the forward and backward blend kernels (gfx950).
+#pragma once
+#include "egs_common.h"
+
+// Tiles are handed to workgroups so that each XCD (workgroup b runs on XCD b % 8 on MI355X -- used for
+// L2 affinity only, never for correctness) owns one contiguous band of tile rows: neighbouring tiles
+// share most of their splats, so a band keeps its splat records in that XCD's private 4 MiB L2.
+#define EGS_XCDS 8
+__host__ __device__ __forceinline__ int egs_tiles_per_xcd(int n_tiles) { return (n_tiles + EGS_XCDS - 1) / EGS_XCDS; }
+__host__ __forceinline__ int egs_blocks_for_tiles(int n_tiles) { return egs_tiles_per_xcd(n_tiles) * EGS_XCDS; }
+__device__ __forceinline__ int egs_tile_of_block(unsigned b, int n_tiles) {
+    const int t = (int)(b % EGS_XCDS) * egs_tiles_per_xcd(n_tiles) + (int)(b / EGS_XCDS);
+    return (b / EGS_XCDS) < (unsigned)egs_tiles_per_xcd(n_tiles) && t < n_tiles ? t : -1;
+}
+
+__device__ __forceinline__ void egs_load_rec(const float4* __restrict__ rec, uint32_t id, bool ok, float4& a,
+                                             float4& b, float4& c) {
+    if (ok) {
+        const float4* r = rec + (size_t)id * EGS_SPLAT_REC_F4;
+        a = r[0]; b = r[1]; c = r[2];
+    } else {
+        a = b = make_float4(0.f, 0.f, 0.f, 0.f);
+        c = make_float4(0.f, 0.f, __uint_as_float(1u), __uint_as_float(1u));     // empty bbox
+    }
+}
+
+// Does the record's pixel bounding box (c.z = x0 | x1<<16, c.w = y0 | y1<<16) intersect [qx0,qx1]x[qy0,qy1]?
+__device__ __forceinline__ bool egs_bbox_hits(const float4& c, uint32_t qx0, uint32_t qx1, uint32_t qy0, uint32_t qy1) {
+    const uint32_t bx = __float_as_uint(c.z), by = __float_as_uint(c.w);
+    const uint32_t x0 = bx & 0xffffu, x1 = bx >> 16, y0 = by & 0xffffu, y1 = by >> 16;
+    return x0 <= qx1 && x1 >= qx0 && y0 <= qy1 && y1 >= qy0;
+}
+
+// alpha = min(0.99, o * exp(power)), power = -0.5 (A dx^2 + C dy^2) - B dx dy.
+// Returns a negative value when the published algorithm skips the pair (power > 0 or alpha < 1/255).
+// Explicit fma / mul so the forward and the backward evaluate bit-identical alphas.
+__device__ __forceinline__ float egs_alpha(float dx, float dy, float A, float B, float C, float o, float& G) {
+    float p = __fmul_rn(__fmul_rn(A, dx), dx);
+    p = __fmaf_rn(__fmul_rn(C, dy), dy, p);
+    const float power = __fmaf_rn(-__fmul_rn(B, dx), dy, __fmul_rn(-0.5f, p));
+    G = __builtin_amdgcn_exp2f(__fmul_rn(power, 1.4426950408889634f));
+    const float alpha = fminf(0.99f, __fmul_rn(o, G));
+    return (power > 0.f || alpha < (1.0f / 255.0f)) ? -1.f : alpha;
+}

@@ -1,0 +1,73 @@
+// egs_common.h -- shared declarations of the gfx950 rasterizer library (internal; the public C ABI
+// is include/egs_raster.h).  Wave = 64 lanes everywhere; no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/egs_raster.h"
+
+#define EGS_WAVE 64
+#define EGS_SPLAT_REC_F4 3          // float4 per packed splat record (48 B)
+
+// Packed per-Gaussian record produced by preprocess and gathered by the blend kernels:
+//   f4[0] = (x, y, depth, opacity)   f4[1] = (conA, conB, conC, red)
+//   f4[2] = (green, blue, bits(bbox_x = x0 | x1<<16), bits(bbox_y = y0 | y1<<16))
+// bbox = conservative pixel bounding box of {alpha >= 1/255}; x0 > x1 marks "never contributes".
+
+// Per-Gaussian gradient accumulator written by the blend backward (one 48-B line per Gaussian):
+//   [0]=dmean2D.x [1]=dmean2D.y [2]=dconic.xx [3]=dconic.xy(half) [4]=dconic.yy [5]=dopacity
+//   [6..8]=dcolor rgb [9]=ddepth [10..11]=pad
+#define EGS_GRAD_STRIDE 12
+
+struct EgsGeomPtrs {
+    float4* rec; uint2* rect; uint32_t* offsets; uint8_t* clamped; uint32_t* scan_scratch; uint64_t* total;
+};
+struct EgsBinPtrs {
+    uint64_t* keys_a; uint64_t* keys_b; uint32_t* vals_a; uint32_t* vals_b; uint32_t* hist; uint32_t* spine;
+    int sorted_in_b, key_bits, passes;
+};
+struct EgsImgPtrs { uint2* ranges; float* final_T; uint32_t* n_contrib; };
+
+static inline size_t egs_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// radix sort geometry (binning.hip)
+#define EGS_SORT_BITS 8
+#define EGS_SORT_BINS 256
+#define EGS_SORT_THREADS 256
+#define EGS_SORT_ITEMS 16
+#define EGS_SORT_KPB (EGS_SORT_THREADS * EGS_SORT_ITEMS)      // keys per block
+#define EGS_SCAN_THREADS 256
+#define EGS_SCAN_ITEMS 8
+#define EGS_SCAN_EPB (EGS_SCAN_THREADS * EGS_SCAN_ITEMS)      // elements per block
+
+int egs_key_bits_for_tiles(int n_tiles);
+size_t egs_scan_scratch_elems(size_t n);
+
+// ---- launchers (host side, one per translation unit) -------------------------------------------
+struct EgsCamera {
+    const float* view; const float* proj; const float* campos;
+    int W, H; float tanfovx, tanfovy;
+};
+hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
+                                 const float* opac, const float* scales, float mod, const float* rots,
+                                 const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, hipStream_t s);
+hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* means3D, const float* shs,
+                                          const float* scales, float mod, const float* rots, const float* cov3D,
+                                          EgsCamera cam, const int32_t* radii, EgsGeomPtrs g, const float* grad_acc,
+                                          int colors_given, float* dmeans2D, float* dcolors, float* dopac,
+                                          float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,
+                                          hipStream_t s);
+hipError_t egs_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+
+// exclusive/inclusive u32 scan of n elements; scratch holds egs_scan_scratch_elems(n) u32; optionally
+// writes the grand total (u64) to *total.
+hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int inclusive, uint32_t* scratch,
+                               uint64_t* total, hipStream_t s);
+hipError_t egs_launch_binning(int P, int64_t R, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
+                              hipStream_t s, int debug);
+hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
+                                     EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha,
+                                     hipStream_t s);
+hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
+                                      EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
+                                      const float* dL_dalpha, float* grad_acc, hipStream_t s);

@@ -1,0 +1,432 @@
+// preprocess.hip -- per-Gaussian stages of the rasterizer for gfx950:
+//   k_preprocess           3D->2D projection, EWA covariance, conic, radius, tile rect, SH->RGB
+//   k_preprocess_backward  conic/mean2D/colour/depth gradients -> mean3D, cov3D, SH, scale, quaternion
+//   k_mark_visible         near-plane test
+// Replaces the per-Gaussian stages of the upstream op called from
+// /root/reference/gaussian_renderer/__init__.py:90-98.
+//
+// One lane per Gaussian; a wave reads 64 consecutive xyz / cov6 / SH rows, i.e. contiguous 768 B /
+// 1.5 KB / 768 B spans, so the array-of-rows inputs coalesce without staging.  The forward result is
+// packed into one 48-byte record per Gaussian (egs_common.h) so the blend kernels gather three
+// dwordx4 per splat instead of touching five arrays.
+//
+// This translation unit is compiled with -ffp-contract=off and every expression follows the order of
+// oracle/raster_oracle.c, so radii, tile rectangles and depth bits are bit-identical to the oracle.
+#include "egs_common.h"
+
+namespace {
+
+__device__ __constant__ float kC0 = 0.28209479177387814f;
+__device__ __constant__ float kC1 = 0.4886025119029199f;
+__device__ __constant__ float kC2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                         -1.0925484305920792f, 0.5462742152960396f };
+__device__ __constant__ float kC3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                         0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                         -0.5900435899266435f };
+
+__device__ __forceinline__ void xform43(const float* p, const float* m, float* o) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+__device__ __forceinline__ void xform44(const float* p, const float* m, float* o) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+    o[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+}
+
+__device__ __forceinline__ void quat_to_rot(const float* q, float* R) {
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// cov3D = (R S)(R S)^T, six unique entries (00,01,02,11,12,22); quaternion used as given.
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* s, float mod, const float* q, float* c6) {
+    float R[9]; quat_to_rot(q, R);
+    float sc[3] = { mod * s[0], mod * s[1], mod * s[2] };
+    float L[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) L[3 * i + k] = R[3 * i + k] * sc[k];
+    c6[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+    c6[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
+    c6[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8];
+    c6[3] = L[3] * L[3] + L[4] * L[4] + L[5] * L[5];
+    c6[4] = L[3] * L[6] + L[4] * L[7] + L[5] * L[8];
+    c6[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
+}
+
+// Everything the forward and backward share: camera-space point, clamped Jacobian rows (J R), Sigma*m.
+struct Ewa {
+    float t[3], tx, ty, txtz, tytz, limx, limy, fx, fy;
+    float m0[3], m1[3], S0[3], S1[3], a, b, c;
+};
+__device__ __forceinline__ void ewa_project(const float* p, const float* c6, const float* V, int W, int H,
+                                            float tanfovx, float tanfovy, Ewa& e) {
+    xform43(p, V, e.t);
+    e.fx = (float)W / (2.f * tanfovx); e.fy = (float)H / (2.f * tanfovy);
+    e.limx = 1.3f * tanfovx; e.limy = 1.3f * tanfovy;
+    e.txtz = e.t[0] / e.t[2]; e.tytz = e.t[1] / e.t[2];
+    e.tx = fminf(e.limx, fmaxf(-e.limx, e.txtz)) * e.t[2];
+    e.ty = fminf(e.limy, fmaxf(-e.limy, e.tytz)) * e.t[2];
+    float j00 = e.fx / e.t[2], j02 = -(e.fx * e.tx) / (e.t[2] * e.t[2]);
+    float j11 = e.fy / e.t[2], j12 = -(e.fy * e.ty) / (e.t[2] * e.t[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        e.m0[k] = j00 * V[4 * k + 0] + j02 * V[4 * k + 2];
+        e.m1[k] = j11 * V[4 * k + 1] + j12 * V[4 * k + 2];
+    }
+    e.S0[0] = c6[0] * e.m0[0] + c6[1] * e.m0[1] + c6[2] * e.m0[2];
+    e.S0[1] = c6[1] * e.m0[0] + c6[3] * e.m0[1] + c6[4] * e.m0[2];
+    e.S0[2] = c6[2] * e.m0[0] + c6[4] * e.m0[1] + c6[5] * e.m0[2];
+    e.S1[0] = c6[0] * e.m1[0] + c6[1] * e.m1[1] + c6[2] * e.m1[2];
+    e.S1[1] = c6[1] * e.m1[0] + c6[3] * e.m1[1] + c6[4] * e.m1[2];
+    e.S1[2] = c6[2] * e.m1[0] + c6[4] * e.m1[1] + c6[5] * e.m1[2];
+    e.a = e.m0[0] * e.S0[0] + e.m0[1] * e.S0[1] + e.m0[2] * e.S0[2] + 0.3f;
+    e.b = e.m0[0] * e.S1[0] + e.m0[1] * e.S1[1] + e.m0[2] * e.S1[2];
+    e.c = e.m1[0] * e.S1[0] + e.m1[1] * e.S1[1] + e.m1[2] * e.S1[2] + 0.3f;
+}
+
+__device__ __forceinline__ float sh_channel(int deg, const float* sh, int ch, float x, float y, float z) {
+#define SH(k) sh[(k) * 3 + ch]
+    float v = kC0 * SH(0);
+    if (deg > 0) {
+        v = v - kC1 * y * SH(1) + kC1 * z * SH(2) - kC1 * x * SH(3);
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            v = v + kC2[0] * xy * SH(4) + kC2[1] * yz * SH(5) + kC2[2] * (2.f * zz - xx - yy) * SH(6) +
+                kC2[3] * xz * SH(7) + kC2[4] * (xx - yy) * SH(8);
+            if (deg > 2) {
+                v = v + kC3[0] * y * (3.f * xx - yy) * SH(9) + kC3[1] * xy * z * SH(10) +
+                    kC3[2] * y * (4.f * zz - xx - yy) * SH(11) + kC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * SH(12) +
+                    kC3[4] * x * (4.f * zz - xx - yy) * SH(13) + kC3[5] * z * (xx - yy) * SH(14) +
+                    kC3[6] * x * (xx - 3.f * yy) * SH(15);
+            }
+        }
+    }
+#undef SH
+    return v + 0.5f;
+}
+
+__global__ __launch_bounds__(256) void k_preprocess(
+    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales, float mod,
+    const float* __restrict__ rots, const float* __restrict__ cov3D_in, const float* __restrict__ V,
+    const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
+    int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
+    uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
+    radii[i] = 0; tiles_touched[i] = 0;
+
+    const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
+    float c6[6];
+    if (cov3D_in) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = cov3D_in[6 * (size_t)i + k];
+    } else {
+        const float s[3] = { scales[3 * i], scales[3 * i + 1], scales[3 * i + 2] };
+        const float q[4] = { rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3] };
+        cov3d_from_scale_rot(s, mod, q, c6);
+    }
+    Ewa e; ewa_project(p, c6, V, W, H, tanfovx, tanfovy, e);
+    if (e.t[2] <= 0.2f) return;                                   // near-plane cull
+    float hom[4]; xform44(p, PM, hom);
+    const float pw = 1.f / (hom[3] + 0.0000001f);
+    const float ndc_x = hom[0] * pw, ndc_y = hom[1] * pw;
+
+    const float det = e.a * e.c - e.b * e.b;
+    if (det == 0.f) return;
+    const float det_inv = 1.f / det;
+    const float conA = e.c * det_inv, conB = -e.b * det_inv, conC = e.a * det_inv;
+    const float mid = 0.5f * (e.a + e.c);
+    const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float lam1 = mid + disc, lam2 = mid - disc;
+    const int rad = (int)ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
+    const float px = ((ndc_x + 1.f) * (float)W - 1.f) * 0.5f;
+    const float py = ((ndc_y + 1.f) * (float)H - 1.f) * 0.5f;
+    const int rx0 = min(gx, max(0, (int)((px - (float)rad) / (float)EGS_TILE)));
+    const int ry0 = min(gy, max(0, (int)((py - (float)rad) / (float)EGS_TILE)));
+    const int rx1 = min(gx, max(0, (int)((px + (float)rad + (float)(EGS_TILE - 1)) / (float)EGS_TILE)));
+    const int ry1 = min(gy, max(0, (int)((py + (float)rad + (float)(EGS_TILE - 1)) / (float)EGS_TILE)));
+    if ((rx1 - rx0) * (ry1 - ry0) == 0) return;
+
+    float rgb[3]; uint32_t cl = 0;
+    if (colors) {
+        rgb[0] = colors[3 * i]; rgb[1] = colors[3 * i + 1]; rgb[2] = colors[3 * i + 2];
+    } else {
+        float dir[3] = { p[0] - campos[0], p[1] - campos[1], p[2] - campos[2] };
+        const float inv = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+        dir[0] *= inv; dir[1] *= inv; dir[2] *= inv;
+        const float* sh = shs + (size_t)i * M * 3;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float v = sh_channel(D, sh, ch, dir[0], dir[1], dir[2]);
+            if (v < 0.f) cl |= 1u << ch;
+            rgb[ch] = fmaxf(v, 0.f);
+        }
+    }
+    const float o = opac[i];
+
+    // Conservative pixel bounding box of {alpha >= 1/255}: the ellipse 0.5 d^T Q d <= tau with
+    // tau = ln(255 o).  Not part of the published algorithm -- it only lets the blend kernels skip
+    // (8x8 pixel block, splat) pairs that provably contribute nothing, so results are unchanged.
+    uint32_t bbx = 1u, bby = 1u;                                   // x0 = 1 > x1 = 0: empty
+    {
+        const float lo = 255.f * o;
+        if (!(lo < 0.999f)) {
+            const float tau2 = 2.f * (logf(fmaxf(lo, 1.f)) + 0.01f);
+            const float detq = conA * conC - conB * conB;
+            float ex = 1e9f, ey = 1e9f;
+            if (detq > 0.f && conA * conC < 1e4f * detq) {
+                ex = fmaxf(sqrtf(tau2 * conC / detq), sqrtf(tau2 * e.a)) * 1.002f + 0.01f;
+                ey = fmaxf(sqrtf(tau2 * conA / detq), sqrtf(tau2 * e.c)) * 1.002f + 0.01f;
+            }
+            const float fx0 = fmaxf(floorf(px - ex), 0.f), fx1 = fminf(ceilf(px + ex), (float)(W - 1));
+            const float fy0 = fmaxf(floorf(py - ey), 0.f), fy1 = fminf(ceilf(py + ey), (float)(H - 1));
+            if (fx0 <= fx1 && fy0 <= fy1) {
+                bbx = (uint32_t)fx0 | ((uint32_t)fx1 << 16);
+                bby = (uint32_t)fy0 | ((uint32_t)fy1 << 16);
+            } else if (!(ex == ex) || !(ey == ey) || !(px == px) || !(py == py)) {   // NaN: never cull
+                bbx = 0u | ((uint32_t)(W - 1) << 16); bby = 0u | ((uint32_t)(H - 1) << 16);
+            }
+        }
+    }
+
+    radii[i] = rad;
+    tiles_touched[i] = (uint32_t)((rx1 - rx0) * (ry1 - ry0));
+    rect_out[i] = make_uint2((uint32_t)rx0 | ((uint32_t)rx1 << 16), (uint32_t)ry0 | ((uint32_t)ry1 << 16));
+    clamped_out[i] = (uint8_t)cl;
+    float4* r = rec + (size_t)i * EGS_SPLAT_REC_F4;
+    r[0] = make_float4(px, py, e.t[2], o);
+    r[1] = make_float4(conA, conB, conC, rgb[0]);
+    r[2] = make_float4(rgb[1], rgb[2], __uint_as_float(bbx), __uint_as_float(bby));
+}
+
+__global__ __launch_bounds__(256) void k_preprocess_backward(
+    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ scales, float mod, const float* __restrict__ rots, const float* __restrict__ cov3D_in,
+    const float* __restrict__ V, const float* __restrict__ PM, const float* __restrict__ campos, int W, int H,
+    float tanfovx, float tanfovy, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
+    const float* __restrict__ grad_acc, float* __restrict__ dmeans2D, float* __restrict__ dcolors,
+    float* __restrict__ dopac, float* __restrict__ dmeans3D, float* __restrict__ dcov3D, float* __restrict__ dsh,
+    float* __restrict__ dscales, float* __restrict__ drots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const bool vis = radii[i] > 0;
+    float acc[EGS_GRAD_STRIDE];
+    {
+        const float4* ga = reinterpret_cast<const float4*>(grad_acc + (size_t)i * EGS_GRAD_STRIDE);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float4 v = vis ? ga[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
+        }
+    }
+    // the blend backward accumulates d/d(pixel position); the published op reports it in NDC units
+    acc[0] *= 0.5f * (float)W; acc[1] *= 0.5f * (float)H;
+    dmeans2D[3 * i] = acc[0]; dmeans2D[3 * i + 1] = acc[1]; dmeans2D[3 * i + 2] = 0.f;
+    dcolors[3 * i] = acc[6]; dcolors[3 * i + 1] = acc[7]; dcolors[3 * i + 2] = acc[8];
+    dopac[i] = acc[5];
+    float gmean[3] = { 0.f, 0.f, 0.f }, g6[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    if (!vis) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) dmeans3D[3 * i + k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) dcov3D[6 * (size_t)i + k] = 0.f;
+        if (dsh) for (int k = 0; k < M * 3; k++) dsh[(size_t)i * M * 3 + k] = 0.f;
+        if (dscales) { dscales[3 * i] = 0.f; dscales[3 * i + 1] = 0.f; dscales[3 * i + 2] = 0.f; }
+        if (drots) { drots[4 * i] = 0.f; drots[4 * i + 1] = 0.f; drots[4 * i + 2] = 0.f; drots[4 * i + 3] = 0.f; }
+        return;
+    }
+    const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
+    float c6[6], s[3] = { 0.f, 0.f, 0.f }, q[4] = { 1.f, 0.f, 0.f, 0.f };
+    if (cov3D_in) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = cov3D_in[6 * (size_t)i + k];
+    } else {
+        s[0] = scales[3 * i]; s[1] = scales[3 * i + 1]; s[2] = scales[3 * i + 2];
+        q[0] = rots[4 * i]; q[1] = rots[4 * i + 1]; q[2] = rots[4 * i + 2]; q[3] = rots[4 * i + 3];
+        cov3d_from_scale_rot(s, mod, q, c6);
+    }
+    Ewa e; ewa_project(p, c6, V, W, H, tanfovx, tanfovy, e);
+
+    // conic (xx, xy/2, yy) -> cov2D (a,b,c); the published backward regularises 1/det^2 by 1e-7.
+    const float gA = acc[2], gB = acc[3], gC = acc[4];
+    const float denom = e.a * e.c - e.b * e.b;
+    const float d2inv = 1.f / (denom * denom + 0.0000001f);
+    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+    if (d2inv != 0.f) {
+        dL_da = d2inv * (-e.c * e.c * gA + 2.f * e.b * e.c * gB + (denom - e.a * e.c) * gC);
+        dL_dc = d2inv * (-e.a * e.a * gC + 2.f * e.a * e.b * gB + (denom - e.a * e.c) * gA);
+        dL_db = d2inv * 2.f * (e.b * e.c * gA - (denom + 2.f * e.b * e.b) * gB + e.a * e.b * gC);
+        const float* m0 = e.m0; const float* m1 = e.m1;
+        g6[0] = m0[0] * m0[0] * dL_da + m0[0] * m1[0] * dL_db + m1[0] * m1[0] * dL_dc;
+        g6[3] = m0[1] * m0[1] * dL_da + m0[1] * m1[1] * dL_db + m1[1] * m1[1] * dL_dc;
+        g6[5] = m0[2] * m0[2] * dL_da + m0[2] * m1[2] * dL_db + m1[2] * m1[2] * dL_dc;
+        g6[1] = 2.f * m0[0] * m0[1] * dL_da + (m0[0] * m1[1] + m0[1] * m1[0]) * dL_db + 2.f * m1[0] * m1[1] * dL_dc;
+        g6[2] = 2.f * m0[0] * m0[2] * dL_da + (m0[0] * m1[2] + m0[2] * m1[0]) * dL_db + 2.f * m1[0] * m1[2] * dL_dc;
+        g6[4] = 2.f * m0[2] * m0[1] * dL_da + (m0[1] * m1[2] + m0[2] * m1[1]) * dL_db + 2.f * m1[1] * m1[2] * dL_dc;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) dcov3D[6 * (size_t)i + k] = g6[k];
+
+    // cov2D -> rows of (J R) -> J -> camera-space point -> mean
+    float gJ00 = 0.f, gJ02 = 0.f, gJ11 = 0.f, gJ12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float gm0 = 2.f * e.S0[k] * dL_da + e.S1[k] * dL_db;
+        const float gm1 = 2.f * e.S1[k] * dL_dc + e.S0[k] * dL_db;
+        gJ00 += V[4 * k + 0] * gm0; gJ02 += V[4 * k + 2] * gm0;
+        gJ11 += V[4 * k + 1] * gm1; gJ12 += V[4 * k + 2] * gm1;
+    }
+    const float xmask = (e.txtz < -e.limx || e.txtz > e.limx) ? 0.f : 1.f;
+    const float ymask = (e.tytz < -e.limy || e.tytz > e.limy) ? 0.f : 1.f;
+    const float tz = 1.f / e.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+    const float gtx = xmask * -e.fx * tz2 * gJ02;
+    const float gty = ymask * -e.fy * tz2 * gJ12;
+    const float gtz = -e.fx * tz2 * gJ00 - e.fy * tz2 * gJ11 + (2.f * e.fx * e.tx) * tz3 * gJ02 +
+                      (2.f * e.fy * e.ty) * tz3 * gJ12;
+#pragma unroll
+    for (int k = 0; k < 3; k++) gmean[k] += V[4 * k + 0] * gtx + V[4 * k + 1] * gty + V[4 * k + 2] * gtz;
+
+    // screen-space mean (NDC-scaled) through the projective divide
+    float hom[4]; xform44(p, PM, hom);
+    const float mw = 1.f / (hom[3] + 0.0000001f);
+    const float mul1 = hom[0] * mw * mw, mul2 = hom[1] * mw * mw;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        gmean[k] += (PM[4 * k + 0] * mw - PM[4 * k + 3] * mul1) * acc[0] + (PM[4 * k + 1] * mw - PM[4 * k + 3] * mul2) * acc[1];
+
+    // depth = view.z
+    const float mul3 = V[2] * p[0] + V[6] * p[1] + V[10] * p[2] + V[14];
+#pragma unroll
+    for (int k = 0; k < 3; k++) gmean[k] += (V[4 * k + 2] - V[4 * k + 3] * mul3) * acc[9];
+
+    // colour -> SH coefficients and view direction
+    if (shs) {
+        const float d0[3] = { p[0] - campos[0], p[1] - campos[1], p[2] - campos[2] };
+        const float inv = 1.f / sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
+        const float x = d0[0] * inv, y = d0[1] * inv, z = d0[2] * inv;
+        const float* sh = shs + (size_t)i * M * 3;
+        float* gsh = dsh + (size_t)i * M * 3;
+        const uint32_t cl = clamped[i];
+        float gdir[3] = { 0.f, 0.f, 0.f };
+        for (int ch = 0; ch < 3; ch++) {
+            const float g = ((cl >> ch) & 1u) ? 0.f : acc[6 + ch];
+#define SH(k) sh[(k) * 3 + ch]
+#define GSH(k) gsh[(k) * 3 + ch]
+            float dx_ = 0.f, dy_ = 0.f, dz_ = 0.f;
+            GSH(0) = kC0 * g;
+            if (D > 0) {
+                GSH(1) = -kC1 * y * g; GSH(2) = kC1 * z * g; GSH(3) = -kC1 * x * g;
+                dx_ = -kC1 * SH(3); dy_ = -kC1 * SH(1); dz_ = kC1 * SH(2);
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    GSH(4) = kC2[0] * xy * g; GSH(5) = kC2[1] * yz * g; GSH(6) = kC2[2] * (2.f * zz - xx - yy) * g;
+                    GSH(7) = kC2[3] * xz * g; GSH(8) = kC2[4] * (xx - yy) * g;
+                    dx_ += kC2[0] * y * SH(4) + kC2[2] * 2.f * -x * SH(6) + kC2[3] * z * SH(7) + kC2[4] * 2.f * x * SH(8);
+                    dy_ += kC2[0] * x * SH(4) + kC2[1] * z * SH(5) + kC2[2] * 2.f * -y * SH(6) + kC2[4] * 2.f * -y * SH(8);
+                    dz_ += kC2[1] * y * SH(5) + kC2[2] * 4.f * z * SH(6) + kC2[3] * x * SH(7);
+                    if (D > 2) {
+                        GSH(9) = kC3[0] * y * (3.f * xx - yy) * g; GSH(10) = kC3[1] * xy * z * g;
+                        GSH(11) = kC3[2] * y * (4.f * zz - xx - yy) * g;
+                        GSH(12) = kC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                        GSH(13) = kC3[4] * x * (4.f * zz - xx - yy) * g; GSH(14) = kC3[5] * z * (xx - yy) * g;
+                        GSH(15) = kC3[6] * x * (xx - 3.f * yy) * g;
+                        dx_ += kC3[0] * SH(9) * 6.f * xy + kC3[1] * SH(10) * yz + kC3[2] * SH(11) * -2.f * xy +
+                               kC3[3] * SH(12) * -6.f * xz + kC3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                               kC3[5] * SH(14) * 2.f * xz + kC3[6] * SH(15) * 3.f * (xx - yy);
+                        dy_ += kC3[0] * SH(9) * 3.f * (xx - yy) + kC3[1] * SH(10) * xz +
+                               kC3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + kC3[3] * SH(12) * -6.f * yz +
+                               kC3[4] * SH(13) * -2.f * xy + kC3[5] * SH(14) * -2.f * yz + kC3[6] * SH(15) * -6.f * xy;
+                        dz_ += kC3[1] * SH(10) * xy + kC3[2] * SH(11) * 8.f * yz + kC3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                               kC3[4] * SH(13) * 8.f * xz + kC3[5] * SH(14) * (xx - yy);
+                    }
+                }
+            }
+            for (int k = (D + 1) * (D + 1); k < M; k++) GSH(k) = 0.f;     // coefficients above the active degree
+#undef SH
+#undef GSH
+            gdir[0] += dx_ * g; gdir[1] += dy_ * g; gdir[2] += dz_ * g;
+        }
+        const float dot = x * gdir[0] + y * gdir[1] + z * gdir[2];
+        gmean[0] += (gdir[0] - x * dot) * inv; gmean[1] += (gdir[1] - y * dot) * inv; gmean[2] += (gdir[2] - z * dot) * inv;
+    }
+    dmeans3D[3 * i] = gmean[0]; dmeans3D[3 * i + 1] = gmean[1]; dmeans3D[3 * i + 2] = gmean[2];
+
+    // cov3D -> scale, quaternion (only when the forward built cov3D itself)
+    if (dscales && drots) {
+        float Rm[9]; quat_to_rot(q, Rm);
+        const float sc[3] = { mod * s[0], mod * s[1], mod * s[2] };
+        const float Gs[9] = { g6[0], 0.5f * g6[1], 0.5f * g6[2], 0.5f * g6[1], g6[3], 0.5f * g6[4],
+                              0.5f * g6[2], 0.5f * g6[4], g6[5] };
+        float L[9], gL[9], gR[9];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) L[3 * a + k] = Rm[3 * a + k] * sc[k];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                gL[3 * a + k] = 2.f * (Gs[3 * a] * L[k] + Gs[3 * a + 1] * L[3 + k] + Gs[3 * a + 2] * L[6 + k]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            dscales[3 * i + k] = mod * (gL[k] * Rm[k] + gL[3 + k] * Rm[3 + k] + gL[6 + k] * Rm[6 + k]);
+#pragma unroll
+            for (int a = 0; a < 3; a++) gR[3 * a + k] = gL[3 * a + k] * sc[k];
+        }
+        const float r = q[0], qx = q[1], qy = q[2], qz = q[3];
+        drots[4 * i + 0] = 2.f * (-qz * gR[1] + qy * gR[2] + qz * gR[3] - qx * gR[5] - qy * gR[6] + qx * gR[7]);
+        drots[4 * i + 1] = 2.f * (qy * gR[1] + qz * gR[2] + qy * gR[3] - 2.f * qx * gR[4] - r * gR[5] + qz * gR[6] + r * gR[7] - 2.f * qx * gR[8]);
+        drots[4 * i + 2] = 2.f * (-2.f * qy * gR[0] + qx * gR[1] + r * gR[2] + qx * gR[3] + qz * gR[5] - r * gR[6] + qz * gR[7] - 2.f * qy * gR[8]);
+        drots[4 * i + 3] = 2.f * (-2.f * qz * gR[0] - r * gR[1] + qx * gR[2] + r * gR[3] - 2.f * qz * gR[4] + qy * gR[5] + qx * gR[6] + qy * gR[7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
+                                                       const float* __restrict__ V, uint8_t* __restrict__ present) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
+    float t[3]; xform43(p, V, t);
+    present[i] = t[2] > 0.2f ? 1 : 0;
+}
+
+}  // namespace
+
+hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
+                                 const float* opac, const float* scales, float mod, const float* rots,
+                                 const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_preprocess, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, colors, opac, scales,
+                       mod, rots, cov3D, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.tanfovx, cam.tanfovy, radii,
+                       g.rec, g.rect, g.offsets, g.clamped);
+    return hipGetLastError();
+}
+
+hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* means3D, const float* shs,
+                                          const float* scales, float mod, const float* rots, const float* cov3D,
+                                          EgsCamera cam, const int32_t* radii, EgsGeomPtrs g, const float* grad_acc,
+                                          int colors_given, float* dmeans2D, float* dcolors, float* dopac,
+                                          float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,
+                                          hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_preprocess_backward, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D,
+                       colors_given ? nullptr : shs, scales, mod, rots, cov3D, cam.view, cam.proj, cam.campos, cam.W,
+                       cam.H, cam.tanfovx, cam.tanfovy, radii, g.clamped, grad_acc, dmeans2D, dcolors, dopac, dmeans3D,
+                       dcov3D, colors_given ? nullptr : dsh, cov3D ? nullptr : dscales, cov3D ? nullptr : drots);
+    return hipGetLastError();
+}
+
+hipError_t egs_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+    return hipGetLastError();
+}

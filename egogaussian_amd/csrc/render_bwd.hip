@@ -1,0 +1,171 @@
+// render_bwd.hip -- back-to-front replay of the compositing and per-splat gradient accumulation (gfx950).
+// Replaces the backward `render` stage of the upstream op reached through loss.backward() at
+// /root/reference/trainers/train_static.py:110.
+//
+// Same wave-per-8x8-quadrant mapping as render_fwd.hip (no workgroup barriers; bounding-box ballot as the
+// work list; wave-private LDS slice read with a uniform address).  What is specific to the backward:
+//   * the replay starts at the wave's maximum n_contrib, not at the end of the tile list, so saturated
+//     tiles do not walk the occluded tail;
+//   * the colour / depth / alpha channels share ONE running accumulator: with u_j = c_j . dL/dC + d_j dL/dD
+//     + dL/dA the published per-channel recurrences collapse to U <- a_last u_last + (1 - a_last) U and
+//     dL/dalpha_j = T_j (u_j - U_j) - T_final/(1-a_j) bg . dL/dC   (algebraically identical);
+//   * the 10 per-splat partial sums (mean2D.xy, conic xx/xy/yy, opacity, rgb, depth) are reduced across the
+//     64 lanes with gfx950's v_permlane32_swap / v_permlane16_swap "transpose-and-add" (5+3 instructions
+//     fold ten registers into three) followed by four DPP row steps on those three -- 29 VALU instead of 60
+//     for ten independent butterflies -- and land in ten different lanes, which issue ONE global_atomic_add_f32
+//     instruction into the Gaussian's 48-byte accumulator line (egs_common.h) instead of ten.
+#include "egs_common.h"
+#include "blend_common.h"
+
+namespace {
+
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+
+// a' + b' where (a', b') = halves-swapped (a, b): lanes 0-31 <- a[l] + a[l+32], lanes 32-63 <- b[l-32] + b[l].
+__device__ __forceinline__ float fold32(float a, float b) {
+    const uint2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// rows (16 lanes): out = [a.r0+a.r1, b.r0+b.r1, a.r2+a.r3, b.r2+b.r3]
+__device__ __forceinline__ float fold16(float a, float b) {
+    const uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+// all 16 lanes of every row end up holding that row's sum
+__device__ __forceinline__ float row_sum(float v) {
+    v = dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);      // row_half_mirror
+    v = dpp_add<0x140>(v);      // row_mirror
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_render_backward(
+    int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+    const float* __restrict__ dL_dalpha, float* __restrict__ grad_acc) {
+    __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
+    const int tile = egs_tile_of_block(blockIdx.x, n_tiles);
+    if (tile < 0) return;
+    const unsigned lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    float4* my = lds[q];
+    const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
+    if (qx0 >= W || qy0 >= H) return;
+    const int px = qx0 + (int)(lane & 7), py = qy0 + (int)(lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint32_t qx1 = (uint32_t)min(qx0 + 7, W - 1), qy1 = (uint32_t)min(qy0 + 7, H - 1);
+
+    const uint2 range = ranges[tile];
+    const uint32_t* list = point_list + range.x;
+
+    float T_final = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f, g_a = 0.f;
+    uint32_t last = 0;
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        T_final = final_T[pix]; last = n_contrib[pix];
+        g_r = dL_dcolor[pix]; g_g = dL_dcolor[HW + pix]; g_b = dL_dcolor[2 * HW + pix];
+        if (dL_ddepth) g_d = dL_ddepth[pix];
+        if (dL_dalpha) g_a = dL_dalpha[pix];
+    }
+    const float bg_term = -T_final * (bg[0] * g_r + bg[1] * g_g + bg[2] * g_b);
+    uint32_t wmax = last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
+    if (wmax == 0) return;
+
+    // which of the ten reduced sums this lane publishes (see the fold order below), or -1
+    int slot = -1;
+    {
+        const unsigned r = lane >> 4, c = lane & 15;
+        if (c == 0) slot = r == 0 ? 0 : r == 1 ? 2 : r == 2 ? 1 : 3;
+        else if (c == 1) slot = r == 0 ? 4 : r == 1 ? 6 : r == 2 ? 5 : 7;
+        else if (c == 2 && (r & 1) == 0) slot = r == 0 ? 8 : 9;
+    }
+    const unsigned csel = lane & 15;
+
+    float T = T_final, U = 0.f, last_u = 0.f, last_alpha = 0.f;
+
+    const int nb = (int)((wmax + 63) / 64);
+    int b = nb - 1;
+    uint32_t id_next = (uint32_t)b * 64 + lane < wmax ? list[(uint32_t)b * 64 + lane] : 0u;
+    float4 r0, r1, r2;
+    egs_load_rec(rec, id_next, (uint32_t)b * 64 + lane < wmax, r0, r1, r2);
+    uint32_t id_cur = id_next;
+    id_next = b >= 1 ? list[(uint32_t)(b - 1) * 64 + lane] : 0u;
+
+    for (; b >= 0; b--) {
+        const uint32_t base = (uint32_t)b * 64;
+        const float4 c0 = r0, c1 = r1, c2 = r2;
+        const uint32_t my_id = id_cur;
+        const bool have = base + lane < wmax;
+        egs_load_rec(rec, id_next, b >= 1, r0, r1, r2);
+        id_cur = id_next;
+        id_next = b >= 2 ? list[(uint32_t)(b - 2) * 64 + lane] : 0u;
+
+        uint64_t mask = __ballot(have && egs_bbox_hits(c2, (uint32_t)qx0, qx1, (uint32_t)qy0, qy1));
+        if (mask == 0ull) continue;
+        my[lane * 3 + 0] = c0; my[lane * 3 + 1] = c1; my[lane * 3 + 2] = c2;
+        __builtin_amdgcn_wave_barrier();
+        while (mask) {
+            const int j = 63 - __builtin_clzll(mask);
+            mask &= ~(1ull << j);
+            const float4 s0 = my[j * 3 + 0], s1 = my[j * 3 + 1], s2 = my[j * 3 + 2];
+            const float dx = s0.x - pxf, dy = s0.y - pyf;
+            float G;
+            const float alpha = egs_alpha(dx, dy, s1.x, s1.y, s1.z, s0.w, G);
+            const bool contrib = (base + (uint32_t)j + 1u <= last) && alpha >= 0.f;
+            if (__ballot(contrib) == 0ull) continue;
+            const float a = contrib ? alpha : 0.f;
+            const float rcp = __builtin_amdgcn_rcpf(1.f - a);
+            const float Tn = T * rcp;                                   // transmittance in front of this splat
+            const float w = contrib ? a * Tn : 0.f;
+            const float u = fmaf(s1.w, g_r, fmaf(s2.x, g_g, fmaf(s2.y, g_b, fmaf(s0.z, g_d, g_a))));
+            const float Un = fmaf(last_alpha, last_u - U, U);
+            float dLda = (u - Un) * Tn;
+            dLda = fmaf(bg_term, rcp, dLda);
+            dLda = contrib ? dLda : 0.f;
+            T = contrib ? Tn : T; U = contrib ? Un : U; last_u = contrib ? u : last_u; last_alpha = contrib ? a : last_alpha;
+
+            const float dL_dG = s0.w * dLda;
+            const float gdx = G * dx, gdy = G * dy;
+            float v0 = dL_dG * (-gdx * s1.x - gdy * s1.y);             // d/d mean2D.x (pixel units)
+            float v1 = dL_dG * (-gdy * s1.z - gdx * s1.y);             // d/d mean2D.y
+            const float h = -0.5f * dL_dG;
+            float v2 = h * gdx * dx, v3 = h * gdx * dy, v4 = h * gdy * dy;   // conic xx, xy (half), yy
+            float v5 = G * dLda;                                        // opacity
+            float v6 = w * g_r, v7 = w * g_g, v8 = w * g_b, v9 = w * g_d;
+
+            // 64-lane sums of v0..v9, ten results in ten lanes
+            const float s01 = fold32(v0, v1), s23 = fold32(v2, v3), s45 = fold32(v4, v5), s67 = fold32(v6, v7),
+                        s89 = fold32(v8, v9);
+            float t0 = fold16(s01, s23);       // rows: v0 v2 v1 v3
+            float t1 = fold16(s45, s67);       // rows: v4 v6 v5 v7
+            float t2 = fold16(s89, s89);       // rows: v8 v8 v9 v9
+            t0 = row_sum(t0); t1 = row_sum(t1); t2 = row_sum(t2);
+            const float out = csel == 0 ? t0 : csel == 1 ? t1 : t2;
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)my_id, j);
+            if (slot >= 0) unsafeAtomicAdd(grad_acc + (size_t)gid * EGS_GRAD_STRIDE + slot, out);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
+                                      EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
+                                      const float* dL_dalpha, float* grad_acc, hipStream_t s) {
+    const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
+    const int n_tiles = gx * gy;
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_render_backward, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
+                       im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
+                       grad_acc);
+    return hipGetLastError();
+}

@@ -1,0 +1,108 @@
+// render_fwd.hip -- front-to-back compositing of colour, depth and alpha for gfx950.
+// Replaces the forward `render` stage of the upstream op called from
+// /root/reference/gaussian_renderer/__init__.py:90-98.
+//
+// Mapping (wave64-first, not a 16x16-thread block port):
+//   * a workgroup is one 16x16 tile = 4 waves; each WAVE owns one 8x8 pixel quadrant and runs on its
+//     own -- there is no __syncthreads() anywhere, a wave whose 64 pixels are saturated simply leaves;
+//   * the tile's sorted splat list is consumed in batches of 64: lane j fetches list entry j's packed
+//     48-byte record (three dwordx4, L2-resident gather), tests the record's pixel bounding box against
+//     the wave's quadrant, and a 64-bit ballot becomes the work list -- splats that cannot reach the
+//     quadrant cost nothing (s_ff1 over the mask), which removes roughly half of the (pixel, splat)
+//     evaluations of a whole-tile loop at 3DGS-typical footprints;
+//   * surviving records are parked in a wave-private 3 KiB LDS slice and re-read with a wave-uniform
+//     address (hardware broadcast, conflict-free) -- the LDS is a register-file extension here, not a
+//     cross-wave exchange;
+//   * the next batch's ids and records are issued before the current batch is blended, so the gather
+//     latency hides under VALU work.
+// Arithmetic: alpha evaluation is shared with the backward (blend_common.h) so both make identical
+// keep/skip decisions.
+#include "egs_common.h"
+#include "blend_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_render_forward(
+    int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
+    float* __restrict__ out_depth, float* __restrict__ out_alpha, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib) {
+    __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
+    const int tile = egs_tile_of_block(blockIdx.x, n_tiles);
+    if (tile < 0) return;
+    const unsigned lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    float4* my = lds[q];
+    const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
+    if (qx0 >= W || qy0 >= H) return;                             // quadrant entirely outside the image
+    const int px = qx0 + (int)(lane & 7), py = qy0 + (int)(lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint32_t qx1 = (uint32_t)min(qx0 + 7, W - 1), qy1 = (uint32_t)min(qy0 + 7, H - 1);
+
+    const uint2 range = ranges[tile];
+    const uint32_t n = range.y - range.x;
+    const uint32_t* list = point_list + range.x;
+
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f, Aacc = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    // software pipeline: ids two batches ahead, records one batch ahead
+    uint32_t id_next = lane < n ? list[lane] : 0u;
+    float4 r0, r1, r2;
+    egs_load_rec(rec, id_next, lane < n, r0, r1, r2);
+    id_next = 64 + lane < n ? list[64 + lane] : 0u;
+
+    for (uint32_t base = 0; base < n; base += 64) {
+        const float4 c0 = r0, c1 = r1, c2 = r2;
+        const bool have = base + lane < n;
+        // issue the next batch's gathers now
+        egs_load_rec(rec, id_next, base + 64 + lane < n, r0, r1, r2);
+        id_next = base + 128 + lane < n ? list[base + 128 + lane] : 0u;
+
+        uint64_t mask = __ballot(have && egs_bbox_hits(c2, (uint32_t)qx0, qx1, (uint32_t)qy0, qy1));
+        if (mask == 0ull) continue;
+        my[lane * 3 + 0] = c0; my[lane * 3 + 1] = c1; my[lane * 3 + 2] = c2;
+        __builtin_amdgcn_wave_barrier();
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const float4 s0 = my[j * 3 + 0], s1 = my[j * 3 + 1], s2 = my[j * 3 + 2];
+            float G;
+            const float alpha = egs_alpha(s0.x - pxf, s0.y - pyf, s1.x, s1.y, s1.z, s0.w, G);
+            // alpha < 0 encodes "skip" (power > 0 or alpha < 1/255)
+            const float test_T = T * (1.f - alpha);
+            const bool live = !done && alpha >= 0.f;
+            const bool stop = live && test_T < 0.0001f;
+            const bool add = live && !stop;
+            const float w = add ? alpha * T : 0.f;
+            C0 = fmaf(s1.w, w, C0); C1 = fmaf(s2.x, w, C1); C2 = fmaf(s2.y, w, C2);
+            Dacc = fmaf(s0.z, w, Dacc); Aacc += w;
+            T = add ? test_T : T;
+            last = add ? base + (uint32_t)j + 1u : last;
+            done = done || stop;
+            if (__ballot(!done) == 0ull) { mask = 0ull; base = n; }      // whole quadrant saturated
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        final_T[pix] = T; n_contrib[pix] = last;
+        out_color[pix] = fmaf(T, bg[0], C0); out_color[HW + pix] = fmaf(T, bg[1], C1);
+        out_color[2 * HW + pix] = fmaf(T, bg[2], C2);
+        out_depth[pix] = Dacc; out_alpha[pix] = Aacc;
+    }
+}
+
+}  // namespace
+
+hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
+                                     EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha,
+                                     hipStream_t s) {
+    const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
+    const int n_tiles = gx * gy;
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_render_forward, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
+                       im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib);
+    return hipGetLastError();
+}

@@ -1,0 +1,73 @@
+"""ctypes binding of libegs_raster.so (C ABI: include/egs_raster.h).
+
+There is no fallback: if the shared library is missing or cannot be loaded this module raises, and so
+does every op built on it.  Build it with `python __graft_entry__.py` or `make -C egogaussian_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libegs_raster.so")
+ABI_VERSION = 1
+
+vp, f32, i32, i64 = C.c_void_p, C.c_float, C.c_int, C.c_int64
+
+
+class GeomLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("rec", "rect", "offsets", "clamped", "scan_scratch", "total")]
+
+
+class BinningLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("keys_a", "keys_b", "vals_a", "vals_b", "hist", "spine")] + \
+               [(n, C.c_int) for n in ("sorted_in_b", "key_bits", "passes")]
+
+
+class ImageLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("ranges", "final_T", "n_contrib")]
+
+
+# name -> (restype, argtypes); every symbol include/egs_raster.h declares
+SIGNATURES = {
+    "egs_abi_version": (C.c_int, []),
+    "egs_error_string": (C.c_char_p, [C.c_int]),
+    "egs_device_info": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    "egs_geom_bytes": (C.c_size_t, [i32]),
+    "egs_binning_bytes": (C.c_size_t, [i64, i32, i32]),
+    "egs_image_bytes": (C.c_size_t, [i32, i32]),
+    "egs_backward_scratch_bytes": (C.c_size_t, [i32]),
+    "egs_get_geom_layout": (C.c_int, [i32, C.POINTER(GeomLayout)]),
+    "egs_get_binning_layout": (C.c_int, [i64, i32, i32, C.POINTER(BinningLayout)]),
+    "egs_get_image_layout": (C.c_int, [i32, i32, C.POINTER(ImageLayout)]),
+    "egs_forward_geometry": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, f32, f32,
+                                       i32, vp, vp, C.POINTER(i64), vp, i32]),
+    "egs_forward_render": (C.c_int, [i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
+    "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, f32, f32,
+                               vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
+    "egs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises RuntimeError when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the MI355X rasterizer has no CPU or PyTorch fallback. "
+            "Build it first (python -c 'import __graft_entry__ as g; g.build()' or make -C egogaussian_amd/csrc).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    if lib.egs_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libegs_raster.so ABI {lib.egs_abi_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise RuntimeError(f"libegs_raster: {load().egs_error_string(code).decode()} (code {code})")

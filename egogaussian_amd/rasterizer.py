@@ -1,0 +1,106 @@
+"""Python surface of the drop-in `diff_gaussian_rasterization` package.
+
+The reference constructs these objects at /root/reference/gaussian_renderer/__init__.py:38-53 and
+/root/reference/gaussian_renderer/render_helper.py:15-28,61 and calls the module at
+/root/reference/gaussian_renderer/__init__.py:90-98 and render_helper.py:63 (SURVEY.md section 8a rows
+a-2, a-3, a-12):
+
+    GaussianRasterizationSettings(image_height=, image_width=, tanfovx=, tanfovy=, bg=, scale_modifier=,
+                                  viewmatrix=, projmatrix=, sh_degree=, campos=, prefiltered=, debug=)
+    GaussianRasterizer(raster_settings)(means3D=, means2D=, opacities=, shs=|colors_precomp=,
+                                        scales=+rotations= | cov3D_precomp=) -> (color, radii, depth, alpha)
+
+`means2D` is never read; it only receives the screen-space gradient (NDC-scaled), which the reference's
+densification statistic consumes (/root/reference/scene/gaussian_model.py:735-740).
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
+            rs.campos, rs.prefiltered, rs.debug)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img,
+                              alpha)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, alpha = ctx.saved_tensors
+        H, W = int(rs.image_height), int(rs.image_width)
+        dev = means3D.device
+        if grad_color is None:
+            grad_color = torch.zeros((3, H, W), device=dev)
+        if grad_depth is None:
+            grad_depth = torch.empty(0, device=dev)
+        if grad_alpha is None:
+            grad_alpha = torch.empty(0, device=dev)
+        (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = _C.rasterize_gaussians_backward(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos, geom,
+            ctx.num_rendered, binning, img, alpha, rs.debug)
+        none_if_absent = lambda g, x: g if x.numel() != 0 else None
+        return (g_means3D, g_means2D, none_if_absent(g_sh, sh), none_if_absent(g_colors, colors_precomp),
+                g_opac, none_if_absent(g_scales, scales),
+                none_if_absent(g_rots, rotations), none_if_absent(g_cov3D, cov3Ds_precomp), None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("GaussianRasterizer: pass exactly one of `shs` or `colors_precomp`")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("GaussianRasterizer: pass exactly one of (`scales`, `rotations`) or `cov3D_precomp`")
+        empty = torch.empty(0, device=means3D.device, dtype=torch.float32)
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)

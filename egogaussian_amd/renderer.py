@@ -1,0 +1,78 @@
+"""Host-side mirror of the reference's render boundary: render() and get_render_label().
+
+Same names, arguments, argument meaning and return dict as /root/reference/gaussian_renderer/__init__.py:18-107
+and /root/reference/gaussian_renderer/render_helper.py:7-64, written
+against this package's rasterizer so a trainer can import it in place of `gaussian_renderer`.  Tensors are
+created on the point cloud's own device (the reference hard-codes "cuda").
+"""
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def get_raster_settings(viewpoint_camera, pc, bg_color, scaling_modifier=1.0):
+    return GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, rot_cov=False,
+           accum_R=None, which_object=None, during_training=False):
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0       # harvests d loss / d mean2D
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    rasterizer = GaussianRasterizer(raster_settings=get_raster_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
+
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        if rot_cov:
+            cov3D_precomp = pc.get_rotated_covariance(accum_R, which_object, during_training, scaling_modifier)
+        else:
+            cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+
+    shs = colors_precomp = None
+    if override_color is not None:
+        colors_precomp = override_color
+    elif pipe.convert_SHs_python:
+        from .sh import eval_sh
+        feats = pc.get_features
+        shs_view = feats.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+        dirs = xyz - viewpoint_camera.camera_center.repeat(feats.shape[0], 1)
+        dirs = dirs / dirs.norm(dim=1, keepdim=True)
+        colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dirs) + 0.5, 0.0)
+    else:
+        shs = pc.get_features
+
+    image, radii, depth, alpha = rasterizer(means3D=xyz, means2D=screenspace_points, shs=shs,
+                                            colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales,
+                                            rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+            "depth": depth, "alpha": alpha}
+
+
+def get_pts_label_as_rgb(gaussians_label):
+    return gaussians_label.reshape(-1, 1).float().expand(-1, 3).contiguous()
+
+
+def gaussians_to_label_rendervar(gaussians):
+    xyz = gaussians.get_xyz.detach()
+    return {"means3D": xyz, "colors_precomp": get_pts_label_as_rgb(gaussians.get_label),
+            "rotations": gaussians.get_rotation.detach(), "opacities": gaussians.get_opacity.detach(),
+            "scales": gaussians.get_scaling.detach(), "means2D": torch.zeros_like(xyz) + 0}
+
+
+def get_render_label(viewpoint_camera, pc, bg_color):
+    """Per-Gaussian scalar label rendered as a grey colour through a fresh rasterizer (object segmentation)."""
+    renderer = GaussianRasterizer(get_raster_settings(viewpoint_camera, pc, bg_color))
+    label, _, _, _ = renderer(**gaussians_to_label_rendervar(pc))
+    return label

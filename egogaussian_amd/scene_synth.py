@@ -107,3 +107,59 @@ def perturb_student(scene, seed=1):
     out["xyz"] += rng.normal(0, 0.01, out["xyz"].shape).astype(np.float32)
     out["features"][:, :1] += rng.normal(0, 0.1, out["features"][:, :1].shape).astype(np.float32)
     return out
+
+
+class SynthGaussians:
+    """Minimal parameter holder with the getters render() reads -- a stand-in for
+    scene.gaussian_model.GaussianModel (/root/reference/scene/gaussian_model.py:125-171) over a synthetic scene.
+    Raw parameters are leaf tensors; activations match the reference (exp, sigmoid, normalize)."""
+
+    def __init__(self, scene, device="cpu", sh_degree=0, requires_grad=True):
+        from . import covariance as _cov
+        self._cov = _cov
+        t = lambda a: torch.tensor(a, device=device).requires_grad_(requires_grad)
+        self._xyz = t(scene["xyz"])
+        self._features_dc = t(scene["features"][:, :1].copy())
+        self._features_rest = t(scene["features"][:, 1:].copy())
+        self._scaling = t(scene["log_scale"])
+        self._rotation = t(scene["quat"])
+        self._opacity = t(scene["opacity_logit"])
+        n = scene["xyz"].shape[0]
+        self._label = torch.zeros((n, 1), device=device).requires_grad_(requires_grad)
+        self._is_object = torch.zeros((n, 1), device=device)
+        self.active_sh_degree = sh_degree
+        self.max_sh_degree = sh_degree
+        self.trainable_object_move = None
+
+    def parameters(self):
+        return [self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity]
+
+    @property
+    def get_xyz(self): return self._xyz
+    @property
+    def get_scaling(self): return torch.exp(self._scaling)
+    @property
+    def get_rotation(self): return torch.nn.functional.normalize(self._rotation)
+    @property
+    def get_opacity(self): return torch.sigmoid(self._opacity)
+    @property
+    def get_features(self): return torch.cat((self._features_dc, self._features_rest), dim=1)
+    @property
+    def get_label(self): return self._label
+    @property
+    def get_is_object(self): return self._is_object
+
+    def get_covariance(self, scaling_modifier=1):
+        return self._cov.covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
+
+    def get_rotated_covariance(self, accum_R, which_object, during_training, scaling_modifier=1):
+        rot_L = self.trainable_object_move.rot_L if (during_training and self.trainable_object_move is not None) else None
+        return self._cov.rotated_covariance_from_scaling_rotation(
+            self.get_scaling, scaling_modifier, self._rotation, accum_R, self._is_object, which_object, rot_L)
+
+
+class Pipe:
+    """PipelineParams as every stage runs it: /root/reference/arguments/__init__.py:66-68, /root/reference/train.py:49."""
+    convert_SHs_python = False
+    compute_cov3D_python = True
+    debug = False

@@ -1,0 +1,137 @@
+/*
+ * egs_raster.h -- C ABI of libegs_raster.so, the MI355X (gfx950) differentiable 3D Gaussian
+ * tile rasterizer behind EgoGaussian's gaussian_renderer.render() path.
+ *
+ * What each entry point replaces.  The reference binds the CUDA extension
+ * `diff_gaussian_rasterization._C` (an un-vendored submodule: ashawkey/diff-gaussian-rasterization
+ * @ 8829d14f, /root/reference/README.md:26, /root/reference/.gitmodules:1-3) through the Python
+ * surface imported at
+ *     /root/reference/gaussian_renderer/__init__.py:14      (GaussianRasterizationSettings, GaussianRasterizer)
+ *     /root/reference/gaussian_renderer/render_helper.py:3
+ * and invoked at
+ *     /root/reference/gaussian_renderer/__init__.py:90-98   (training call: shs + cov3D_precomp)
+ *     /root/reference/gaussian_renderer/render_helper.py:61-63 (label call: colors_precomp + scales/rotations)
+ *   egs_forward_geometry + egs_forward_render  <->  _C.rasterize_gaussians          (forward)
+ *   egs_backward                                <->  _C.rasterize_gaussians_backward (backward)
+ *   egs_mark_visible                            <->  _C.mark_visible
+ *   egs_*_bytes / egs_*_layout                  <->  the three resizable byte buffers
+ *                                                    (geomBuffer, binningBuffer, imgBuffer) the
+ *                                                    upstream op allocates through callbacks
+ * The forward is split in two because the number of (Gaussian, tile) instances R is data dependent:
+ * egs_forward_geometry returns R on the host, the caller sizes the binning buffer, then calls
+ * egs_forward_render.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers unless marked HOST.  fp32, contiguous, row-major.
+ *   - The library never allocates or frees device memory and keeps no global state; every buffer is
+ *     owned by the caller and must stay alive until the work enqueued on `stream` has completed.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it.  egs_forward_geometry is
+ *     the only call that waits on the stream (one 8-byte device->host read of R).
+ *   - Matrices use the reference's row-vector layout (/root/reference/scene/cameras.py:67-69):
+ *     viewmatrix = W2V^T, projmatrix = W2V^T * P^T, 16 floats each.
+ *   - Optional inputs are NULL when absent: exactly one of {shs, colors_precomp} and exactly one of
+ *     {cov3D_precomp, (scales, rotations)} must be non-NULL.
+ *   - Return value: 0 on success; EGS_ERR_* (negative) for argument errors; a positive hipError_t if
+ *     the HIP runtime reported one.  Nothing throws across this boundary.
+ *   - debug != 0 synchronises the stream and checks for errors after every kernel.
+ */
+#ifndef EGS_RASTER_H
+#define EGS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGS_ABI_VERSION 1
+#define EGS_TILE 16                 /* tile edge in pixels; part of the parity contract */
+#define EGS_MAX_SH_DEGREE 3
+
+#define EGS_ERR_ARG        (-1)     /* NULL / inconsistent arguments */
+#define EGS_ERR_MODE       (-2)     /* colour or covariance mode not "exactly one of" */
+#define EGS_ERR_RANGE      (-3)     /* size outside supported range (image > 65535 px, R >= 2^32, degree > 3) */
+#define EGS_ERR_NO_DEVICE  (-4)     /* no HIP device / wrong architecture */
+
+int         egs_abi_version(void);
+const char* egs_error_string(int code);
+/* Name of the device the current HIP context runs on and its gcnArchName; returns 0 or an error. */
+int         egs_device_info(char* name, int name_len, char* arch, int arch_len, int* compute_units);
+
+/* ---- buffer sizes (bytes) -------------------------------------------------------------------- */
+size_t egs_geom_bytes(int P);
+size_t egs_binning_bytes(int64_t R, int width, int height);
+size_t egs_image_bytes(int width, int height);
+size_t egs_backward_scratch_bytes(int P);
+
+/* ---- buffer layouts, for tests and tools: byte offsets of the named sub-arrays ----------------- */
+typedef struct egs_geom_layout {
+    size_t rec;            /* float4[P][3]  packed splat record: (x, y, depth, opacity | conA, conB, conC, r | g, b, bbox_x, bbox_y) */
+    size_t rect;           /* uint32[P][2]  tile rect: (x0 | x1<<16, y0 | y1<<16) */
+    size_t offsets;        /* uint32[P]     inclusive scan of tiles touched */
+    size_t clamped;        /* uint8[P]      bit c set <=> colour channel c was clamped at 0 */
+    size_t scan_scratch;   /* uint32[..]    spine of the scan */
+    size_t total;          /* uint64[1]     R */
+} egs_geom_layout;
+typedef struct egs_binning_layout {
+    size_t keys_a, keys_b; /* uint64[R] ping / pong */
+    size_t vals_a, vals_b; /* uint32[R] ping / pong */
+    size_t hist;           /* uint32[..] per-block digit histograms */
+    size_t spine;          /* uint32[..] scan spine */
+    int    sorted_in_b;    /* 1 if the sorted result lives in (keys_b, vals_b) */
+    int    key_bits;       /* low key bits sorted: 32 + bits(tile count) */
+    int    passes;         /* radix passes */
+} egs_binning_layout;
+typedef struct egs_image_layout {
+    size_t ranges;         /* uint32[tiles][2] */
+    size_t final_T;        /* float[H*W] */
+    size_t n_contrib;      /* uint32[H*W] */
+} egs_image_layout;
+int egs_get_geom_layout(int P, egs_geom_layout* out);
+int egs_get_binning_layout(int64_t R, int width, int height, egs_binning_layout* out);
+int egs_get_image_layout(int width, int height, egs_image_layout* out);
+
+/* ---- forward, part 1: per-Gaussian geometry + scan  (upstream: preprocess + InclusiveSum) ------ */
+int egs_forward_geometry(
+    int P, int sh_degree, int sh_coeffs /* M: coefficients per channel in `shs` */,
+    const float* means3D /*[P,3]*/, const float* shs /*[P,M,3] or NULL*/, const float* colors_precomp /*[P,3] or NULL*/,
+    const float* opacities /*[P]*/, const float* scales /*[P,3] or NULL*/, float scale_modifier,
+    const float* rotations /*[P,4] or NULL*/, const float* cov3D_precomp /*[P,6] or NULL*/,
+    const float* viewmatrix /*[16]*/, const float* projmatrix /*[16]*/, const float* campos /*[3]*/,
+    int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
+    int32_t* radii /*[P] out*/, void* geom_buffer, int64_t* num_rendered /*HOST out: R*/,
+    void* stream, int debug);
+
+/* ---- forward, part 2: duplicate, sort, tile ranges, blend  (upstream: duplicateWithKeys,
+ *      SortPairs, identifyTileRanges, render) -------------------------------------------------- */
+int egs_forward_render(
+    int P, int64_t R, const float* background /*[3]*/, int width, int height,
+    const void* geom_buffer, void* binning_buffer, void* image_buffer,
+    float* out_color /*[3,H,W]*/, float* out_depth /*[1,H,W]*/, float* out_alpha /*[1,H,W]*/,
+    void* stream, int debug);
+
+/* ---- backward  (upstream: render backward + computeCov2D backward + preprocess backward) ------- */
+int egs_backward(
+    int P, int sh_degree, int sh_coeffs, int64_t R,
+    const float* background, const float* means3D, const float* shs, const float* colors_precomp,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    int width, int height, float tan_fovx, float tan_fovy,
+    const int32_t* radii, const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+    const float* dL_dout_color /*[3,H,W]*/, const float* dL_dout_depth /*[1,H,W] or NULL*/,
+    const float* dL_dout_alpha /*[1,H,W] or NULL*/,
+    float* dL_dmeans2D /*[P,3] out, NDC-scaled (x 0.5*W, 0.5*H), z = 0*/,
+    float* dL_dcolors /*[P,3] out*/, float* dL_dopacity /*[P] out*/, float* dL_dmeans3D /*[P,3] out*/,
+    float* dL_dcov3D /*[P,6] out*/, float* dL_dsh /*[P,M,3] out or NULL*/,
+    float* dL_dscales /*[P,3] out or NULL*/, float* dL_drotations /*[P,4] out or NULL*/,
+    void* scratch /* egs_backward_scratch_bytes(P) */, void* stream, int debug);
+
+/* ---- frustum test only  (upstream: markVisible) -------------------------------------------------- */
+int egs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present /*[P] out, 0/1*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGS_RASTER_H */

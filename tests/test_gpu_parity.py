@@ -1,0 +1,215 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bars (BASELINE.json north_star): tile / sort indices bit-exact; RGB / depth / alpha and gradients within
+1e-4 relative fp32.  Two fp32 effects are handled explicitly rather than by loosening the bar:
+  * exp() on the GPU (v_exp_f32) and in glibc differ in the last ulp, so a (pixel, splat) pair whose alpha sits
+    within ~1e-6 relative of the 1/255 or 1e-4 thresholds can be kept on one side and skipped on the other.
+    Such pixels are rare and are counted: the strict bound applies to all but a 1e-4 fraction of pixels, and the
+    exceptions are bounded by the size of one threshold-level contribution.
+  * gradient sums are accumulated in a different order (wave reductions + atomics).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.common import make_inputs, seeded_grads, rel_err, outlier_fraction
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _to(d, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+def hip_forward(d, dev, debug=False):
+    from egogaussian_amd import _C
+    g = _to(d, dev)
+    e = torch.empty(0, device=dev)
+    out = _C.rasterize_gaussians(g["bg"], g["means3D"], g.get("colors_precomp", e), g["opacities"], g.get("scales", e),
+                                 g.get("rotations", e), g["scale_modifier"], g.get("cov3D_precomp", e), g["viewmatrix"],
+                                 g["projmatrix"], g["tanfovx"], g["tanfovy"], g["image_height"], g["image_width"],
+                                 g.get("shs", e), g["sh_degree"], g["campos"], False, debug)
+    return g, out
+
+
+def hip_backward(g, out, grads, dev, debug=False):
+    from egogaussian_amd import _C
+    R, color, depth, alpha, radii, geom, binning, img = out
+    e = torch.empty(0, device=dev)
+    gc, gd, ga = [x.to(dev) for x in grads]
+    return _C.rasterize_gaussians_backward(g["bg"], g["means3D"], radii, g.get("colors_precomp", e), g.get("scales", e),
+                                           g.get("rotations", e), g["scale_modifier"], g.get("cov3D_precomp", e),
+                                           g["viewmatrix"], g["projmatrix"], g["tanfovx"], g["tanfovy"], gc, gd, ga,
+                                           g.get("shs", e), g["sh_degree"], g["campos"], geom, R, binning, img, alpha, debug)
+
+
+def oracle_forward(d, nthreads=8):
+    from oracle.oracle import Oracle
+    o = Oracle(np.float32, nthreads=nthreads)
+    return o, o.forward(**d)
+
+
+CASES = [
+    # N, H, W, seed, deg, mode, scale_mul
+    (3000, 64, 64, 0, 0, "sh_cov", 1.0),       # BASELINE config 1 shape (training call)
+    (3000, 70, 100, 1, 0, "sh_cov", 4.0),      # ragged image (not a multiple of 16), long lists, saturation
+    (2000, 96, 128, 2, 3, "sh_cov", 2.0),      # SH degree 3
+    (2000, 96, 128, 3, 0, "col_sr", 2.0),      # label call: colours + scale/rotation
+    (2000, 50, 37, 4, 2, "sh_sr", 3.0),
+    (2000, 64, 80, 5, 0, "col_cov", 3.0),
+    (20000, 270, 480, 6, 0, "sh_cov", 2.0),
+]
+
+
+@pytest.mark.parametrize("N,H,W,seed,deg,mode,smul", CASES)
+def test_forward_and_backward_parity(N, H, W, seed, deg, mode, smul):
+    from egogaussian_amd import _C
+    dev = _dev()
+    d = make_inputs(N, H, W, seed, deg, mode, scale_mul=smul)
+    o, st = oracle_forward(d)
+    g, out = hip_forward(d, dev, debug=True)
+    R, color, depth, alpha, radii, geom, binning, img = out
+    torch.cuda.synchronize()
+
+    # ---- integer stages: bit-exact -------------------------------------------------------------------
+    assert R == st["R"], f"R {R} vs oracle {st['R']}"
+    assert np.array_equal(radii.cpu().numpy(), st["radii"])
+    gv = _C.geom_views(geom, N)
+    vis = st["radii"] > 0
+    assert np.array_equal(gv["offsets"].cpu().numpy().view(np.uint32), st["offsets"])
+    rec = gv["rec"].cpu().numpy()
+    assert np.array_equal(rec[vis, 0:2].view(np.uint32), st["xy"][vis].view(np.uint32)), "pixel centres not bit-exact"
+    assert np.array_equal(rec[vis, 2].view(np.uint32), st["depths"][vis].view(np.uint32)), "depth not bit-exact"
+    assert np.array_equal(rec[vis, 4:7].view(np.uint32), st["conic_opacity"][vis, 0:3].view(np.uint32)), "conic not bit-exact"
+    rgb_hip = np.stack([rec[:, 7], rec[:, 8], rec[:, 9]], 1)
+    assert rel_err(rgb_hip[vis], st["rgb"][vis]) < 1e-6
+    rect = gv["rect"].cpu().numpy().view(np.uint32)
+    rects_hip = np.stack([rect[:, 0] & 0xffff, rect[:, 1] & 0xffff, rect[:, 0] >> 16, rect[:, 1] >> 16], 1).astype(np.int32)
+    assert np.array_equal(rects_hip[vis], st["rects"][vis])
+    bv = _C.binning_views(binning, R, W, H)
+    assert bv["key_bits"] == st["key_bits"]
+    assert np.array_equal(bv["keys"].cpu().numpy().view(np.uint64), st["keys"]), "sorted keys not bit-exact"
+    assert np.array_equal(bv["point_list"].cpu().numpy().view(np.uint32), st["point_list"]), "sorted values not bit-exact"
+    iv = _C.image_views(img, W, H)
+    assert np.array_equal(iv["ranges"].cpu().numpy().view(np.uint32), st["ranges"])
+
+    # ---- images ----------------------------------------------------------------------------------------
+    nc_eq = (iv["n_contrib"].cpu().numpy().view(np.uint32) == st["n_contrib"]).mean()
+    e_c, e_d, e_a = (rel_err(color.cpu().numpy(), st["color"]), rel_err(depth.cpu().numpy(), st["depth"]),
+                     rel_err(alpha.cpu().numpy(), st["alpha"]))
+    f_c = outlier_fraction(color.cpu().numpy(), st["color"], TOL)
+    print(f"\n[{N}@{W}x{H} {mode} deg{deg}] R={R} n_contrib equal {nc_eq:.6f}; max rel err colour {e_c:.2e} depth {e_d:.2e} "
+          f"alpha {e_a:.2e}; colour outliers>{TOL:g}: {f_c:.2e}")
+    assert nc_eq > 0.9995
+    for name, hip, ora in (("color", color, st["color"]), ("depth", depth, st["depth"]), ("alpha", alpha, st["alpha"])):
+        assert outlier_fraction(hip.cpu().numpy(), ora, TOL) <= 1e-4, name
+        assert rel_err(hip.cpu().numpy(), ora) < 2e-2, name          # a threshold flip moves one pixel by <= ~alpha_min * c
+    assert rel_err(iv["final_T"].cpu().numpy(), st["final_T"]) < 2e-2
+
+    # ---- gradients -------------------------------------------------------------------------------------
+    grads = seeded_grads(H, W, seed + 10)
+    hb = hip_backward(g, out, grads, dev, debug=True)
+    torch.cuda.synchronize()
+    gb = o.backward(st, *grads)
+    names = ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot"]
+    report = []
+    for name, h in zip(names, hb):
+        ora = gb.get(name)
+        if ora is None or h.numel() == 0:
+            continue
+        if name == "dL_dcov3D" and "cov3D_precomp" not in d:
+            pass                                          # still produced internally; compare anyway
+        e = rel_err(h.cpu().numpy().reshape(ora.shape), ora)
+        f = outlier_fraction(h.cpu().numpy().reshape(ora.shape), ora, TOL)
+        report.append(f"{name} {e:.1e} (out {f:.1e})")
+        assert f <= 2e-4, f"{name}: {f} of entries off by more than {TOL} relative"
+        assert e < 5e-3, f"{name}: max rel err {e}"
+    print("   grads: " + "; ".join(report))
+
+
+def test_empty_and_culled_inputs():
+    from egogaussian_amd import _C
+    dev = _dev()
+    d = make_inputs(100, 48, 64, 0, 0, "sh_cov")
+    # all behind the camera
+    d2 = dict(d); d2["means3D"] = d["means3D"].clone(); d2["means3D"][:, 2] = -5.0
+    g, out = hip_forward(d2, dev)
+    R, color, depth, alpha, radii = out[:5]
+    assert R == 0 and int(radii.abs().sum()) == 0
+    bgimg = d["bg"].view(3, 1, 1).expand(3, 48, 64)
+    assert torch.equal(color.cpu(), bgimg) and float(alpha.abs().sum()) == 0 and float(depth.abs().sum()) == 0
+    hb = hip_backward(g, out, seeded_grads(48, 64), dev)
+    assert all(float(t.abs().sum()) == 0 for t in hb if t.numel())
+    # P == 0
+    d0 = {k: (v[:0] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == 100 else v) for k, v in d.items()}
+    g, out = hip_forward(d0, dev)
+    assert out[0] == 0 and torch.equal(out[1].cpu(), bgimg) and out[4].numel() == 0
+    hb = hip_backward(g, out, seeded_grads(48, 64), dev)
+    assert hb[0].shape == (0, 3)
+
+
+def test_mark_visible_matches_oracle():
+    from egogaussian_amd import _C
+    from oracle.oracle import Oracle
+    dev = _dev()
+    d = make_inputs(5000, 64, 64, 3)
+    d["means3D"][::3, 2] -= 8.0
+    vis = _C.mark_visible(d["means3D"].to(dev), d["viewmatrix"].to(dev), d["projmatrix"].to(dev))
+    assert np.array_equal(vis.cpu().numpy(), Oracle(np.float32).mark_visible(d["means3D"], d["viewmatrix"]))
+
+
+def test_autograd_surface_reaches_all_parameters():
+    """render() through the drop-in module: gradients reach xyz, features, scaling, rotation, opacity (mode 1) and
+    label (mode 2), as probed for the reference in SURVEY.md appendix A."""
+    from egogaussian_amd.scene_synth import make_scene, make_camera, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render, get_render_label
+    dev = _dev()
+    H, W = 64, 64
+    sc = make_scene(1000, H, W, 0); sc["log_scale"] += math.log(3.0)
+    pc = SynthGaussians(sc, device=dev)
+    cam = make_camera(0, H, W, device=dev)
+    bg = torch.zeros(3, device=dev)
+    out = render(cam, pc, Pipe, bg)
+    assert out["render"].shape == (3, H, W) and out["depth"].shape == (1, H, W) and out["alpha"].shape == (1, H, W)
+    assert out["radii"].dtype == torch.int32 and out["visibility_filter"].dtype == torch.bool
+    (out["render"].sum() + out["alpha"].sum()).backward()
+    for p in (pc._xyz, pc._features_dc, pc._scaling, pc._rotation, pc._opacity):
+        assert p.grad is not None and float(p.grad.abs().sum()) > 0
+    assert out["viewspace_points"].grad is not None and float(out["viewspace_points"].grad[:, 2].abs().sum()) == 0
+    lab = get_render_label(cam, pc, bg)
+    lab.mean().backward()
+    assert float(pc._label.grad.abs().sum()) > 0
+
+
+def test_image_invariants_at_full_size():
+    """Size-independent properties at BASELINE config B/C shape (100k @ 960x540): alpha = 1 - final_T,
+    colour(bg) - colour(0) = final_T * bg, sum(tiles_touched) = R, keys sorted, permutation invariance."""
+    from egogaussian_amd import _C
+    dev = _dev()
+    N, H, W = 100000, 540, 960
+    d = make_inputs(N, H, W, 0, 0, "sh_cov")
+    g, out = hip_forward(d, dev)
+    R, color, depth, alpha, radii, geom, binning, img = out
+    iv = _C.image_views(img, W, H); bv = _C.binning_views(binning, R, W, H); gv = _C.geom_views(geom, N)
+    assert abs(float((alpha[0] + iv["final_T"] - 1).abs().max())) < 1e-4
+    keys = bv["keys"].cpu().numpy().view(np.uint64)
+    assert np.all(keys[1:] >= keys[:-1])
+    assert int(gv["offsets"][-1]) == R
+    d0 = dict(d); d0["bg"] = torch.zeros(3)
+    _, out0 = hip_forward(d0, dev)
+    diff = color - out0[1]
+    expect = iv["final_T"][None] * d["bg"].to(dev).view(3, 1, 1)
+    assert float((diff - expect).abs().max()) < 1e-5
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(0))
+    dp = {k: (v[perm] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == N else v) for k, v in d.items()}
+    _, outp = hip_forward(dp, dev)
+    assert outlier_fraction(outp[1].cpu().numpy(), color.cpu().numpy(), 1e-5) < 1e-4
