@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on its quoted configuration, one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+
+Workload (config C of BASELINE.md): synthetic scene S(500k Gaussians, 540, 960, seed 0), the 300-frame synthetic
+orbit, SH degree 0, cov3D built in PyTorch (the reference forces compute_cov3D_python, /root/reference/train.py:49).
+One step = one full training iteration of /root/reference/trainers/train_static.py:67-138 without densification or
+logging: get_covariance -> render() forward (HIP) -> 0.8 L1 + 0.2 (1 - SSIM) -> backward (HIP + autograd) -> Adam.
+Frames are sharded round-robin over ranks (1 frame per GPU per step); ranks exchange only
+scalars (loss / PSNR sums) through one RCCL all-reduce; `value` = steps of all ranks / max-over-ranks time.
+
+The JSON line also carries
+  roofline      the dominant rasterizer stage: algorithmic bytes per launch / its mean duration, measured with HIP
+                events recorded by the library on the launch stream inside the timed region;
+  stages        the same for every stage (ms per launch, GB/s algorithmic);
+  cpu_baseline  the C oracle (oracle/raster_oracle.c, "port") timed on this box's host cores on one forward+backward
+                of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+
+def algorithmic_bytes(stage, N, R, npix, passes):
+    """Bytes one launch of `stage` must move at minimum (DESIGN.md section 'Kernels'): per-unit figures x units."""
+    return {
+        "preprocess": 52 * N + 48 * N,                 # xyz 12 + cov 24 + opacity 4 + sh 12 in; record 48 out
+        "scan": 8 * N,
+        "duplicate": 12 * N + 12 * R,                  # offsets + rect in; key 8 + value 4 out
+        "sort": passes * 24 * R,                       # per pass: read 12, write 12 per instance
+        "tile_ranges": 8 * R,
+        "render_forward": 4 * R + 48 * R + 28 * npix,  # id + record per instance; 7 floats per pixel out
+        "render_backward": 4 * R + 48 * R + 40 * R + 32 * npix,   # + one 40-byte accumulate per instance; 8 floats/pixel in
+        "preprocess_backward": 48 * N + 52 * N + 100 * N,          # accumulator + inputs in; grads out
+    }[stage]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--gaussians", type=int, default=500_000)
+    ap.add_argument("--height", type=int, default=540)
+    ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--op-only", action="store_true", help="time rasterizer fwd+bwd only (seeded upstream grads)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)        # "nccl" is RCCL on ROCm
+
+    from egogaussian_amd import lib as egs_lib, _C
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe, N_FRAMES
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.losses import training_loss, psnr
+    egs_lib.load()
+
+    N, H, W = args.gaussians, args.height, args.width
+    teacher = make_scene(N, H, W, seed=0)
+    student = perturb_student(teacher)
+    bg = torch.zeros(3, device=dev)
+    my_frames = list(range(rank, N_FRAMES, world))
+    n_used = min(len(my_frames), args.warmup + args.steps)
+    cams = [make_camera(k, H, W, device=dev) for k in my_frames[:n_used]]
+
+    with torch.no_grad():                                      # ground truth = teacher rendered by the same path
+        tpc = SynthGaussians(teacher, device=dev, requires_grad=False)
+        gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
+        del tpc
+    pc = SynthGaussians(student, device=dev)
+    opt = torch.optim.Adam([                                    # /root/reference/scene/gaussian_model.py:180-198 defaults
+        {"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3},
+        {"params": [pc._opacity], "lr": 0.05}, {"params": [pc._scaling], "lr": 5e-3},
+        {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15)
+
+    def eval_psnr():
+        with torch.no_grad():
+            vals = [psnr(render(cams[i], pc, Pipe, bg)["render"][None], gts[i][None]).item() for i in range(min(4, n_used))]
+        return float(np.mean(vals))
+
+    g = torch.Generator().manual_seed(1234)
+    up_c, up_d, up_a = [torch.rand(s, generator=g).to(dev) for s in ((3, H, W), (1, H, W), (1, H, W))]
+    loss_acc = torch.zeros((), device=dev)
+    r_sum = [0, 0]
+
+    def step(i):
+        k = i % n_used
+        out = render(cams[k], pc, Pipe, bg)
+        if args.op_only:
+            loss = (out["render"] * up_c).sum() + (out["depth"] * up_d).sum() + (out["alpha"] * up_a).sum()
+        else:
+            loss = training_loss(out["render"], gts[k])
+        loss.backward()
+        if not args.op_only:
+            opt.step()
+        opt.zero_grad(set_to_none=True)
+        loss_acc.add_(loss.detach())
+        r_sum[0] += _C.stats["num_rendered"]; r_sum[1] += 1
+
+    psnr_start = eval_psnr()
+    for i in range(args.warmup):
+        step(i)
+    loss_acc.zero_(); r_sum[:] = [0, 0]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    egs_lib.profile_begin(max_records=min(200000, 16 * (args.steps + 8)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stages = egs_lib.profile_end()
+    psnr_end = eval_psnr()
+
+    stats = torch.tensor([elapsed, loss_acc.item(), psnr_end, psnr_start, float(r_sum[0]) / max(r_sum[1], 1)],
+                         device=dev, dtype=torch.float64)
+    tmax = stats[:1].clone()
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)            # max over ranks of the timed region
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)           # scalar metrics only (RCCL over xGMI)
+    elapsed_max = float(tmax.item())
+    mean_loss = float(stats[1].item()) / (world * args.steps)
+    psnr_e, psnr_s, R_mean = float(stats[2].item()) / world, float(stats[3].item()) / world, float(stats[4].item()) / world
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    npix = H * W
+    passes = _C.binning_passes(W, H)
+    stage_rows, dominant = {}, None
+    for name, (ms, n) in stages.items():
+        if n == 0:
+            continue
+        per = ms / n
+        ab = algorithmic_bytes(name, N, R_mean, npix, passes)
+        stage_rows[name] = {"ms_per_launch": round(per, 4), "launches": n, "alg_MB": round(ab / 1e6, 2),
+                            "alg_GBps": round(ab / (per * 1e-3) / 1e9, 1), "frac_hbm": round(ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if dominant is None or per * n > stages[dominant][0]:
+            dominant = name
+    traffic = None
+    if os.path.exists(PMC_FILE):
+        try:
+            pmc = json.load(open(PMC_FILE))
+            ent = pmc.get(f"{N}@{W}x{H}", {}).get(dominant)
+            traffic = ent["hbm_bytes_per_launch"] if ent else None
+        except Exception:
+            traffic = None
+    d = stage_rows[dominant]
+    roofline = {"kernel": dominant, "bound": "hbm", "achieved": d["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(d["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "ms_per_launch": d["ms_per_launch"], "alg_bytes_per_launch": int(d["alg_MB"] * 1e6),
+                "note": "blend stages are VALU/LDS-bound (per pixel-splat pair work), not HBM-bound; see `stages` for the streaming kernels"}
+    op_ms = sum(ms for ms, n in stages.values()) / max(args.steps, 1)
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.oracle import Oracle
+        cores = os.cpu_count() or 1
+        with torch.no_grad():
+            inp = dict(means3D=pc.get_xyz.cpu(), opacities=pc.get_opacity.cpu(), shs=pc.get_features.cpu(),
+                       cov3D_precomp=pc.get_covariance().cpu(), viewmatrix=cams[0].world_view_transform.cpu(),
+                       projmatrix=cams[0].full_proj_transform.cpu(), campos=cams[0].camera_center.cpu(), bg=bg.cpu(),
+                       image_height=H, image_width=W, tanfovx=math.tan(cams[0].FoVx / 2), tanfovy=math.tan(cams[0].FoVy / 2))
+        o = Oracle(np.float32, nthreads=cores)
+        tc = time.perf_counter()
+        st = o.forward(**inp)
+        o.backward(st, up_c.cpu(), up_d.cpu(), up_a.cpu())
+        tcpu = time.perf_counter() - tc
+        cpu = {"value": round(1.0 / tcpu, 4), "unit": "iters/s", "cores": cores, "kind": "port",
+               "sample": f"1 rasterizer forward+backward (op only, no loss/optimizer) of the same {N}@{W}x{H} frame 0, "
+                         f"oracle/raster_oracle.c with OpenMP over tiles ({tcpu:.1f} s)"}
+
+    total_steps = world * args.steps
+    out = {
+        "metric": "train iters/s (fwd+bwd render) + PSNR, 500k Gaussians @ 960x540",
+        "value": round(total_steps / elapsed_max, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed_max / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"S({N},{H},{W},seed0) teacher/student, 300-frame orbit, 1 frame per GPU per step; step = "
+                               + ("rasterizer fwd+bwd only (seeded upstream grads on colour/depth/alpha)" if args.op_only else
+                                  "cov3D(torch) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) + bwd (HIP+autograd) + Adam"),
+                   "gaussians": N, "image": [H, W], "sh_degree": 0, "instances_R": int(R_mean), "sort_passes": passes,
+                   "parallelism": f"frames sharded over {world} GPU(s), scalar all-reduce only"},
+        "psnr_db": round(psnr_e, 3), "psnr_db_before": round(psnr_s, 3), "mean_loss": round(mean_loss, 6),
+        "rasterizer_ms_per_step": round(op_ms, 4),
+        "roofline": roofline, "stages": stage_rows, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

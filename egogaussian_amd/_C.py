@@ -14,6 +14,16 @@ import torch
 from . import lib as _lib
 
 
+stats = {"num_rendered": 0}       # R of the most recent forward (read by bench.py)
+
+
+def binning_passes(W, H):
+    """Radix passes the sort runs for a W x H image."""
+    lay = _lib.BinningLayout()
+    _lib.check(_lib.load().egs_get_binning_layout(0, int(W), int(H), C.byref(lay)))
+    return int(lay.passes)
+
+
 def _ptr(t):
     return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
 
@@ -70,6 +80,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         binning = torch.empty((L.egs_binning_bytes(R.value, W, H),), device=dev, dtype=torch.uint8)
         _lib.check(L.egs_forward_render(P, R.value, _ptr(background), W, H, _ptr(geom), _ptr(binning), _ptr(img),
                                         _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), _stream(), int(bool(debug))))
+    stats["num_rendered"] = int(R.value)
     return int(R.value), out_color, out_depth, out_alpha, radii, geom, binning, img
 
 

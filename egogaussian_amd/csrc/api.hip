@@ -79,9 +79,59 @@ int check_modes(const float* shs, const float* colors, const float* scales, cons
 #define EGS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define EGS_SYNC_IF_DEBUG(s) do { if (debug) { EGS_TRY(hipStreamSynchronize(s)); EGS_TRY(hipGetLastError()); } } while (0)
 
+// ---- stage timing pool -----------------------------------------------------------------------------
+struct ProfRec { int stage; hipEvent_t a, b; bool closed; };
+ProfRec* g_prof = nullptr; int g_prof_cap = 0, g_prof_n = 0; int g_prof_open[EGS_K_COUNT];
+
 }  // namespace
 
+void egs_prof_start(int stage, hipStream_t s) {
+    if (!g_prof || g_prof_n >= g_prof_cap) return;
+    ProfRec& r = g_prof[g_prof_n];
+    r.stage = stage; r.closed = false;
+    if (hipEventRecord(r.a, s) != hipSuccess) return;
+    g_prof_open[stage] = g_prof_n++;
+}
+void egs_prof_stop(int stage, hipStream_t s) {
+    if (!g_prof) return;
+    const int i = g_prof_open[stage];
+    if (i < 0) return;
+    if (hipEventRecord(g_prof[i].b, s) == hipSuccess) g_prof[i].closed = true;
+    g_prof_open[stage] = -1;
+}
+
 extern "C" {
+
+int egs_profile_begin(int max_records) {
+    if (g_prof || max_records <= 0) return EGS_ERR_ARG;
+    g_prof = new ProfRec[max_records];
+    for (int i = 0; i < max_records; i++) {
+        if (hipEventCreate(&g_prof[i].a) != hipSuccess || hipEventCreate(&g_prof[i].b) != hipSuccess) return EGS_ERR_NO_DEVICE;
+        g_prof[i].closed = false;
+    }
+    for (int k = 0; k < EGS_K_COUNT; k++) g_prof_open[k] = -1;
+    g_prof_cap = max_records; g_prof_n = 0;
+    return 0;
+}
+int egs_profile_end(double* total_ms, int* launches) {
+    if (!g_prof || !total_ms || !launches) return EGS_ERR_ARG;
+    for (int k = 0; k < EGS_K_COUNT; k++) { total_ms[k] = 0.0; launches[k] = 0; }
+    for (int i = 0; i < g_prof_n; i++) {
+        if (!g_prof[i].closed) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof[i].b) == hipSuccess && hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b) == hipSuccess) {
+            total_ms[g_prof[i].stage] += ms; launches[g_prof[i].stage]++;
+        }
+    }
+    for (int i = 0; i < g_prof_cap; i++) { (void)hipEventDestroy(g_prof[i].a); (void)hipEventDestroy(g_prof[i].b); }
+    delete[] g_prof; g_prof = nullptr; g_prof_cap = g_prof_n = 0;
+    return 0;
+}
+const char* egs_profile_stage_name(int stage) {
+    static const char* n[EGS_K_COUNT] = { "preprocess", "scan", "duplicate", "sort", "tile_ranges", "render_forward",
+                                          "render_backward", "preprocess_backward" };
+    return stage >= 0 && stage < EGS_K_COUNT ? n[stage] : "?";
+}
 
 int egs_abi_version(void) { return EGS_ABI_VERSION; }
 
@@ -139,10 +189,14 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
     hipStream_t s = (hipStream_t)stream;
     EgsGeomPtrs g = geom_ptrs(geom_buffer, P);
     EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
+    egs_prof_start(EGS_K_PREPROCESS, s);
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                                   rotations, cov3D_precomp, cam, radii, g, s));
+    egs_prof_stop(EGS_K_PREPROCESS, s);
     EGS_SYNC_IF_DEBUG(s);
+    egs_prof_start(EGS_K_SCAN, s);
     EGS_TRY(egs_launch_scan_u32(g.offsets, g.offsets, (size_t)P, 1, g.scan_scratch, g.total, s));
+    egs_prof_stop(EGS_K_SCAN, s);
     EGS_SYNC_IF_DEBUG(s);
     uint64_t R = 0;
     EGS_TRY(hipMemcpyAsync(&R, g.total, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -166,7 +220,9 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
     EgsImgPtrs im = img_ptrs(image_buffer, width, height);
     EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, s, debug));
     const uint32_t* point_list = b.sorted_in_b ? b.vals_b : b.vals_a;
+    egs_prof_start(EGS_K_RENDER_FWD, s);
     EGS_TRY(egs_launch_render_forward(width, height, background, g, point_list, im, out_color, out_depth, out_alpha, s));
+    egs_prof_stop(EGS_K_RENDER_FWD, s);
     EGS_SYNC_IF_DEBUG(s);
     return 0;
 }
@@ -197,15 +253,19 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
     EGS_TRY(hipMemsetAsync(grad_acc, 0, (size_t)P * EGS_GRAD_STRIDE * sizeof(float), s));
     if (R > 0) {
         const uint32_t* point_list = b.sorted_in_b ? b.vals_b : b.vals_a;
+        egs_prof_start(EGS_K_RENDER_BWD, s);
         EGS_TRY(egs_launch_render_backward(width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth,
                                            dL_dout_alpha, grad_acc, s));
+        egs_prof_stop(EGS_K_RENDER_BWD, s);
         EGS_SYNC_IF_DEBUG(s);
     }
+    egs_prof_start(EGS_K_PREPROCESS_BWD, s);
     EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
     EGS_TRY(egs_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, shs, scales, scale_modifier, rotations,
                                            cov3D_precomp, cam, radii, g, grad_acc, colors_precomp != nullptr, dL_dmeans2D,
                                            dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
                                            dL_drotations, s));
+    egs_prof_stop(EGS_K_PREPROCESS_BWD, s);
     EGS_SYNC_IF_DEBUG(s);
     return 0;
 }

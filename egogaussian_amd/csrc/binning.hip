@@ -272,10 +272,13 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     if (e != hipSuccess) return e;
     if (R64 == 0 || P == 0) return hipSuccess;
     const uint32_t R = (uint32_t)R64;
+    egs_prof_start(EGS_K_DUPLICATE, s);
     hipLaunchKernelGGL(k_duplicate, dim3((P + 255) / 256), dim3(256), 0, s, P, g.rec, g.rect, g.offsets, gx, b.keys_a, b.vals_a);
+    egs_prof_stop(EGS_K_DUPLICATE, s);
     EGS_DBG(s);
     const uint32_t nblocks = (R + EGS_SORT_KPB - 1) / EGS_SORT_KPB;
     uint64_t* kin = b.keys_a; uint64_t* kout = b.keys_b; uint32_t* vin = b.vals_a; uint32_t* vout = b.vals_b;
+    egs_prof_start(EGS_K_SORT, s);
     for (int pass = 0; pass < b.passes; pass++) {
         const int shift = pass * EGS_SORT_BITS;
         hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(EGS_SORT_THREADS), 0, s, kin, R, shift, nblocks, b.hist);
@@ -286,7 +289,10 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
         EGS_DBG(s);
         uint64_t* tk = kin; kin = kout; kout = tk; uint32_t* tv = vin; vin = vout; vout = tv;
     }
+    egs_prof_stop(EGS_K_SORT, s);
+    egs_prof_start(EGS_K_RANGES, s);
     hipLaunchKernelGGL(k_tile_ranges, dim3((R + 255) / 256), dim3(256), 0, s, R, kin, im.ranges);
+    egs_prof_stop(EGS_K_RANGES, s);
     EGS_DBG(s);
     return hipGetLastError();
 }

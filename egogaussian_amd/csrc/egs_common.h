@@ -71,3 +71,7 @@ hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs 
 hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
                                       const float* dL_dalpha, float* grad_acc, hipStream_t s);
+
+// optional stage timing (api.hip); no-ops unless egs_profile_begin() was called
+void egs_prof_start(int stage, hipStream_t s);
+void egs_prof_stop(int stage, hipStream_t s);

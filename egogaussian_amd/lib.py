@@ -44,7 +44,24 @@ SIGNATURES = {
     "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, f32, f32,
                                vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
+    "egs_profile_begin": (C.c_int, [i32]),
+    "egs_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "egs_profile_stage_name": (C.c_char_p, [i32]),
 }
+N_STAGES = 8
+
+
+def profile_begin(max_records=65536):
+    check(load().egs_profile_begin(max_records))
+
+
+def profile_end():
+    """-> {stage: (total_ms, launches)}"""
+    ms = (C.c_double * N_STAGES)()
+    n = (C.c_int * N_STAGES)()
+    L = load()
+    check(L.egs_profile_end(ms, n))
+    return {L.egs_profile_stage_name(k).decode(): (float(ms[k]), int(n[k])) for k in range(N_STAGES)}
 
 _lib = None
 

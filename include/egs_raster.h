@@ -131,6 +131,18 @@ int egs_backward(
 int egs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present /*[P] out, 0/1*/, void* stream);
 
+/* ---- optional per-stage timing with HIP events on the caller's stream (bench / profiling aid) ------
+ * The only process-wide state in the library; off by default.  egs_profile_begin allocates an event pool and
+ * turns recording on; every stage launched afterwards is bracketed by two events on its stream;
+ * egs_profile_end waits for the events, returns per-stage total milliseconds and launch counts, frees the pool. */
+enum {
+    EGS_K_PREPROCESS = 0, EGS_K_SCAN, EGS_K_DUPLICATE, EGS_K_SORT, EGS_K_RANGES, EGS_K_RENDER_FWD,
+    EGS_K_RENDER_BWD, EGS_K_PREPROCESS_BWD, EGS_K_COUNT
+};
+int         egs_profile_begin(int max_records);
+int         egs_profile_end(double* total_ms /*HOST [EGS_K_COUNT]*/, int* launches /*HOST [EGS_K_COUNT]*/);
+const char* egs_profile_stage_name(int stage);
+
 #ifdef __cplusplus
 }
 #endif
