@@ -27,9 +27,15 @@ def strip_symmetric(S):
     return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1)
 
 
+def _outer_gram(L):
+    """L L^T for [N,3,3] without a batched GEMM: on ROCm a 500k-batch of 3x3 products runs for milliseconds in
+    rocBLAS, while the broadcast product + reduction is two elementwise kernels."""
+    return (L[:, :, None, :] * L[:, None, :, :]).sum(-1)
+
+
 def covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
     L = scaling_rotation(scaling_modifier * scaling, rotation)
-    return strip_symmetric(L @ L.transpose(1, 2))
+    return strip_symmetric(_outer_gram(L))
 
 
 def rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation, accum_R, is_object=None,
@@ -44,8 +50,8 @@ def rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation
         sel = (is_object.reshape(-1) == which_object)
     else:
         sel = torch.ones(L.shape[0], dtype=torch.bool, device=L.device)
-    moved = torch.matmul(accum_R, L)
+    moved = (accum_R.to(L.dtype)[None, :, :, None] * L[:, None, :, :]).sum(2)        # accum_R @ L, per Gaussian
     if rot_L is not None:
         moved = rot_L(moved)
     L = torch.where(sel[:, None, None], moved, L)
-    return strip_symmetric(L @ L.transpose(1, 2))
+    return strip_symmetric(_outer_gram(L))
