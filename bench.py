@@ -62,17 +62,13 @@ def main():
     ap.add_argument("--op-only", action="store_true", help="time rasterizer fwd+bwd only (seeded upstream grads)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from egogaussian_amd import dist as egs_dist
+    rank, world, local_rank = egs_dist.env_world()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)        # "nccl" is RCCL on ROCm
+    egs_dist.init("nccl", dev)                                 # "nccl" is RCCL on ROCm
 
     from egogaussian_amd import lib as egs_lib, _C
     from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe, N_FRAMES
@@ -84,7 +80,7 @@ def main():
     teacher = make_scene(N, H, W, seed=0)
     student = perturb_student(teacher)
     bg = torch.zeros(3, device=dev)
-    my_frames = list(range(rank, N_FRAMES, world))
+    my_frames = egs_dist.shard_frames(N_FRAMES, rank, world)
     n_used = min(len(my_frames), args.warmup + args.steps)
     cams = [make_camera(k, H, W, device=dev) for k in my_frames[:n_used]]
 
@@ -127,34 +123,26 @@ def main():
         step(i)
     loss_acc.zero_(); r_sum[:] = [0, 0]
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    egs_dist.barrier()
     egs_lib.profile_begin(max_records=min(200000, 16 * (args.steps + 8)))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    egs_dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     stages = egs_lib.profile_end()
     psnr_end = eval_psnr()
 
-    stats = torch.tensor([elapsed, loss_acc.item(), psnr_end, psnr_start, float(r_sum[0]) / max(r_sum[1], 1)],
-                         device=dev, dtype=torch.float64)
-    tmax = stats[:1].clone()
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)            # max over ranks of the timed region
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)           # scalar metrics only (RCCL over xGMI)
-    elapsed_max = float(tmax.item())
-    mean_loss = float(stats[1].item()) / (world * args.steps)
-    psnr_e, psnr_s, R_mean = float(stats[2].item()) / world, float(stats[3].item()) / world, float(stats[4].item()) / world
+    elapsed_max = egs_dist.reduce_scalars([elapsed], dev, "max")[0]          # max over ranks of the timed region
+    sums = egs_dist.reduce_scalars([loss_acc.item(), psnr_end, psnr_start, float(r_sum[0]) / max(r_sum[1], 1)], dev, "sum")
+    mean_loss = sums[0] / (world * args.steps)                                # scalar metrics only (RCCL over xGMI)
+    psnr_e, psnr_s, R_mean = sums[1] / world, sums[2] / world, sums[3] / world
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        egs_dist.shutdown()
         return
 
     npix = H * W
@@ -218,8 +206,7 @@ def main():
         "roofline": roofline, "stages": stage_rows, "cpu_baseline": cpu,
     }
     print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    egs_dist.shutdown()
 
 
 if __name__ == "__main__":

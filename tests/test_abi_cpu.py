@@ -1,0 +1,109 @@
+"""CPU: the C-ABI library loads, exports every symbol include/egs_raster.h declares, sizes/layouts are sane and
+argument errors are reported before any device work.  No compute calls (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "egs_raster.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(egs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from egogaussian_amd import lib
+    L = lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/egs_raster.h but not exported"
+    assert set(lib.SIGNATURES) == set(names), "python binding table and header disagree"
+    assert L.egs_abi_version() == lib.ABI_VERSION
+
+
+def test_sizes_and_layouts():
+    from egogaussian_amd import lib
+    L = lib.load()
+    assert L.egs_geom_bytes(0) >= 0 and L.egs_geom_bytes(1000) < L.egs_geom_bytes(2000)
+    assert L.egs_geom_bytes(500000) >= 500000 * (48 + 8 + 4 + 1)
+    assert L.egs_binning_bytes(10**6, 960, 540) >= 10**6 * 24
+    assert L.egs_image_bytes(960, 540) >= 960 * 540 * 8 + 60 * 34 * 8
+    assert L.egs_backward_scratch_bytes(1000) >= 48000
+    g = lib.GeomLayout(); assert L.egs_get_geom_layout(1000, C.byref(g)) == 0
+    offs = [g.rec, g.rect, g.offsets, g.clamped, g.scan_scratch, g.total]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs) and offs[-1] + 8 <= L.egs_geom_bytes(1000)
+    b = lib.BinningLayout(); assert L.egs_get_binning_layout(5000, 960, 540, C.byref(b)) == 0
+    assert b.key_bits == 32 + 11 and b.passes == 6 and b.sorted_in_b == 0          # 60 x 34 = 2040 tiles -> 11 bits
+    assert L.egs_get_binning_layout(5000, 1920, 1080, C.byref(b)) == 0 and b.key_bits == 45
+    assert L.egs_get_binning_layout(5000, 64, 64, C.byref(b)) == 0 and b.key_bits == 37 and b.passes == 5 and b.sorted_in_b == 1
+    i = lib.ImageLayout(); assert L.egs_get_image_layout(100, 70, C.byref(i)) == 0 and i.ranges < i.final_T < i.n_contrib
+
+
+def test_argument_errors_precede_device_work():
+    from egogaussian_amd import lib
+    L = lib.load()
+    R = C.c_int64(-7)
+    none = None
+    # null required pointers
+    rc = L.egs_forward_geometry(10, 0, 1, none, none, none, none, none, 1.0, none, none, none, none, none, 64, 64, 1.0, 1.0, 0,
+                                none, none, C.byref(R), none, 0)
+    assert rc == -1 and R.value == 0
+    assert L.egs_forward_geometry(-1, 0, 1, none, none, none, none, none, 1.0, none, none, none, none, none, 64, 64, 1.0, 1.0, 0,
+                                  none, none, C.byref(R), none, 0) == -1
+    assert L.egs_forward_geometry(10, 0, 1, none, none, none, none, none, 1.0, none, none, none, none, none, 70000, 64, 1.0, 1.0,
+                                  0, none, none, C.byref(R), none, 0) == -3
+    # P == 0 is a valid no-op
+    assert L.egs_forward_geometry(0, 0, 0, none, none, none, none, none, 1.0, none, none, none, none, none, 64, 64, 1.0, 1.0, 0,
+                                  none, none, C.byref(R), none, 0) == 0 and R.value == 0
+    # mode errors: both shs and colours given (fake non-null pointers are never dereferenced before the check)
+    p = C.c_void_p(4096)
+    assert L.egs_forward_geometry(10, 0, 1, p, p, p, p, none, 1.0, none, p, p, p, p, 64, 64, 1.0, 1.0, 0, p, p, C.byref(R),
+                                  none, 0) == -2
+    assert L.egs_forward_geometry(10, 0, 1, p, p, none, p, p, 1.0, none, none, p, p, p, 64, 64, 1.0, 1.0, 0, p, p, C.byref(R),
+                                  none, 0) == -2      # scales without rotations
+    assert L.egs_forward_geometry(10, 4, 25, p, p, none, p, none, 1.0, none, p, p, p, p, 64, 64, 1.0, 1.0, 0, p, p, C.byref(R),
+                                  none, 0) == -3      # SH degree 4 unsupported
+    assert b"exactly one" in L.egs_error_string(-2)
+    assert L.egs_mark_visible(5, none, none, none, none, none) == -1
+
+
+def test_python_surface_validation_and_no_cpu_fallback():
+    import diff_gaussian_rasterization as dgr
+    from egogaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    assert dgr.GaussianRasterizer is GaussianRasterizer and hasattr(dgr._C, "rasterize_gaussians") \
+        and hasattr(dgr._C, "rasterize_gaussians_backward") and hasattr(dgr._C, "mark_visible")
+    rs = GaussianRasterizationSettings(image_height=32, image_width=32, tanfovx=1.0, tanfovy=1.0, bg=torch.zeros(3),
+                                       scale_modifier=1.0, viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=0,
+                                       campos=torch.zeros(3), prefiltered=False, debug=False)
+    r = GaussianRasterizer(raster_settings=rs)
+    assert GaussianRasterizer(rs).raster_settings is rs                       # positional ctor (render_helper.py:61)
+    x, o = torch.zeros(4, 3), torch.ones(4, 1)
+    with pytest.raises(Exception, match="exactly one"):
+        r(means3D=x, means2D=x, opacities=o, shs=None, colors_precomp=None, cov3D_precomp=torch.zeros(4, 6))
+    with pytest.raises(Exception, match="exactly one"):
+        r(means3D=x, means2D=x, opacities=o, shs=torch.zeros(4, 1, 3), colors_precomp=torch.zeros(4, 3), cov3D_precomp=torch.zeros(4, 6))
+    with pytest.raises(Exception, match="exactly one"):
+        r(means3D=x, means2D=x, opacities=o, shs=torch.zeros(4, 1, 3), scales=torch.ones(4, 3))
+    with pytest.raises(Exception, match="exactly one"):
+        r(means3D=x, means2D=x, opacities=o, shs=torch.zeros(4, 1, 3), scales=torch.ones(4, 3), rotations=torch.ones(4, 4),
+          cov3D_precomp=torch.zeros(4, 6))
+    # CPU tensors: loud failure, never a silent fallback
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        r(means3D=x, means2D=x, opacities=o, shs=torch.zeros(4, 1, 3), cov3D_precomp=torch.zeros(4, 6))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "egogaussian_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports the oracle"
+                assert "liboracle" not in text
+    assert not re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(ROOT, "diff_gaussian_rasterization", "__init__.py")).read(), flags=re.M)

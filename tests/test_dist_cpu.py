@@ -1,0 +1,45 @@
+"""CPU, world_size 2 over gloo: the N > 1 layout of the path -- frames sharded round-robin, no data-path collective,
+scalars all-reduced (egogaussian_amd/dist.py)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from egogaussian_amd import dist as d
+    r, w = d.init("gloo")
+    assert (r, w) == (rank, world) and d.env_world() == (rank, world, rank)
+    frames = d.shard_frames(300, r, w)
+    # every rank "renders" its frames: a per-frame scalar stands in for the per-frame loss / PSNR
+    local = [float(sum(k * 0.5 for k in frames)), float(len(frames)), 1.0 + rank]
+    tot = d.reduce_scalars(local, "cpu", "sum")
+    tmax = d.reduce_scalars([10.0 + rank], "cpu", "max")[0]
+    d.barrier()
+    out[rank] = (frames, tot, tmax)
+    d.shutdown()
+
+
+def test_frame_sharding_and_scalar_allreduce_world2():
+    world = 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    f0, t0, m0 = out[0]; f1, t1, m1 = out[1]
+    assert sorted(f0 + f1) == list(range(300)) and not set(f0) & set(f1) and abs(len(f0) - len(f1)) <= 1
+    assert t0 == t1 and m0 == m1 == 11.0
+    assert abs(t0[0] - 0.5 * sum(range(300))) < 1e-9 and t0[1] == 300.0 and t0[2] == 3.0
+
+
+def test_single_process_is_identity():
+    from egogaussian_amd import dist as d
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    assert d.env_world() == (0, 1, 0) and d.shard_frames(7, 0, 1) == list(range(7))
+    assert d.reduce_scalars([1.5, 2.0]) == [1.5, 2.0]
+    d.barrier()

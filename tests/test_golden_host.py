@@ -1,0 +1,175 @@
+"""CPU: this package's host-side mirrors against fixtures captured from the reference's own Python
+(tests/golden/make_golden.py is the recipe; fixtures are data only)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+load = lambda n: np.load(os.path.join(GOLD, n), allow_pickle=False)
+T = lambda a: torch.tensor(np.asarray(a))
+
+
+def test_camera_matrices_match_reference():
+    from egogaussian_amd.scene_synth import projection_matrix, world_to_view, SynthCamera, ZNEAR, ZFAR
+    g = load("camera.npz")
+    for i in range(3):
+        fovx, fovy = g[f"fov{i}"]
+        assert np.array_equal(world_to_view(g[f"R{i}"], g[f"T{i}"]), g[f"w2v{i}"])          # translate = 0, scale = 1
+        assert np.allclose(projection_matrix(ZNEAR, ZFAR, fovx, fovy).numpy(), g[f"P{i}"], rtol=0, atol=0)
+        cam = SynthCamera(g[f"w2v{i}"], 10, 10, fovx, fovy)
+        assert np.array_equal(cam.world_view_transform.numpy(), g[f"wvt{i}"])
+        assert np.allclose(cam.full_proj_transform.numpy(), g[f"full{i}"], rtol=1e-6, atol=1e-7)
+        assert np.allclose(cam.camera_center.numpy(), g[f"center{i}"], rtol=1e-6, atol=1e-7)
+
+
+def test_sh_matches_reference_and_oracle():
+    from egogaussian_amd.sh import eval_sh, RGB2SH, SH2RGB
+    from oracle.oracle import Oracle
+    from egogaussian_amd.scene_synth import SynthCamera
+    g = load("sh.npz")
+    dirs, sh = T(g["dirs"]), T(g["sh"])
+    for deg in range(4):
+        assert np.allclose(eval_sh(deg, sh, dirs).numpy(), g[f"eval{deg}"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(RGB2SH(T(g["rgb"])).numpy(), g["rgb2sh"]) and np.allclose(SH2RGB(T(g["rgb"])).numpy(), g["sh2rgb"])
+    # the oracle's in-"kernel" SH: place Gaussians along the fixture directions in front of an identity camera
+    keep = g["dirs"][:, 2] > 0.3
+    d = g["dirs"][keep].astype(np.float64)
+    n = d.shape[0]
+    tan = 5.0
+    cam = SynthCamera(np.eye(4), 64, 64, 2 * math.atan(tan), 2 * math.atan(tan))
+    for deg in range(4):
+        shs = np.transpose(g["sh"][keep], (0, 2, 1)).astype(np.float64)               # [n,16,3]
+        st = Oracle(np.float64).forward(means3D=4.0 * d, opacities=np.full(n, 0.5), shs=shs, scales=np.full((n, 3), 0.05),
+                                        rotations=np.tile([1.0, 0, 0, 0], (n, 1)), viewmatrix=cam.world_view_transform,
+                                        projmatrix=cam.full_proj_transform, campos=np.zeros(3), bg=np.zeros(3),
+                                        image_height=64, image_width=64, tanfovx=tan, tanfovy=tan, sh_degree=deg,
+                                        stop_after="preprocess")
+        vis = st["radii"] > 0
+        assert vis.sum() >= 5
+        expect = np.maximum(g[f"eval{deg}"][keep] + 0.5, 0.0)
+        assert np.allclose(st["rgb"][vis], expect[vis], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(st["clamped"][vis].astype(bool), (g[f"eval{deg}"][keep] + 0.5 < 0)[vis])
+
+
+def test_losses_match_reference():
+    from egogaussian_amd.losses import l1_loss, l2_loss, ssim, psnr
+    g = load("losses.npz")
+    a, b = T(g["a"]).requires_grad_(True), T(g["b"])
+    assert np.allclose(l1_loss(a, b).item(), g["l1"], rtol=1e-6) and np.allclose(l2_loss(a, b).item(), g["l2"], rtol=1e-6)
+    s = ssim(a, b)
+    assert abs(s.item() - float(g["ssim"])) < 2e-6            # separable window vs the reference's 2-D window
+    s.backward()
+    assert np.abs(a.grad.numpy() - g["ssim_grad_a"]).max() < 1e-7 + 1e-3 * np.abs(g["ssim_grad_a"]).max()
+    assert np.allclose(ssim(a[None], b[None], size_average=False).detach().numpy(), g["ssim_per_image"], atol=2e-6)
+    assert np.allclose(psnr(a[None].detach(), b[None]).numpy(), g["psnr"], rtol=1e-6)
+
+
+def test_covariance_matches_reference():
+    from egogaussian_amd.covariance import covariance_from_scaling_rotation, rotated_covariance_from_scaling_rotation
+    g = load("covariance.npz")
+    ls, q, w = T(g["log_scale"]).requires_grad_(True), T(g["quat"]).requires_grad_(True), T(g["wcov"])
+    cov = covariance_from_scaling_rotation(torch.exp(ls), 1.0, q)
+    assert np.allclose(cov.detach().numpy(), g["cov"], rtol=1e-5, atol=1e-9)
+    (cov * w).sum().backward()
+    assert np.allclose(ls.grad.numpy(), g["g_scaling"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(q.grad.numpy(), g["g_rotation"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(covariance_from_scaling_rotation(torch.exp(ls), 2.0, q).detach().numpy(), g["cov_mod2"], rtol=1e-5)
+    ls.grad = None; q.grad = None
+    R, is_obj = T(g["accum_R"]), T(g["is_object"])
+    rc = rotated_covariance_from_scaling_rotation(torch.exp(ls), 1.0, q, R, is_obj, 1)
+    assert np.allclose(rc.detach().numpy(), g["rcov"], rtol=1e-5, atol=1e-9)
+    (rc * w).sum().backward()
+    assert np.allclose(ls.grad.numpy(), g["rg_scaling"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(q.grad.numpy(), g["rg_rotation"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(rotated_covariance_from_scaling_rotation(torch.exp(ls), 1.0, q, torch.eye(3), is_obj, 1).detach().numpy(),
+                       g["rcov_identity"], rtol=1e-5, atol=1e-9)
+    assert np.allclose(rotated_covariance_from_scaling_rotation(torch.exp(ls), 1.0, q, R, is_obj, None).detach().numpy(),
+                       g["rcov_all"], rtol=1e-5, atol=1e-9)
+
+
+def _model_from_boundary(g, device="cpu"):
+    from egogaussian_amd.scene_synth import SynthGaussians, SynthCamera
+    scene = dict(xyz=g["xyz"], features=g["features_dc"], log_scale=g["log_scale"], quat=g["quat"],
+                 opacity_logit=g["opacity_logit"])
+    pc = SynthGaussians(scene, device=device)
+    pc._label = torch.tensor(g["label"], device=device).requires_grad_(True)
+    pc._is_object = torch.tensor(g["is_object"], device=device)
+    H, W = int(g["H"]), int(g["W"])
+    cam = SynthCamera(g["wvt"].T, H, W, float(g["fov"][0]), float(g["fov"][1]), device=device)
+    return pc, cam
+
+
+def test_boundary_arguments_match_reference_render():
+    """My render()/get_render_label() hand the rasterizer exactly what the reference's do (mode 1 and mode 2)."""
+    from egogaussian_amd.renderer import get_raster_settings, gaussians_to_label_rendervar
+    g = load("boundary.npz")
+    pc, cam = _model_from_boundary(g)
+    assert np.array_equal(cam.world_view_transform.numpy(), g["m1_viewmatrix"])
+    assert np.allclose(cam.full_proj_transform.numpy(), g["m1_projmatrix"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(cam.camera_center.numpy(), g["m1_campos"], rtol=1e-6, atol=1e-7)
+    rs = get_raster_settings(cam, pc, torch.tensor(g["bg"]))
+    assert np.allclose([rs.tanfovx, rs.tanfovy], g["m1_tanfov"], rtol=1e-12) and rs.sh_degree == int(g["m1_sh_degree"])
+    assert rs.scale_modifier == float(g["m1_scale_modifier"]) and [rs.prefiltered, rs.debug] == list(g["m1_flags"])
+    assert rs._fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
+                          "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
+    # mode 1 tensors
+    assert np.array_equal(pc.get_xyz.detach().numpy(), g["m1_means3D"])
+    assert np.allclose(pc.get_opacity.detach().numpy(), g["m1_opacities"], rtol=1e-6)
+    assert np.array_equal(pc.get_features.detach().numpy(), g["m1_shs"])
+    assert np.allclose(pc.get_covariance(1.0).detach().numpy(), g["m1_cov3D_precomp"], rtol=1e-5, atol=1e-10)
+    assert all(g[f"m1_{k}_rg"] for k in ("means3D", "means2D", "opacities", "shs", "cov3D_precomp")) and g["m1_absent"].all()
+    # mode 2 tensors
+    rv = gaussians_to_label_rendervar(pc)
+    assert np.array_equal(rv["means3D"].numpy(), g["m2_means3D"]) and not rv["means3D"].requires_grad
+    assert np.allclose(rv["scales"].numpy(), g["m2_scales"], rtol=1e-6)
+    assert np.allclose(rv["rotations"].numpy(), g["m2_rotations"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(rv["opacities"].numpy(), g["m2_opacities"], rtol=1e-6)
+    assert np.array_equal(rv["colors_precomp"].detach().numpy(), g["m2_colors_precomp"]) and rv["colors_precomp"].requires_grad
+    assert not any(g[f"m2_{k}_rg"] for k in ("means3D", "means2D", "opacities", "scales", "rotations")) and g["m2_absent"].all()
+
+
+def test_oracle_reproduces_boundary_images():
+    """The C oracle, fed the captured mode-1 / mode-2 arguments, reproduces the images the reference's render() got
+    back (those came from the independent torch restatement)."""
+    from oracle.oracle import Oracle
+    g = load("boundary.npz")
+    H, W = int(g["H"]), int(g["W"])
+    common = dict(viewmatrix=g["m1_viewmatrix"], projmatrix=g["m1_projmatrix"], campos=g["m1_campos"], bg=g["bg"],
+                  image_height=H, image_width=W, tanfovx=float(g["m1_tanfov"][0]), tanfovy=float(g["m1_tanfov"][1]))
+    st = Oracle(np.float32).forward(means3D=g["m1_means3D"], opacities=g["m1_opacities"], shs=g["m1_shs"],
+                                    cov3D_precomp=g["m1_cov3D_precomp"], **common)
+    assert np.array_equal(st["radii"], g["m1_radii"]) and np.array_equal(st["radii"] > 0, g["m1_visibility"])
+    for name, key in (("color", "m1_render"), ("depth", "m1_depth"), ("alpha", "m1_alpha")):
+        assert np.abs(st[name] - g[key]).max() < 2e-5 * max(1.0, np.abs(g[key]).max()), name
+    st2 = Oracle(np.float32).forward(means3D=g["m2_means3D"], opacities=g["m2_opacities"], colors_precomp=g["m2_colors_precomp"],
+                                     scales=g["m2_scales"], rotations=g["m2_rotations"], **common)
+    assert np.abs(st2["color"] - g["m2_label_render"]).max() < 2e-5 * max(1.0, np.abs(g["m2_label_render"]).max())
+    gr = Oracle(np.float32).backward(st2, g["wc"])
+    assert np.abs(gr["dL_dcolors_precomp"].sum(1, keepdims=True) - g["m2_g_label"]).max() < 1e-4 * np.abs(g["m2_g_label"]).max()
+
+
+@pytest.mark.gpu
+def test_render_through_hip_matches_reference_end_to_end():
+    """GPU: my render()/get_render_label() + HIP rasterizer reproduce the images and the PARAMETER gradients the
+    reference's render() + GaussianModel produced (with the oracle standing in for the absent CUDA kernel)."""
+    from egogaussian_amd.renderer import render, get_render_label
+    from egogaussian_amd.scene_synth import Pipe
+    g = load("boundary.npz")
+    dev = "cuda:0"
+    pc, cam = _model_from_boundary(g, dev)
+    bg = torch.tensor(g["bg"], device=dev)
+    out = render(cam, pc, Pipe, bg)
+    wc, wd, wa = [torch.tensor(g[k], device=dev) for k in ("wc", "wd", "wa")]
+    ((out["render"] * wc).sum() + (out["depth"] * wd).sum() + (out["alpha"] * wa).sum()).backward()
+    close = lambda a, b, tol=1e-4: np.abs(a.detach().cpu().numpy() - b).max() <= tol * max(np.abs(b).max(), 1e-12)
+    assert np.array_equal(out["radii"].cpu().numpy(), g["m1_radii"])
+    assert close(out["render"], g["m1_render"]) and close(out["depth"], g["m1_depth"]) and close(out["alpha"], g["m1_alpha"])
+    assert close(pc._xyz.grad, g["m1_g_xyz"]) and close(pc._features_dc.grad, g["m1_g_features_dc"])
+    assert close(pc._scaling.grad, g["m1_g_scaling"]) and close(pc._rotation.grad, g["m1_g_rotation"])
+    assert close(pc._opacity.grad, g["m1_g_opacity"]) and close(out["viewspace_points"].grad, g["m1_g_viewspace"])
+    lab = get_render_label(cam, pc, bg)
+    (lab * wc).sum().backward()
+    assert close(lab, g["m2_label_render"]) and close(pc._label.grad, g["m2_g_label"])

@@ -14,7 +14,7 @@ def main():
         f.write(f"# {title}\n\nSource: rocprofv3 --kernel-trace --stats (durations in microseconds).\n\n")
         f.write("| kernel | calls | total us | avg us | % of GPU time |\n|---|---:|---:|---:|---:|\n")
         for name, calls, tot, avg, pct in rows[:60]:
-            f.write(f"| `{str(name)[:110]}` | {calls} | {tot / 1e3:.1f} | {avg / 1e3:.2f} | {pct:.2f} |\n")
+            f.write(f"| `{str(name)[:110]}` | {calls} | {tot:.1f} | {avg:.2f} | {pct:.2f} |\n")
     print(f"wrote {out} ({len(rows)} kernels)")
 
 
