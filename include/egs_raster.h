@@ -23,8 +23,9 @@
  *
  * Conventions
  *   - All pointers are DEVICE pointers unless marked HOST.  fp32, contiguous, row-major.
- *   - The library never allocates or frees device memory and keeps no global state; every buffer is
- *     owned by the caller and must stay alive until the work enqueued on `stream` has completed.
+ *   - The library never allocates or frees device memory; every buffer is owned by the caller and must
+ *     stay alive until the work enqueued on `stream` has completed.  The only process-wide state is the
+ *     optional profiling pool (egs_profile_begin / egs_profile_end), off by default.
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it.  egs_forward_geometry is
  *     the only call that waits on the stream (one 8-byte device->host read of R).
  *   - Matrices use the reference's row-vector layout (/root/reference/scene/cameras.py:67-69):
