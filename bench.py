@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--width", type=int, default=960)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op-only", action="store_true", help="time rasterizer fwd+bwd only (seeded upstream grads)")
+    ap.add_argument("--torch-host-ops", action="store_true",
+                    help="build cov3D and the loss with PyTorch ops (as the reference does) instead of the fused HIP kernels")
     args = ap.parse_args()
 
     from egogaussian_amd import dist as egs_dist
@@ -74,6 +76,7 @@ def main():
     from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe, N_FRAMES
     from egogaussian_amd.renderer import render
     from egogaussian_amd.losses import training_loss, psnr
+    from egogaussian_amd.fused import l1_ssim_loss
     egs_lib.load()
 
     N, H, W = args.gaussians, args.height, args.width
@@ -88,11 +91,11 @@ def main():
         tpc = SynthGaussians(teacher, device=dev, requires_grad=False)
         gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
         del tpc
-    pc = SynthGaussians(student, device=dev)
+    pc = SynthGaussians(student, device=dev, fused=not args.torch_host_ops)
     opt = torch.optim.Adam([                                    # /root/reference/scene/gaussian_model.py:180-198 defaults
         {"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3},
         {"params": [pc._opacity], "lr": 0.05}, {"params": [pc._scaling], "lr": 5e-3},
-        {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15)
+        {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15, fused=True)
 
     def eval_psnr():
         with torch.no_grad():
@@ -109,8 +112,10 @@ def main():
         out = render(cams[k], pc, Pipe, bg)
         if args.op_only:
             loss = (out["render"] * up_c).sum() + (out["depth"] * up_d).sum() + (out["alpha"] * up_a).sum()
-        else:
+        elif args.torch_host_ops:
             loss = training_loss(out["render"], gts[k])
+        else:
+            loss = l1_ssim_loss(out["render"], gts[k], 0.2)
         loss.backward()
         if not args.op_only:
             opt.step()
@@ -198,7 +203,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"S({N},{H},{W},seed0) teacher/student, 300-frame orbit, 1 frame per GPU per step; step = "
                                + ("rasterizer fwd+bwd only (seeded upstream grads on colour/depth/alpha)" if args.op_only else
-                                  "cov3D(torch) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) + bwd (HIP+autograd) + Adam"),
+                                  ("cov3D(torch) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) (torch) + bwd + Adam" if args.torch_host_ops else
+                                   "cov3D (HIP) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) (HIP) + bwd (HIP+autograd) + Adam")),
                    "gaussians": N, "image": [H, W], "sh_degree": 0, "instances_R": int(R_mean), "sort_passes": passes,
                    "parallelism": f"frames sharded over {world} GPU(s), scalar all-reduce only"},
         "psnr_db": round(psnr_e, 3), "psnr_db_before": round(psnr_s, 3), "mean_loss": round(mean_loss, 6),

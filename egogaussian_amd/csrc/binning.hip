@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_duplicate(int P, const float4* __restri
     const uint32_t excl = have ? prev - wave_base : 0xffffffffu;     // start of my span, relative to the wave
     const uint32_t cnt = have ? incl - prev : 0u;
     uint2 rc = make_uint2(0u, 0u); uint32_t dbits = 0;
-    if (cnt) { rc = rect[i]; dbits = __float_as_uint(rec[(size_t)i * EGS_SPLAT_REC_F4].z); }
+    if (cnt) { rc = rect[i]; dbits = __float_as_uint(rec[(size_t)i * EGS_SPLAT_REC_F4 + 2].y); }
     const uint32_t total = wave_end - wave_base;
     for (uint32_t s0 = 0; s0 < total; s0 += 64) {
         const uint32_t s = s0 + lane;

@@ -31,14 +31,21 @@ __device__ __forceinline__ bool egs_bbox_hits(const float4& c, uint32_t qx0, uin
     return x0 <= qx1 && x1 >= qx0 && y0 <= qy1 && y1 >= qy0;
 }
 
-// alpha = min(0.99, o * exp(power)), power = -0.5 (A dx^2 + C dy^2) - B dx dy.
-// Returns a negative value when the published algorithm skips the pair (power > 0 or alpha < 1/255).
-// Explicit fma / mul so the forward and the backward evaluate bit-identical alphas.
-__device__ __forceinline__ float egs_alpha(float dx, float dy, float A, float B, float C, float o, float& G) {
-    float p = __fmul_rn(__fmul_rn(A, dx), dx);
-    p = __fmaf_rn(__fmul_rn(C, dy), dy, p);
-    const float power = __fmaf_rn(-__fmul_rn(B, dx), dy, __fmul_rn(-0.5f, p));
-    G = __builtin_amdgcn_exp2f(__fmul_rn(power, 1.4426950408889634f));
-    const float alpha = fminf(0.99f, __fmul_rn(o, G));
-    return (power > 0.f || alpha < (1.0f / 255.0f)) ? -1.f : alpha;
+// log2 of the Gaussian falloff from the pre-scaled conic (egs_common.h): qa dx^2 + qb dx dy + qc dy^2.
+// Explicit fma / mul so the forward and the backward evaluate bit-identical values.
+__device__ __forceinline__ float egs_log2_falloff(float dx, float dy, float qa, float qb, float qc) {
+    const float t = __fmaf_rn(qb, dy, __fmul_rn(qa, dx));
+    return __fmaf_rn(__fmul_rn(qc, dy), dy, __fmul_rn(t, dx));
+}
+
+// alpha = min(0.99, o * G) with the published skip rules folded in: returns 0 when the pair is skipped
+// (power > 0 or alpha < 1/255), so "alpha > 0" means "kept".  G = exp(power) is returned for the backward.
+// Both predicates stay in VCC -> v_cndmask form (no scalar mask round trip).
+__device__ __forceinline__ float egs_alpha(float dx, float dy, float qa, float qb, float qc, float o, float& G) {
+    const float p = egs_log2_falloff(dx, dy, qa, qb, qc);
+    G = __builtin_amdgcn_exp2f(p);
+    float a = fminf(0.99f, __fmul_rn(o, G));
+    a = p > 0.f ? 0.f : a;
+    a = a < (1.0f / 255.0f) ? 0.f : a;
+    return a;
 }

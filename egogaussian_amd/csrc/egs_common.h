@@ -10,9 +10,14 @@
 #define EGS_SPLAT_REC_F4 3          // float4 per packed splat record (48 B)
 
 // Packed per-Gaussian record produced by preprocess and gathered by the blend kernels:
-//   f4[0] = (x, y, depth, opacity)   f4[1] = (conA, conB, conC, red)
-//   f4[2] = (green, blue, bits(bbox_x = x0 | x1<<16), bits(bbox_y = y0 | y1<<16))
+//   f4[0] = (x, y, qa, qb)   f4[1] = (qc, opacity, red, green)
+//   f4[2] = (blue, depth, bits(bbox_x = x0 | x1<<16), bits(bbox_y = y0 | y1<<16))
+// (qa, qb, qc) = (-0.5 A, -B, -0.5 C) * log2(e): the conic pre-scaled so that
+//   log2(G) = qa dx^2 + qb dx dy + qc dy^2   feeds v_exp_f32 directly (5 VALU instead of 8).
+// The blend loop reads f4[0], f4[1] and the first half of f4[2] (ds_read_b128 x2 + ds_read_b64).
 // bbox = conservative pixel bounding box of {alpha >= 1/255}; x0 > x1 marks "never contributes".
+#define EGS_LOG2E 1.4426950408889634f
+#define EGS_LN2   0.6931471805599453f
 
 // Per-Gaussian gradient accumulator written by the blend backward (one 48-B line per Gaussian):
 //   [0]=dmean2D.x [1]=dmean2D.y [2]=dconic.xx [3]=dconic.xy(half) [4]=dconic.yy [5]=dopacity

@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void k_preprocess(
     rect_out[i] = make_uint2((uint32_t)rx0 | ((uint32_t)rx1 << 16), (uint32_t)ry0 | ((uint32_t)ry1 << 16));
     clamped_out[i] = (uint8_t)cl;
     float4* r = rec + (size_t)i * EGS_SPLAT_REC_F4;
-    r[0] = make_float4(px, py, e.t[2], o);
-    r[1] = make_float4(conA, conB, conC, rgb[0]);
-    r[2] = make_float4(rgb[1], rgb[2], __uint_as_float(bbx), __uint_as_float(bby));
+    r[0] = make_float4(px, py, (-0.5f * EGS_LOG2E) * conA, -EGS_LOG2E * conB);
+    r[1] = make_float4((-0.5f * EGS_LOG2E) * conC, o, rgb[0], rgb[1]);
+    r[2] = make_float4(rgb[2], e.t[2], __uint_as_float(bbx), __uint_as_float(bby));
 }
 
 __global__ __launch_bounds__(256) void k_preprocess_backward(

@@ -115,27 +115,29 @@ __global__ __launch_bounds__(256) void k_render_backward(
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << j);
-            const float4 s0 = my[j * 3 + 0], s1 = my[j * 3 + 1], s2 = my[j * 3 + 2];
+            const float4 s0 = my[j * 3 + 0], s1 = my[j * 3 + 1];
+            const float2 s2 = *reinterpret_cast<const float2*>(&my[j * 3 + 2]);
             const float dx = s0.x - pxf, dy = s0.y - pyf;
             float G;
-            const float alpha = egs_alpha(dx, dy, s1.x, s1.y, s1.z, s0.w, G);
-            const bool contrib = (base + (uint32_t)j + 1u <= last) && alpha >= 0.f;
-            if (__ballot(contrib) == 0ull) continue;
-            const float a = contrib ? alpha : 0.f;
+            const float alpha = egs_alpha(dx, dy, s0.z, s0.w, s1.x, s1.y, G);
+            const float a = (base + (uint32_t)j + 1u <= last) ? alpha : 0.f;          // 0 = this pixel does not use the splat
+            if (__ballot(a > 0.f) == 0ull) continue;
             const float rcp = __builtin_amdgcn_rcpf(1.f - a);
             const float Tn = T * rcp;                                   // transmittance in front of this splat
-            const float w = contrib ? a * Tn : 0.f;
-            const float u = fmaf(s1.w, g_r, fmaf(s2.x, g_g, fmaf(s2.y, g_b, fmaf(s0.z, g_d, g_a))));
+            const float w = a * Tn;
+            const float u = fmaf(s1.z, g_r, fmaf(s1.w, g_g, fmaf(s2.x, g_b, fmaf(s2.y, g_d, g_a))));
             const float Un = fmaf(last_alpha, last_u - U, U);
-            float dLda = (u - Un) * Tn;
-            dLda = fmaf(bg_term, rcp, dLda);
+            const bool contrib = a > 0.f;
+            float dLda = fmaf(bg_term, rcp, (u - Un) * Tn);
             dLda = contrib ? dLda : 0.f;
-            T = contrib ? Tn : T; U = contrib ? Un : U; last_u = contrib ? u : last_u; last_alpha = contrib ? a : last_alpha;
+            T = Tn; U = contrib ? Un : U; last_u = contrib ? u : last_u; last_alpha = contrib ? a : last_alpha;
 
-            const float dL_dG = s0.w * dLda;
+            // conic in natural units: A = qa * (-2 ln2), B = qb * (-ln2), C = qc * (-2 ln2)
+            const float dL_dG = s1.y * dLda;
             const float gdx = G * dx, gdy = G * dy;
-            float v0 = dL_dG * (-gdx * s1.x - gdy * s1.y);             // d/d mean2D.x (pixel units)
-            float v1 = dL_dG * (-gdy * s1.z - gdx * s1.y);             // d/d mean2D.y
+            const float gA = s0.z * (-2.f * EGS_LN2), gB = s0.w * (-EGS_LN2), gC = s1.x * (-2.f * EGS_LN2);
+            float v0 = dL_dG * (-gdx * gA - gdy * gB);                  // d/d mean2D.x (pixel units)
+            float v1 = dL_dG * (-gdy * gC - gdx * gB);                  // d/d mean2D.y
             const float h = -0.5f * dL_dG;
             float v2 = h * gdx * dx, v3 = h * gdx * dy, v4 = h * gdy * dy;   // conic xx, xy (half), yy
             float v5 = G * dLda;                                        // opacity

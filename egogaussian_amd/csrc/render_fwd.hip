@@ -10,6 +10,8 @@
 //     the wave's quadrant, and a 64-bit ballot becomes the work list -- splats that cannot reach the
 //     quadrant cost nothing (s_ff1 over the mask), which removes roughly half of the (pixel, splat)
 //     evaluations of a whole-tile loop at 3DGS-typical footprints;
+//   * per-pixel state is branch-free: predicates live in VCC and feed v_cndmask directly, a stopped pixel is
+//     represented by a live transmittance of 0, and the loop exit is one s_cbranch on the `cont` compare;
 //   * surviving records are parked in a wave-private 3 KiB LDS slice and re-read with a wave-uniform
 //     address (hardware broadcast, conflict-free) -- the LDS is a register-file extension here, not a
 //     cross-wave exchange;
@@ -43,9 +45,10 @@ __global__ __launch_bounds__(256) void k_render_forward(
     const uint32_t n = range.y - range.x;
     const uint32_t* list = point_list + range.x;
 
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f, Aacc = 0.f;
+    // Tl: live transmittance, forced to 0 once the pixel has stopped (so later splats add nothing);
+    // Tf: the value final_T reports.  Invariant while live: Tl == Tf >= 1e-4.
+    float Tl = inside ? 1.f : 0.f, Tf = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f, Aacc = 0.f;
     uint32_t last = 0;
-    bool done = !inside;
 
     // software pipeline: ids two batches ahead, records one batch ahead
     uint32_t id_next = lane < n ? list[lane] : 0u;
@@ -53,7 +56,8 @@ __global__ __launch_bounds__(256) void k_render_forward(
     egs_load_rec(rec, id_next, lane < n, r0, r1, r2);
     id_next = 64 + lane < n ? list[64 + lane] : 0u;
 
-    for (uint32_t base = 0; base < n; base += 64) {
+    bool alive = true;                                             // wave-uniform: some pixel still live
+    for (uint32_t base = 0; alive && base < n; base += 64) {
         const float4 c0 = r0, c1 = r1, c2 = r2;
         const bool have = base + lane < n;
         // issue the next batch's gathers now
@@ -64,27 +68,26 @@ __global__ __launch_bounds__(256) void k_render_forward(
         if (mask == 0ull) continue;
         my[lane * 3 + 0] = c0; my[lane * 3 + 1] = c1; my[lane * 3 + 2] = c2;
         __builtin_amdgcn_wave_barrier();
-        while (mask) {
+        do {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1ull;
-            const float4 s0 = my[j * 3 + 0], s1 = my[j * 3 + 1], s2 = my[j * 3 + 2];
+            const float4 s0 = my[j * 3 + 0], s1 = my[j * 3 + 1];
+            const float2 s2 = *reinterpret_cast<const float2*>(&my[j * 3 + 2]);
             float G;
-            const float alpha = egs_alpha(s0.x - pxf, s0.y - pyf, s1.x, s1.y, s1.z, s0.w, G);
-            // alpha < 0 encodes "skip" (power > 0 or alpha < 1/255)
-            const float test_T = T * (1.f - alpha);
-            const bool live = !done && alpha >= 0.f;
-            const bool stop = live && test_T < 0.0001f;
-            const bool add = live && !stop;
-            const float w = add ? alpha * T : 0.f;
-            C0 = fmaf(s1.w, w, C0); C1 = fmaf(s2.x, w, C1); C2 = fmaf(s2.y, w, C2);
-            Dacc = fmaf(s0.z, w, Dacc); Aacc += w;
-            T = add ? test_T : T;
-            last = add ? base + (uint32_t)j + 1u : last;
-            done = done || stop;
-            if (__ballot(!done) == 0ull) { mask = 0ull; base = n; }      // whole quadrant saturated
-        }
+            const float a = egs_alpha(s0.x - pxf, s0.y - pyf, s0.z, s0.w, s1.x, s1.y, G);   // 0 = skipped
+            const float test = fmaf(-a, Tl, Tl);                  // T (1 - alpha); == Tl when skipped, 0 when stopped
+            const bool cont = test >= 0.0001f;                    // false: this splat stops the pixel (or already stopped)
+            const float w = cont ? a * Tl : 0.f;
+            C0 = fmaf(s1.z, w, C0); C1 = fmaf(s1.w, w, C1); C2 = fmaf(s2.x, w, C2);
+            Dacc = fmaf(s2.y, w, Dacc); Aacc += w;
+            Tf = cont ? test : Tf;
+            Tl = cont ? test : 0.f;
+            last = w > 0.f ? base + (uint32_t)j + 1u : last;
+            alive = __ballot(cont) != 0ull;                       // whole quadrant saturated -> leave
+        } while (mask != 0ull && alive);
         __builtin_amdgcn_wave_barrier();
     }
+    const float T = Tf;
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         final_T[pix] = T; n_contrib[pix] = last;

@@ -1,0 +1,129 @@
+"""Autograd wrappers of the fused HIP ops on the "next" rows of SURVEY.md section 8f, bound through the same C ABI:
+
+  covariance_from_scaling_rotation / rotated_covariance_from_scaling_rotation   (row f-1)
+      drop-in for the reference's covariance activations (/root/reference/scene/gaussian_model.py:29-33,46-63).  A
+      reference GaussianModel can be pointed at them after construction:
+          gaussians.covariance_activation = egogaussian_amd.fused.covariance_from_scaling_rotation
+  l1_ssim_loss   (row f-3)
+      (1 - lambda) * l1_loss + lambda * (1 - ssim), /root/reference/trainers/train_static.py:92-95.
+
+HIP device tensors only.  Their oracles are the PyTorch versions in covariance.py / losses.py, which are pinned by
+fixtures captured from the reference (tests/golden/covariance.npz, losses.npz).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _lib
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_hip(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: fused HIP op has no CPU path (use egogaussian_amd.covariance / losses)")
+    return t.float().contiguous()
+
+
+class _Cov3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scaling, rotation, M, selected, modifier, row0_mult):
+        L = _lib.load()
+        scaling, rotation = _need_hip(scaling, "scaling"), _need_hip(rotation, "rotation")
+        N = scaling.shape[0]
+        Mc = None if M is None else _need_hip(M, "M").reshape(9)
+        sel = None if selected is None else selected.to(torch.uint8).contiguous()
+        cov = torch.empty((N, 6), device=scaling.device, dtype=torch.float32)
+        with torch.cuda.device(scaling.device):
+            _lib.check(L.egs_cov3d_forward(N, _p(scaling), float(modifier), _p(rotation), _p(Mc), _p(sel), _p(cov), _stream()))
+        ctx.save_for_backward(scaling, rotation, Mc if Mc is not None else torch.empty(0), sel if sel is not None else torch.empty(0))
+        ctx.modifier, ctx.row0_mult, ctx.has_M, ctx.has_sel = float(modifier), float(row0_mult), M is not None, selected is not None
+        return cov
+
+    @staticmethod
+    def backward(ctx, dcov):
+        L = _lib.load()
+        scaling, rotation, Mc, sel = ctx.saved_tensors
+        Mc = Mc if ctx.has_M else None
+        sel = sel if ctx.has_sel else None
+        N = scaling.shape[0]
+        dcov = dcov.float().contiguous()
+        ds, dr = torch.empty_like(scaling), torch.empty_like(rotation)
+        dM = torch.empty(9, device=scaling.device) if (ctx.has_M and ctx.needs_input_grad[2]) else None
+        with torch.cuda.device(scaling.device):
+            _lib.check(L.egs_cov3d_backward(N, _p(scaling), ctx.modifier, _p(rotation), _p(Mc), _p(sel), ctx.row0_mult, _p(dcov),
+                                            _p(ds), _p(dr), _p(dM), _stream()))
+        return ds, dr, (None if dM is None else dM.view(3, 3)), None, None, None
+
+
+def covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
+    return _Cov3D.apply(scaling, rotation, None, None, scaling_modifier, 1.0)
+
+
+def rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation, accum_R, is_object=None, which_object=None,
+                                             rot_matrix=None):
+    """`rot_matrix` (3x3, may require grad) is the trainable object rotation applied on top of accum_R during training
+    (trainable_object_move.rot_L in the reference).  Keeps the reference's [N,1]-index quirk, see covariance.py."""
+    dev = scaling.device
+    if accum_R is None:
+        accum_R = torch.eye(3, device=dev)
+    M = accum_R.to(dev).float()
+    if rot_matrix is not None:
+        M = rot_matrix @ M
+    n = scaling.shape[0]
+    sel, mult = None, 1.0
+    if which_object is not None and is_object is not None:
+        sel = (is_object.reshape(-1) == which_object)
+        if is_object.dim() == 2 and n > 0:
+            cnt = int(sel.sum().item())                      # host read: the count is a gradient multiplier for Gaussian 0
+            if cnt > 0:
+                mult = float(cnt + int(sel[0].item()))
+                sel = sel.clone(); sel[0] = True
+    elif is_object is not None and is_object.dim() == 2 and n > 0:
+        mult = float(n + 1)
+    return _Cov3D.apply(scaling, rotation, M, sel, scaling_modifier, mult)
+
+
+class _L1SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, gt, lambda_dssim, gate):
+        L = _lib.load()
+        img, gt = _need_hip(img, "image"), _need_hip(gt, "gt")
+        assert img.dim() == 3 and img.shape == gt.shape
+        Cc, H, W = img.shape
+        dev = img.device
+        partial = torch.empty(L.egs_l1_ssim_partial_count(Cc, H, W), device=dev)
+        maps = torch.empty((3, Cc, H, W), device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.egs_l1_ssim_forward(Cc, H, W, _p(img), _p(gt), _p(partial), _p(maps[0]), _p(maps[1]), _p(maps[2]), _stream()))
+        sums = partial.view(-1, 2).sum(0)
+        n = float(Cc * H * W)
+        loss = (1.0 - lambda_dssim) * (sums[0] / n) + lambda_dssim * (1.0 - sums[1] / n)
+        ctx.save_for_backward(img, gt, maps, gate if gate is not None else torch.empty(0))
+        ctx.lam, ctx.has_gate = float(lambda_dssim), gate is not None
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.load()
+        img, gt, maps, gate = ctx.saved_tensors
+        gate = gate.float().contiguous() if ctx.has_gate else None
+        Cc, H, W = img.shape
+        g = g.reshape(1).float().contiguous()
+        dimg = torch.empty_like(img)
+        with torch.cuda.device(img.device):
+            _lib.check(L.egs_l1_ssim_backward(Cc, H, W, _p(img), _p(gt), ctx.lam, _p(g), _p(gate), _p(maps[0]), _p(maps[1]),
+                                              _p(maps[2]), _p(dimg), _stream()))
+        return dimg, None, None, None
+
+
+def l1_ssim_loss(image, gt, lambda_dssim=0.2, grad_gate=None):
+    """(1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)).  `grad_gate` [H,W] multiplies d loss / d image
+    per pixel (the reference's `render_image.register_hook(lambda grad: grad * (1 - hand_mask))`)."""
+    return _L1SSIM.apply(image, gt, lambda_dssim, grad_gate)

@@ -114,9 +114,10 @@ class SynthGaussians:
     scene.gaussian_model.GaussianModel (/root/reference/scene/gaussian_model.py:125-171) over a synthetic scene.
     Raw parameters are leaf tensors; activations match the reference (exp, sigmoid, normalize)."""
 
-    def __init__(self, scene, device="cpu", sh_degree=0, requires_grad=True):
+    def __init__(self, scene, device="cpu", sh_degree=0, requires_grad=True, fused=True):
         from . import covariance as _cov
         self._cov = _cov
+        self.fused = fused            # use the fused HIP covariance producer (row f-1) when on a HIP device
         t = lambda a: torch.tensor(a, device=device).requires_grad_(requires_grad)
         self._xyz = t(scene["xyz"])
         self._features_dc = t(scene["features"][:, :1].copy())
@@ -150,12 +151,21 @@ class SynthGaussians:
     def get_is_object(self): return self._is_object
 
     def get_covariance(self, scaling_modifier=1):
+        if self.fused and self._xyz.is_cuda:
+            from . import fused
+            return fused.covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
         return self._cov.covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
 
     def get_rotated_covariance(self, accum_R, which_object, during_training, scaling_modifier=1):
-        rot_L = self.trainable_object_move.rot_L if (during_training and self.trainable_object_move is not None) else None
+        tom = self.trainable_object_move if during_training else None
+        if self.fused and self._xyz.is_cuda:
+            from . import fused
+            return fused.rotated_covariance_from_scaling_rotation(
+                self.get_scaling, scaling_modifier, self._rotation, accum_R, self._is_object, which_object,
+                None if tom is None else tom.rot_matrix())
         return self._cov.rotated_covariance_from_scaling_rotation(
-            self.get_scaling, scaling_modifier, self._rotation, accum_R, self._is_object, which_object, rot_L)
+            self.get_scaling, scaling_modifier, self._rotation, accum_R, self._is_object, which_object,
+            None if tom is None else tom.rot_L)
 
 
 class Pipe:

@@ -132,6 +132,36 @@ int egs_backward(
 int egs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present /*[P] out, 0/1*/, void* stream);
 
+/* ==== "next" rows of SURVEY.md section 8f: the callers either side of the rasterizer ======================= */
+
+/* ---- f-1: fused 3D covariance producer.  Replaces build_scaling_rotation / strip_symmetric
+ *      (/root/reference/utils/general_utils.py:110-156) and the covariance activations
+ *      (/root/reference/scene/gaussian_model.py:29-33,46-63):
+ *      q <- q/|q|; L = R(q) diag(scale_modifier * scaling); rows with selected[i] != 0 (all rows if selected == NULL)
+ *      get L <- M L when M9 != NULL; cov6 = unique entries of L L^T in the order (00,01,02,11,12,22). */
+int egs_cov3d_forward(int N, const float* scaling /*[N,3]*/, float scale_modifier, const float* rotation /*[N,4] raw*/,
+                      const float* M9 /*[9] device, row-major, or NULL*/, const uint8_t* selected /*[N] or NULL*/,
+                      float* cov6 /*[N,6] out*/, void* stream);
+/* row0_grad_mult reproduces the reference's duplicated-index gradient on Gaussian 0 (egogaussian_amd/covariance.py);
+ * pass 1.0 otherwise.  dL_dM9 (device [9], may be NULL) is zeroed and accumulated by the callee. */
+int egs_cov3d_backward(int N, const float* scaling, float scale_modifier, const float* rotation, const float* M9,
+                       const uint8_t* selected, float row0_grad_mult, const float* dL_dcov6 /*[N,6]*/,
+                       float* dL_dscaling /*[N,3] out*/, float* dL_drotation /*[N,4] out*/, float* dL_dM9, void* stream);
+
+/* ---- f-3: fused image loss (1 - lambda) * L1 + lambda * (1 - SSIM), 11x11 Gaussian window sigma 1.5, zero padding.
+ *      Replaces l1_loss + ssim (/root/reference/utils/loss_utils.py:57-107) as combined at
+ *      /root/reference/trainers/train_static.py:92-95.  The forward writes per-block partial sums
+ *      (pairs: sum|x-y|, sum SSIM_map; egs_l1_ssim_partial_count floats) for the caller to add up, and three
+ *      derivative maps [C,H,W] the backward consumes.  `gate` (optional, [H,W]) multiplies the image gradient
+ *      per pixel -- the hand-mask hook of train_static.py:91. */
+size_t egs_l1_ssim_partial_count(int channels, int height, int width);
+int egs_l1_ssim_forward(int channels, int height, int width, const float* img /*[C,H,W]*/, const float* gt /*[C,H,W]*/,
+                        float* partial_sums, float* dm_dmu1, float* dm_dexx, float* dm_dexy, void* stream);
+int egs_l1_ssim_backward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
+                         const float* upstream_grad /*device [1]*/, const float* gate /*[H,W] or NULL*/,
+                         const float* dm_dmu1, const float* dm_dexx, const float* dm_dexy, float* dL_dimg /*[C,H,W] out*/,
+                         void* stream);
+
 /* ---- optional per-stage timing with HIP events on the caller's stream (bench / profiling aid) ------
  * The only process-wide state in the library; off by default.  egs_profile_begin allocates an event pool and
  * turns recording on; every stage launched afterwards is bracketed by two events on its stream;

@@ -1,0 +1,92 @@
+"""GPU: the fused HIP ops of the 'next' rows (f-1 covariance producer, f-3 image loss) against their PyTorch versions,
+which tests/test_golden_host.py pins to the reference's own outputs; plus the reference fixtures directly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda:0"
+
+
+def _close(a, b, rtol=2e-5, atol=0.0):
+    a = a.detach().cpu().double().numpy(); b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    return np.abs(a - b).max() <= atol + rtol * max(np.abs(b).max(), 1e-30)
+
+
+def test_fused_covariance_matches_torch_and_reference_fixture():
+    from egogaussian_amd import fused, covariance as ref
+    g = np.load(os.path.join(GOLD, "covariance.npz"))
+    T = lambda a: torch.tensor(np.asarray(a), device=DEV)
+    for variant in ("plain", "mod2", "rotated", "rotated_all"):
+        ls, q = T(g["log_scale"]).requires_grad_(True), T(g["quat"]).requires_grad_(True)
+        ls2, q2 = T(g["log_scale"]).requires_grad_(True), T(g["quat"]).requires_grad_(True)
+        w, R, io = T(g["wcov"]), T(g["accum_R"]), T(g["is_object"])
+        if variant == "plain":
+            a, b, gold = fused.covariance_from_scaling_rotation(torch.exp(ls), 1.0, q), ref.covariance_from_scaling_rotation(torch.exp(ls2), 1.0, q2), g["cov"]
+        elif variant == "mod2":
+            a, b, gold = fused.covariance_from_scaling_rotation(torch.exp(ls), 2.0, q), ref.covariance_from_scaling_rotation(torch.exp(ls2), 2.0, q2), g["cov_mod2"]
+        elif variant == "rotated":
+            a = fused.rotated_covariance_from_scaling_rotation(torch.exp(ls), 1.0, q, R, io, 1)
+            b, gold = ref.rotated_covariance_from_scaling_rotation(torch.exp(ls2), 1.0, q2, R, io, 1), g["rcov"]
+        else:
+            a = fused.rotated_covariance_from_scaling_rotation(torch.exp(ls), 1.0, q, R, io, None)
+            b, gold = ref.rotated_covariance_from_scaling_rotation(torch.exp(ls2), 1.0, q2, R, io, None), g["rcov_all"]
+        assert _close(a, b) and _close(a, gold), variant
+        (a * w).sum().backward(); (b * w).sum().backward()
+        assert _close(ls.grad, ls2.grad, 1e-4) and _close(q.grad, q2.grad, 1e-4), variant
+        if variant == "plain":
+            assert _close(ls.grad, g["g_scaling"], 1e-4) and _close(q.grad, g["g_rotation"], 1e-4)
+        if variant == "rotated":
+            assert _close(ls.grad, g["rg_scaling"], 1e-4) and _close(q.grad, g["rg_rotation"], 1e-4)
+
+
+def test_fused_covariance_trainable_rotation_gradient():
+    from egogaussian_amd import fused, covariance as ref
+    gen = torch.Generator().manual_seed(3)
+    N = 5000
+    s = (torch.rand(N, 3, generator=gen) * 0.1 + 0.01).to(DEV)
+    q = torch.randn(N, 4, generator=gen).to(DEV)
+    io = (torch.rand(N, 1, generator=gen) < 0.4).float().to(DEV)
+    w = torch.randn(N, 6, generator=gen).to(DEV)
+    A = torch.linalg.qr(torch.randn(3, 3, generator=gen))[0].to(DEV)
+    Rt = torch.linalg.qr(torch.randn(3, 3, generator=gen))[0].to(DEV).requires_grad_(True)
+    Rt2 = Rt.detach().clone().requires_grad_(True)
+    a = fused.rotated_covariance_from_scaling_rotation(s, 1.0, q, A, io, 1, rot_matrix=Rt)
+    b = ref.rotated_covariance_from_scaling_rotation(s, 1.0, q, A, io, 1, rot_L=lambda L: torch.matmul(Rt2, L))
+    assert _close(a, b)
+    (a * w).sum().backward(); (b * w).sum().backward()
+    assert _close(Rt.grad, Rt2.grad, 2e-4)
+
+
+@pytest.mark.parametrize("C,H,W", [(3, 40, 56), (3, 37, 50), (1, 16, 16), (3, 540, 960)])
+def test_fused_loss_matches_torch(C, H, W):
+    from egogaussian_amd.fused import l1_ssim_loss
+    from egogaussian_amd.losses import training_loss
+    gen = torch.Generator().manual_seed(H * W)
+    a = torch.rand(C, H, W, generator=gen).to(DEV).requires_grad_(True)
+    b = (a.detach() + 0.1 * torch.randn(C, H, W, generator=gen).to(DEV)).clamp(0, 1)
+    a2 = a.detach().clone().requires_grad_(True)
+    gate = (torch.rand(H, W, generator=gen) > 0.3).float().to(DEV)
+    l1 = l1_ssim_loss(a, b, 0.2, grad_gate=gate)
+    l2 = training_loss(a2, b, 0.2)
+    assert abs(l1.item() - l2.item()) < 2e-6 * max(1.0, abs(l2.item()))
+    (3.0 * l1).backward()
+    a2.register_hook(lambda g: g)        # noqa
+    (3.0 * l2).backward()
+    assert _close(a.grad, a2.grad * gate[None], 2e-4)
+
+
+def test_fused_loss_matches_reference_fixture():
+    from egogaussian_amd.fused import l1_ssim_loss
+    g = np.load(os.path.join(GOLD, "losses.npz"))
+    a = torch.tensor(g["a"], device=DEV).requires_grad_(True)
+    b = torch.tensor(g["b"], device=DEV)
+    ssim_only = l1_ssim_loss(a, b, 1.0)                 # lambda = 1: loss = 1 - SSIM
+    assert abs((1.0 - ssim_only.item()) - float(g["ssim"])) < 3e-6
+    ssim_only.backward()
+    assert _close(-a.grad, g["ssim_grad_a"], 1e-3)
+    l1_only = l1_ssim_loss(a.detach(), b, 0.0)
+    assert abs(l1_only.item() - float(g["l1"])) < 1e-6

@@ -86,11 +86,15 @@ def test_forward_and_backward_parity(N, H, W, seed, deg, mode, smul):
     gv = _C.geom_views(geom, N)
     vis = st["radii"] > 0
     assert np.array_equal(gv["offsets"].cpu().numpy().view(np.uint32), st["offsets"])
-    rec = gv["rec"].cpu().numpy()
+    rec = gv["rec"].cpu().numpy()        # (x, y, qa, qb | qc, opacity, r, g | b, depth, bbox_x, bbox_y), egs_common.h
     assert np.array_equal(rec[vis, 0:2].view(np.uint32), st["xy"][vis].view(np.uint32)), "pixel centres not bit-exact"
-    assert np.array_equal(rec[vis, 2].view(np.uint32), st["depths"][vis].view(np.uint32)), "depth not bit-exact"
-    assert np.array_equal(rec[vis, 4:7].view(np.uint32), st["conic_opacity"][vis, 0:3].view(np.uint32)), "conic not bit-exact"
-    rgb_hip = np.stack([rec[:, 7], rec[:, 8], rec[:, 9]], 1)
+    assert np.array_equal(rec[vis, 9].view(np.uint32), st["depths"][vis].view(np.uint32)), "depth not bit-exact"
+    LOG2E = np.float32(1.4426950408889634)
+    con = st["conic_opacity"][vis]
+    q_expect = np.stack([np.float32(-0.5) * LOG2E * con[:, 0], -LOG2E * con[:, 1], np.float32(-0.5) * LOG2E * con[:, 2]], 1)
+    assert np.array_equal(rec[vis][:, [2, 3, 4]].view(np.uint32), q_expect.astype(np.float32).view(np.uint32)), "conic not bit-exact"
+    assert np.array_equal(rec[vis, 5].view(np.uint32), con[:, 3].view(np.uint32))
+    rgb_hip = np.stack([rec[:, 6], rec[:, 7], rec[:, 8]], 1)
     assert rel_err(rgb_hip[vis], st["rgb"][vis]) < 1e-6
     rect = gv["rect"].cpu().numpy().view(np.uint32)
     rects_hip = np.stack([rect[:, 0] & 0xffff, rect[:, 1] & 0xffff, rect[:, 0] >> 16, rect[:, 1] >> 16], 1).astype(np.int32)
