@@ -37,13 +37,11 @@ PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
 def algorithmic_bytes(stage, N, R, npix, passes):
-    """Bytes one launch of `stage` must move at minimum (DESIGN.md section 'Kernels'): per-unit figures x units."""
+    """Bytes one launch of `stage` must move at minimum: per-unit figures x units."""
     return {
         "preprocess": 52 * N + 48 * N,                 # xyz 12 + cov 24 + opacity 4 + sh 12 in; record 48 out
-        "scan": 8 * N,
-        "duplicate": 12 * N + 12 * R,                  # offsets + rect in; key 8 + value 4 out
-        "sort": passes * 24 * R,                       # per pass: read 12, write 12 per instance
-        "tile_ranges": 8 * R,
+        "tile_bucket": 2 * 16 * N + 8 * R,             # two walks over (tiles_touched, rect, depth) per Gaussian; one pair out per instance
+        "tile_sort": 8 * R + 4 * R,                    # pair in, index out; the radix passes stay in registers/LDS
         "render_forward": 4 * R + 48 * R + 28 * npix,  # id + record per instance; 7 floats per pixel out
         "render_backward": 4 * R + 48 * R + 40 * R + 32 * npix,   # + one 40-byte accumulate per instance; 8 floats/pixel in
         "preprocess_backward": 48 * N + 52 * N + 100 * N,          # accumulator + inputs in; grads out
@@ -151,7 +149,7 @@ def main():
         return
 
     npix = H * W
-    passes = _C.binning_passes(W, H)
+    passes = _C.binning_passes(N, W, H)
     stage_rows, dominant = {}, None
     for name, (ms, n) in stages.items():
         if n == 0:

@@ -17,11 +17,11 @@ from . import lib as _lib
 stats = {"num_rendered": 0}       # R of the most recent forward (read by bench.py)
 
 
-def binning_passes(W, H):
-    """Radix passes the sort runs for a W x H image."""
+def binning_passes(P, W, H):
+    """8-bit radix passes of the per-tile (depth, index) sort for P Gaussians."""
     lay = _lib.BinningLayout()
-    _lib.check(_lib.load().egs_get_binning_layout(0, int(W), int(H), C.byref(lay)))
-    return int(lay.passes)
+    _lib.check(_lib.load().egs_get_binning_layout(int(P), 0, int(W), int(H), C.byref(lay)))
+    return int(lay.index_passes) + 4
 
 
 def _ptr(t):
@@ -77,7 +77,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
                 _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom),
                 C.byref(R), _stream(), int(bool(debug))))
-        binning = torch.empty((L.egs_binning_bytes(R.value, W, H),), device=dev, dtype=torch.uint8)
+        binning = torch.empty((L.egs_binning_bytes(P, R.value, W, H),), device=dev, dtype=torch.uint8)
         _lib.check(L.egs_forward_render(P, R.value, _ptr(background), W, H, _ptr(geom), _ptr(binning), _ptr(img),
                                         _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), _stream(), int(bool(debug))))
     stats["num_rendered"] = int(R.value)
@@ -150,14 +150,14 @@ def geom_views(geom, P):
                 offsets=v(lay.offsets, P * 4, torch.int32), clamped=geom[lay.clamped:lay.clamped + P])
 
 
-def binning_views(binning, R, W, H):
+def binning_views(binning, P, R, W, H):
     lay = _lib.BinningLayout()
-    _lib.check(_lib.load().egs_get_binning_layout(R, W, H, C.byref(lay)))
-    ko, vo = (lay.keys_b, lay.vals_b) if lay.sorted_in_b else (lay.keys_a, lay.vals_a)
-    uo, wo = (lay.keys_a, lay.vals_a) if lay.sorted_in_b else (lay.keys_b, lay.vals_b)
-    return dict(keys=binning[ko:ko + R * 8].view(torch.int64), point_list=binning[vo:vo + R * 4].view(torch.int32),
-                scratch_keys=binning[uo:uo + R * 8].view(torch.int64), scratch_vals=binning[wo:wo + R * 4].view(torch.int32),
-                key_bits=lay.key_bits, passes=lay.passes)
+    _lib.check(_lib.load().egs_get_binning_layout(P, R, W, H, C.byref(lay)))
+    nt = ((W + 15) // 16) * ((H + 15) // 16)
+    return dict(point_list=binning[lay.point_list:lay.point_list + R * 4].view(torch.int32),
+                pairs=binning[lay.pairs:lay.pairs + R * 8].view(torch.int64),
+                table=binning[lay.table:lay.table + nt * lay.bin_blocks * 4].view(torch.int32).view(nt, lay.bin_blocks) if R else None,
+                key_bits=lay.key_bits, index_passes=lay.index_passes, bin_blocks=lay.bin_blocks)
 
 
 def image_views(img, W, H):

@@ -4,6 +4,7 @@
 // /root/reference/gaussian_renderer/__init__.py:14.
 #include "egs_common.h"
 #include <string.h>
+#include <vector>
 
 namespace {
 
@@ -17,23 +18,23 @@ GeomLayout geom_layout(int P) {
     L.o.rect = off;         off = egs_align(off + n * sizeof(uint2));
     L.o.offsets = off;      off = egs_align(off + n * sizeof(uint32_t));
     L.o.clamped = off;      off = egs_align(off + n);
-    L.o.scan_scratch = off; off = egs_align(off + egs_scan_scratch_elems(n) * sizeof(uint32_t));
+    L.o.scan_scratch = off; off = egs_align(off + ((n + 255) / 256 + 64) * sizeof(uint32_t));     // per-block instance counts
     L.o.total = off;        off = egs_align(off + sizeof(uint64_t));
     L.bytes = off; return L;
 }
-BinLayout bin_layout(int64_t R, int W, int H) {
+BinLayout bin_layout(int P, int64_t R, int W, int H) {
     BinLayout L; size_t off = 0; const size_t n = (size_t)(R > 0 ? R : 0);
-    const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
-    L.o.key_bits = egs_key_bits_for_tiles(gx * gy);
-    L.o.passes = (L.o.key_bits + EGS_SORT_BITS - 1) / EGS_SORT_BITS;
-    L.o.sorted_in_b = L.o.passes & 1;
-    const size_t nblocks = (n + EGS_SORT_KPB - 1) / EGS_SORT_KPB;
-    L.o.keys_a = off; off = egs_align(off + n * sizeof(uint64_t));
-    L.o.keys_b = off; off = egs_align(off + n * sizeof(uint64_t));
-    L.o.vals_a = off; off = egs_align(off + n * sizeof(uint32_t));
-    L.o.vals_b = off; off = egs_align(off + n * sizeof(uint32_t));
-    L.o.hist = off;   off = egs_align(off + nblocks * EGS_SORT_BINS * sizeof(uint32_t));
-    L.o.spine = off;  off = egs_align(off + egs_scan_scratch_elems(nblocks * EGS_SORT_BINS) * sizeof(uint32_t));
+    const size_t gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
+    const size_t nblocks = egs_bin_blocks(P > 0 ? P : 0), tab = gx * gy * nblocks;
+    L.o.key_bits = egs_key_bits_for_tiles((int)(gx * gy));
+    L.o.bin_blocks = (int)nblocks;
+    int ib = 0; while (P > 1 && (((unsigned)(P - 1)) >> ib) != 0) ib++;
+    L.o.index_passes = (ib + 7) / 8;
+    L.o.pairs = off;      off = egs_align(off + n * sizeof(uint64_t));
+    L.o.scratch = off;    off = egs_align(off + n * sizeof(uint64_t));
+    L.o.point_list = off; off = egs_align(off + n * sizeof(uint32_t));
+    L.o.table = off;      off = egs_align(off + (n ? tab : 0) * sizeof(uint32_t));
+    L.o.spine = off;      off = egs_align(off + (n ? egs_scan_scratch_elems(tab) : 0) * sizeof(uint32_t));
     L.bytes = off; return L;
 }
 ImgLayout img_layout(int W, int H) {
@@ -50,12 +51,11 @@ EgsGeomPtrs geom_ptrs(void* buf, int P) {
     g.clamped = (uint8_t*)(b + L.o.clamped); g.scan_scratch = (uint32_t*)(b + L.o.scan_scratch);
     g.total = (uint64_t*)(b + L.o.total); return g;
 }
-EgsBinPtrs bin_ptrs(void* buf, int64_t R, int W, int H) {
-    const BinLayout L = bin_layout(R, W, H); char* b = (char*)buf; EgsBinPtrs p;
-    p.keys_a = (uint64_t*)(b + L.o.keys_a); p.keys_b = (uint64_t*)(b + L.o.keys_b);
-    p.vals_a = (uint32_t*)(b + L.o.vals_a); p.vals_b = (uint32_t*)(b + L.o.vals_b);
-    p.hist = (uint32_t*)(b + L.o.hist); p.spine = (uint32_t*)(b + L.o.spine);
-    p.sorted_in_b = L.o.sorted_in_b; p.key_bits = L.o.key_bits; p.passes = L.o.passes; return p;
+EgsBinPtrs bin_ptrs(void* buf, int P, int64_t R, int W, int H) {
+    const BinLayout L = bin_layout(P, R, W, H); char* b = (char*)buf; EgsBinPtrs p;
+    p.pairs = (uint64_t*)(b + L.o.pairs); p.scratch = (uint64_t*)(b + L.o.scratch);
+    p.point_list = (uint32_t*)(b + L.o.point_list); p.table = (uint32_t*)(b + L.o.table); p.spine = (uint32_t*)(b + L.o.spine);
+    return p;
 }
 EgsImgPtrs img_ptrs(void* buf, int W, int H) {
     const ImgLayout L = img_layout(W, H); char* b = (char*)buf; EgsImgPtrs p;
@@ -66,6 +66,7 @@ EgsImgPtrs img_ptrs(void* buf, int W, int H) {
 int check_dims(int P, int W, int H) {
     if (P < 0 || W <= 0 || H <= 0) return EGS_ERR_ARG;
     if (W > 65535 || H > 65535) return EGS_ERR_RANGE;
+    if ((size_t)((W + EGS_TILE - 1) / EGS_TILE) * (size_t)((H + EGS_TILE - 1) / EGS_TILE) > EGS_MAX_TILES) return EGS_ERR_RANGE;
     return 0;
 }
 int check_modes(const float* shs, const float* colors, const float* scales, const float* rots, const float* cov) {
@@ -128,7 +129,7 @@ int egs_profile_end(double* total_ms, int* launches) {
     return 0;
 }
 const char* egs_profile_stage_name(int stage) {
-    static const char* n[EGS_K_COUNT] = { "preprocess", "scan", "duplicate", "sort", "tile_ranges", "render_forward",
+    static const char* n[EGS_K_COUNT] = { "preprocess", "scan", "tile_bucket", "tile_sort", "tile_ranges", "render_forward",
                                           "render_backward", "preprocess_backward" };
     return stage >= 0 && stage < EGS_K_COUNT ? n[stage] : "?";
 }
@@ -158,14 +159,14 @@ int egs_device_info(char* name, int name_len, char* arch, int arch_len, int* com
 }
 
 size_t egs_geom_bytes(int P) { return geom_layout(P).bytes; }
-size_t egs_binning_bytes(int64_t R, int width, int height) { return bin_layout(R, width, height).bytes; }
+size_t egs_binning_bytes(int P, int64_t R, int width, int height) { return bin_layout(P, R, width, height).bytes; }
 size_t egs_image_bytes(int width, int height) { return img_layout(width, height).bytes; }
 size_t egs_backward_scratch_bytes(int P) { return egs_align((size_t)(P > 0 ? P : 0) * EGS_GRAD_STRIDE * sizeof(float)); }
 
 int egs_get_geom_layout(int P, egs_geom_layout* out) { if (!out || P < 0) return EGS_ERR_ARG; *out = geom_layout(P).o; return 0; }
-int egs_get_binning_layout(int64_t R, int width, int height, egs_binning_layout* out) {
-    if (!out || R < 0 || width <= 0 || height <= 0) return EGS_ERR_ARG;
-    *out = bin_layout(R, width, height).o; return 0;
+int egs_get_binning_layout(int P, int64_t R, int width, int height, egs_binning_layout* out) {
+    if (!out || P < 0 || R < 0 || width <= 0 || height <= 0) return EGS_ERR_ARG;
+    *out = bin_layout(P, R, width, height).o; return 0;
 }
 int egs_get_image_layout(int width, int height, egs_image_layout* out) {
     if (!out || width <= 0 || height <= 0) return EGS_ERR_ARG;
@@ -194,13 +195,13 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
                                   rotations, cov3D_precomp, cam, radii, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     EGS_SYNC_IF_DEBUG(s);
-    egs_prof_start(EGS_K_SCAN, s);
-    EGS_TRY(egs_launch_scan_u32(g.offsets, g.offsets, (size_t)P, 1, g.scan_scratch, g.total, s));
-    egs_prof_stop(EGS_K_SCAN, s);
-    EGS_SYNC_IF_DEBUG(s);
-    uint64_t R = 0;
-    EGS_TRY(hipMemcpyAsync(&R, g.total, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    // R = sum of the per-block instance counts (a few KB device->host; the only host wait of the forward)
+    const size_t nb = ((size_t)P + 255) / 256;
+    std::vector<uint32_t> sums(nb);
+    EGS_TRY(hipMemcpyAsync(sums.data(), g.scan_scratch, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     EGS_TRY(hipStreamSynchronize(s));
+    uint64_t R = 0;
+    for (size_t k = 0; k < nb; k++) R += sums[k];
     if (R >= (1ull << 31)) return EGS_ERR_RANGE;
     *num_rendered = (int64_t)R;
     return 0;
@@ -216,10 +217,10 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
     if (R > 0 && !binning_buffer) return EGS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
-    EgsBinPtrs b = bin_ptrs(binning_buffer, R, width, height);
+    EgsBinPtrs b = bin_ptrs(binning_buffer, P, R, width, height);
     EgsImgPtrs im = img_ptrs(image_buffer, width, height);
     EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, s, debug));
-    const uint32_t* point_list = b.sorted_in_b ? b.vals_b : b.vals_a;
+    const uint32_t* point_list = b.point_list;
     egs_prof_start(EGS_K_RENDER_FWD, s);
     EGS_TRY(egs_launch_render_forward(width, height, background, g, point_list, im, out_color, out_depth, out_alpha, s));
     egs_prof_stop(EGS_K_RENDER_FWD, s);
@@ -247,12 +248,12 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
     if (!cov3D_precomp && (!dL_dscales || !dL_drotations)) return EGS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
-    EgsBinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), R, width, height);
+    EgsBinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), P, R, width, height);
     EgsImgPtrs im = img_ptrs(const_cast<void*>(image_buffer), width, height);
     float* grad_acc = (float*)scratch;
     EGS_TRY(hipMemsetAsync(grad_acc, 0, (size_t)P * EGS_GRAD_STRIDE * sizeof(float), s));
     if (R > 0) {
-        const uint32_t* point_list = b.sorted_in_b ? b.vals_b : b.vals_a;
+        const uint32_t* point_list = b.point_list;
         egs_prof_start(EGS_K_RENDER_BWD, s);
         EGS_TRY(egs_launch_render_backward(width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth,
                                            dL_dout_alpha, grad_acc, s));

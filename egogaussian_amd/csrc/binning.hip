@@ -1,26 +1,39 @@
-// binning.hip -- instance generation and ordering for gfx950:
-//   scan of tiles-touched  ->  (tile | depth) keys per (Gaussian, tile) instance  ->  stable LSD radix
-//   sort on the low 32 + bits(tiles) key bits  ->  per-tile [start, end) ranges.
-// Replaces upstream's InclusiveSum / duplicateWithKeys / SortPairs / identifyTileRanges stages of the op
-// called from /root/reference/gaussian_renderer/__init__.py:90-98.
+// binning.hip -- per-tile bucketing and depth ordering of the (Gaussian, tile) instances for gfx950.
+// Replaces upstream's InclusiveSum / duplicateWithKeys / 64-bit SortPairs / identifyTileRanges stages of the op called
+// from /root/reference/gaussian_renderer/__init__.py:90-98.
 //
-// The sort order is the canonical (tile, depth bits, Gaussian index) order: instances are generated in
-// Gaussian-index order and every pass is stable, so ties keep index order -- bit-exact against
-// oracle/raster_oracle.c::egso_sort_pairs.
+// Contract (bit-exact against oracle/raster_oracle.c): the instance list ends up ordered by
+//     (tile id, float bits of depth, Gaussian index)
+// which is what a stable sort of Gaussian-ordered (tile<<32 | depth) keys produces, and ranges[tile] = [start, end).
 //
-// Wave64 specifics: digit ranking inside a wave uses 8 ballots (one per digit bit) to build the
-// "same digit" peer mask and v_mbcnt-style popcounts below the lane; per-wave digit counters live in LDS
-// and are touched only by each peer group's lowest lane, so there are no LDS atomics in the ranking.
+// How it is produced here is not a global 64-bit radix sort (six passes over 12-byte pairs).  The key is two
+// independent pieces -- a tile id with a few thousand values and a depth -- so:
+//   1. k_bin_count    each workgroup walks its Gaussians' tile rectangles and histograms tile ids in LDS
+//                     (LDS atomics, one 4-byte counter per tile), then writes its row of the [tile][block] table;
+//   2. scan           exclusive scan of that table = start of every (tile, block) slice, and of every tile;
+//   3. k_bin_scatter  the same walk again; an LDS cursor per tile hands out slots; writes (depth<<32 | index) pairs
+//                     bucketed by tile (order inside a bucket is arbitrary at this point);
+//   4. k_tile_sort    ONE workgroup per tile sorts its bucket by the full 64-bit (depth, index) pair with an LSD
+//                     radix sort whose keys live in registers and are exchanged through a single LDS buffer, and
+//                     writes the Gaussian indices (point_list) and the tile's range.  Buckets larger than the
+//                     register/LDS capacity take a global-memory path of the same algorithm.
+// HBM traffic per instance: 8 B written + 8 B read + 4 B written (vs 6 x 24 B for the global sort), and the whole
+// stage is 6 launches instead of ~35.
+//
+// Wave64 specifics: instance slots of 64 consecutive Gaussians are dealt to lanes by a 6-step in-wave search over the
+// wave's exclusive offsets (so lanes do equal work however uneven the rectangles are); digit ranking inside a wave uses
+// 8 ballots ("same digit" peer mask) + popcount-below-lane, with per-wave LDS counters touched only by each peer
+// group's lowest lane.
 #include "egs_common.h"
 
 namespace {
 
-__device__ __forceinline__ uint64_t lanemask_lt() {
-    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
-}
 __device__ __forceinline__ unsigned lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    const unsigned lane = lane_id();
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -60,7 +73,6 @@ __global__ __launch_bounds__(EGS_SCAN_THREADS) void k_scan_reduce(const uint32_t
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-// Scans n <= EGS_SCAN_EPB elements in one block (exclusive), in place allowed.
 __global__ __launch_bounds__(EGS_SCAN_THREADS) void k_scan_single(const uint32_t* __restrict__ in,
                                                                    uint32_t* __restrict__ out, size_t n, int inclusive,
                                                                    uint64_t* __restrict__ total) {
@@ -97,142 +109,239 @@ __global__ __launch_bounds__(EGS_SCAN_THREADS) void k_scan_apply(const uint32_t*
 }
 
 // ---------------------------------------------------------------------------------------------
-// duplicate: one key/value per touched tile.  A wave owns 64 consecutive Gaussians and emits their
-// instances cooperatively: output slot s of the wave's contiguous span is mapped back to its Gaussian
-// by a 6-step search over the wave's exclusive offsets (held one per lane), so the 12-byte stores of a
-// wave are consecutive instead of 64 separate strided runs.
+// Tile bucketing.  A workgroup (16 waves) owns EGS_BIN_GPB consecutive Gaussians, 64 per wave.  For
+// each group of 64 Gaussians the wave deals their instance slots to lanes: slot s of the group's contiguous span is
+// mapped back to its Gaussian by a 6-step search over the per-lane exclusive offsets, so lanes do equal work however
+// uneven the rectangles are.  `body(tile, gaussian_index, depth_bits)` runs once per instance.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_duplicate(int P, const float4* __restrict__ rec, const uint2* __restrict__ rect,
-                                                    const uint32_t* __restrict__ offsets, int gx,
-                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned lane = lane_id();
-    const int wave_first = i - (int)lane;
-    if (wave_first >= P) return;
-    const bool have = i < P;
-    const uint32_t incl = have ? offsets[i] : 0u;
-    uint32_t prev = __shfl_up(incl, 1, 64);
-    if (lane == 0) prev = wave_first == 0 ? 0u : offsets[wave_first - 1];
-    const uint32_t wave_base = __shfl(prev, 0, 64);
-    const int last_lane = min(63, P - 1 - wave_first);
-    const uint32_t wave_end = __shfl(incl, last_lane, 64);
-    const uint32_t excl = have ? prev - wave_base : 0xffffffffu;     // start of my span, relative to the wave
-    const uint32_t cnt = have ? incl - prev : 0u;
-    uint2 rc = make_uint2(0u, 0u); uint32_t dbits = 0;
-    if (cnt) { rc = rect[i]; dbits = __float_as_uint(rec[(size_t)i * EGS_SPLAT_REC_F4 + 2].y); }
-    const uint32_t total = wave_end - wave_base;
-    for (uint32_t s0 = 0; s0 < total; s0 += 64) {
-        const uint32_t s = s0 + lane;
-        // owner = last lane whose span starts at or before s (spans are sorted; empty spans share a start
-        // with their successor, and the search lands on the last of them -- fix up by requiring cnt > 0 via
-        // "start <= s" on the NEXT lane being false).
-        int lo = 0;
+template <typename Body>
+__device__ __forceinline__ void for_each_instance(int P, const uint32_t* __restrict__ tiles_touched,
+                                                  const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
+                                                  bool need_depth, Body body) {
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int per_wave = EGS_BIN_GPB / (EGS_BIN_THREADS / 64);
+    const int first = blockIdx.x * EGS_BIN_GPB + (int)w * per_wave;
+    for (int g0 = first; g0 < first + per_wave && g0 < P; g0 += 64) {
+        const int i = g0 + (int)lane;
+        const bool have = i < P;
+        const uint32_t cnt = have ? tiles_touched[i] : 0u;
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (total == 0) continue;
+        const uint32_t excl = have ? incl - cnt : 0xffffffffu;       // span start; invalid lanes sort to the end
+        uint2 rc = make_uint2(0u, 0u); uint32_t dbits = 0;
+        if (cnt) { rc = rect[i]; if (need_depth) dbits = __float_as_uint(rec[(size_t)i * EGS_SPLAT_REC_F4 + 2].y); }
+        for (uint32_t s0 = 0; s0 < total; s0 += 64) {
+            const uint32_t s = s0 + lane;
+            int lo = 0;                                              // last lane whose span starts at or before s
 #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {
-            const int probe = lo + step;
-            const uint32_t st = __shfl(excl, probe & 63, 64);
-            if (probe < 64 && st <= s) lo = probe;
-        }
-        const uint32_t ost = __shfl(excl, lo, 64);
-        const uint2 orc = make_uint2(__shfl(rc.x, lo, 64), __shfl(rc.y, lo, 64));
-        const uint32_t odb = __shfl(dbits, lo, 64);
-        if (s < total) {
-            const uint32_t k = s - ost;
-            const uint32_t x0 = orc.x & 0xffffu, x1 = orc.x >> 16, y0 = orc.y & 0xffffu;
-            const uint32_t w = x1 - x0;
-            const uint32_t ty = y0 + k / w, tx = x0 + k % w;
-            const uint64_t key = ((uint64_t)(ty * (uint32_t)gx + tx) << 32) | odb;
-            keys[wave_base + s] = key;
-            vals[wave_base + s] = (uint32_t)(wave_first + lo);
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int probe = lo + step;
+                const uint32_t st = __shfl(excl, probe & 63, 64);
+                if (probe < 64 && st <= s) lo = probe;
+            }
+            const uint32_t ost = __shfl(excl, lo, 64);
+            const uint2 orc = make_uint2(__shfl(rc.x, lo, 64), __shfl(rc.y, lo, 64));
+            const uint32_t odb = __shfl(dbits, lo, 64);
+            if (s < total) {
+                const uint32_t k = s - ost;
+                const uint32_t x0 = orc.x & 0xffffu, x1 = orc.x >> 16, y0 = orc.y & 0xffffu;
+                const uint32_t wd = x1 - x0;
+                const uint32_t ty = y0 + k / wd, tx = x0 + k % wd;
+                body(ty * (uint32_t)gx + tx, (uint32_t)(g0 + lo), odb);
+            }
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// radix sort pass: histogram -> scan (generic scan above) -> stable scatter.
-// Block b owns keys [b*KPB, (b+1)*KPB); wave w of the block owns a contiguous quarter, processed in
-// ITEMS rounds of 64 consecutive keys, so the in-block order is (wave, round, lane) = input order.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EGS_SORT_THREADS) void k_sort_hist(const uint64_t* __restrict__ keys, uint32_t R, int shift,
-                                                                 uint32_t nblocks, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[EGS_SORT_BINS];
-    h[threadIdx.x] = 0;
+extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+
+__global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, const uint32_t* __restrict__ tiles_touched,
+                                                    const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
+                                                    int n_tiles, uint32_t nblocks, uint32_t* __restrict__ table) {
+    uint32_t* hist = dyn_lds;
+    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) hist[t] = 0;
     __syncthreads();
-    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t base = blockIdx.x * EGS_SORT_KPB + w * (EGS_SORT_KPB / 4);
-#pragma unroll
-    for (int r = 0; r < EGS_SORT_ITEMS; r++) {
-        const uint32_t idx = base + r * 64 + lane;
-        if (idx < R) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & (EGS_SORT_BINS - 1)], 1u);
-    }
+    for_each_instance(P, tiles_touched, rect, rec, gx, false,
+                      [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); });
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];      // digit-major for the scan
+    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) table[(size_t)t * nblocks + blockIdx.x] = hist[t];   // tile-major
 }
 
-__global__ __launch_bounds__(EGS_SORT_THREADS) void k_sort_scatter(
-    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, uint32_t R, int shift, uint32_t nblocks, const uint32_t* __restrict__ hist_scanned) {
-    __shared__ uint32_t cnt[4][EGS_SORT_BINS];          // per-wave running digit counts
-    __shared__ uint32_t gbase[EGS_SORT_BINS];           // global base of digit d for this block
-    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 4; k++) cnt[k][threadIdx.x] = 0;
+__global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, const uint32_t* __restrict__ tiles_touched,
+                                                      const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
+                                                      int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
+                                                      uint64_t* __restrict__ pairs) {
+    uint32_t* cursor = dyn_lds;
+    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) cursor[t] = table_scanned[(size_t)t * nblocks + blockIdx.x];
     __syncthreads();
-    const uint32_t base = blockIdx.x * EGS_SORT_KPB + w * (EGS_SORT_KPB / 4);
+    for_each_instance(P, tiles_touched, rect, rec, gx, true, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
+        const uint32_t pos = atomicAdd(&cursor[tile], 1u);
+        pairs[pos] = ((uint64_t)dbits << 32) | idx;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-tile sort of (depth<<32 | index) pairs.  LSD radix, 8-bit digits, only the digits that can differ:
+// ceil(index_bits / 8) low passes + the 4 depth bytes.  Stable ranking as in a global radix pass, but the whole
+// bucket belongs to one workgroup: wave w owns the contiguous quarter [w*chunk, (w+1)*chunk) in rounds of 64.
+// ---------------------------------------------------------------------------------------------
+#define TS_ITEMS 16
+#define TS_CAP (256 * TS_ITEMS)       // 4096 pairs held in registers, one 32 KiB LDS exchange buffer
+
+__device__ __forceinline__ uint64_t digit_peers(uint32_t d, bool ok) {
+    uint64_t peers = __ballot(ok);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const uint64_t m = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    return peers;
+}
+
+// After every wave has accumulated cnt[w][d] (count of digit d in wave w's quarter): turn them into exclusive
+// positions: cnt[w][d] <- (#keys with digit < d) + (#keys with digit d in waves < w).  256 threads, thread d.
+__device__ __forceinline__ void digit_bases(uint32_t (*cnt)[256], uint32_t* lds4) {
+    const unsigned d = threadIdx.x;
+    const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+    uint32_t tot;
+    const uint32_t base = block_excl_scan(c0 + c1 + c2 + c3, lds4, &tot);
+    cnt[0][d] = base; cnt[1][d] = base + c0; cnt[2][d] = base + c0 + c1; cnt[3][d] = base + c0 + c1 + c2;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
+                                                    uint32_t R, int index_passes, uint64_t* __restrict__ pairs,
+                                                    uint64_t* __restrict__ scratch, uint32_t* __restrict__ point_list,
+                                                    uint2* __restrict__ ranges) {
+    __shared__ uint64_t xbuf[TS_CAP];
+    __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t lds4[4];
+    const int tile = blockIdx.x;
+    const uint32_t beg = table_scanned[(size_t)tile * nblocks];
+    const uint32_t end = tile + 1 < n_tiles ? table_scanned[(size_t)(tile + 1) * nblocks] : R;
+    const uint32_t n = end - beg;
+    if (threadIdx.x == 0) ranges[tile] = n ? make_uint2(beg, end) : make_uint2(0u, 0u);
+    if (n == 0) return;
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
-    uint64_t key[EGS_SORT_ITEMS]; uint32_t val[EGS_SORT_ITEMS]; uint32_t rank[EGS_SORT_ITEMS];
-#pragma unroll
-    for (int r = 0; r < EGS_SORT_ITEMS; r++) {
-        const uint32_t idx = base + r * 64 + lane;
-        const bool ok = idx < R;
-        key[r] = ok ? keys_in[idx] : ~0ull;
-        val[r] = ok ? vals_in[idx] : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < EGS_SORT_ITEMS; r++) {
-        const uint32_t idx = base + r * 64 + lane;
-        const bool ok = idx < R;
-        const uint32_t d = (uint32_t)(key[r] >> shift) & (EGS_SORT_BINS - 1);
-        uint64_t peers = __ballot(ok);
-#pragma unroll
-        for (int b = 0; b < EGS_SORT_BITS; b++) {
-            const uint64_t m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
-        }
-        // peers = lanes (valid) holding my digit.  Lowest peer reads-and-bumps the wave's counter.
-        const unsigned leader = (unsigned)__ffsll((unsigned long long)peers) - 1u;
-        uint32_t start = 0;
-        if (ok && lane == leader) { start = cnt[w][d]; cnt[w][d] = start + (uint32_t)__popcll(peers); }
-        start = __shfl(start, ok ? leader : lane, 64);
-        rank[r] = start + (uint32_t)__popcll(peers & lt);
-    }
-    __syncthreads();
-    {   // thread d: wave-exclusive bases for digit d and the block's global base
-        const unsigned d = threadIdx.x;
-        uint32_t run = hist_scanned[(size_t)d * nblocks + blockIdx.x];
-        gbase[d] = run;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const uint32_t c = cnt[k][d]; cnt[k][d] = run; run += c; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < EGS_SORT_ITEMS; r++) {
-        const uint32_t idx = base + r * 64 + lane;
-        if (idx < R) {
-            const uint32_t d = (uint32_t)(key[r] >> shift) & (EGS_SORT_BINS - 1);
-            const uint32_t pos = cnt[w][d] + rank[r];
-            keys_out[pos] = key[r]; vals_out[pos] = val[r];
-        }
-    }
-}
+    const uint32_t chunk = ((n + 3) / 4 + 63) & ~63u;               // per-wave quarter, multiple of 64
+    const uint32_t wbeg = w * chunk;
+    const int npass = index_passes + 4;
 
-__global__ __launch_bounds__(256) void k_tile_ranges(uint32_t R, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R) return;
-    const uint32_t t = (uint32_t)(keys[i] >> 32);
-    if (i == 0) ranges[t].x = 0;
-    else { const uint32_t p = (uint32_t)(keys[i - 1] >> 32); if (p != t) { ranges[p].y = i; ranges[t].x = i; } }
-    if (i == R - 1) ranges[t].y = R;
+    if (n <= TS_CAP) {
+        // ---- register path ----
+        // Depth ties inside a tile are rare, so the bucket is first sorted on the four depth bytes only; if two
+        // neighbours then share a depth the index bytes are sorted and the depth bytes redone (LSD order), which
+        // restores the canonical (depth, index) order.  `phase` 0: depth only; 1: index then depth.
+        uint64_t key[TS_ITEMS];
+#pragma unroll
+        for (int r = 0; r < TS_ITEMS; r++) {
+            const uint32_t i = wbeg + r * 64 + lane;
+            key[r] = (r * 64u < chunk && i < n) ? pairs[beg + i] : ~0ull;
+        }
+#ifndef TS_MAXPASS
+#define TS_MAXPASS 99
+#endif
+        for (int phase = 0; phase < 2; phase++) {
+            const int first_pass = phase == 0 ? index_passes : 0;
+            for (int p = first_pass; p < npass && p < first_pass + TS_MAXPASS; p++) {
+                const int shift = p < index_passes ? 8 * p : 32 + 8 * (p - index_passes);
+#pragma unroll
+                for (int k = 0; k < 4; k++) cnt[k][threadIdx.x] = 0;
+                __syncthreads();
+                uint32_t rank[TS_ITEMS];
+#pragma unroll
+                for (int r = 0; r < TS_ITEMS; r++) {
+                    rank[r] = 0;
+                    if (r * 64u < chunk) {                              // wave-uniform
+                        const uint32_t i = wbeg + r * 64 + lane;
+                        const bool ok = i < n;
+                        const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+                        const uint64_t peers = digit_peers(d, ok);
+                        // every lane reads the running count of its digit, the group's lowest lane bumps it
+                        // (LDS operations of one wave execute in order, so the next round sees the update)
+                        const uint32_t start = cnt[w][d];
+                        if (ok && lane == (unsigned)__ffsll((unsigned long long)peers) - 1u) cnt[w][d] = start + (uint32_t)__popcll(peers);
+                        rank[r] = start + (uint32_t)__popcll(peers & lt);
+                    }
+                }
+                __syncthreads();
+                digit_bases(cnt, lds4);
+#pragma unroll
+                for (int r = 0; r < TS_ITEMS; r++) {
+                    const uint32_t i = wbeg + r * 64 + lane;
+                    if (r * 64u < chunk && i < n) xbuf[cnt[w][(uint32_t)(key[r] >> shift) & 255u] + rank[r]] = key[r];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < TS_ITEMS; r++) {
+                    const uint32_t i = wbeg + r * 64 + lane;
+                    if (r * 64u < chunk && i < n) key[r] = xbuf[i];
+                }
+                // xbuf stays intact until the next pass writes it (after two barriers), so it can be read below
+            }
+            // sorted by depth (phase 0) or by (depth, index) (phase 1): any equal-depth neighbours?
+            bool tie = false;
+            if (phase == 0) {
+#pragma unroll
+                for (int r = 0; r < TS_ITEMS; r++) {
+                    const uint32_t i = wbeg + r * 64 + lane;
+                    if (r * 64u < chunk && i + 1 < n) tie = tie || (uint32_t)(key[r] >> 32) == (uint32_t)(xbuf[i + 1] >> 32);
+                }
+            }
+            const int any_tie = __syncthreads_or(tie ? 1 : 0);
+            if (!any_tie) break;
+        }
+#pragma unroll
+        for (int r = 0; r < TS_ITEMS; r++) {
+            const uint32_t i = wbeg + r * 64 + lane;
+            if (r * 64u < chunk && i < n) point_list[beg + i] = (uint32_t)key[r];
+        }
+        return;
+    }
+
+    // ---- oversize bucket: same algorithm, keys stay in global memory (ping-pong with `scratch`) ----
+    uint64_t* src = pairs + beg;
+    uint64_t* dst = scratch + beg;
+    for (int p = 0; p < npass; p++) {
+        const int shift = p < index_passes ? 8 * p : 32 + 8 * (p - index_passes);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cnt[k][threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t r0 = 0; r0 < chunk; r0 += 64) {                  // count
+            const uint32_t i = wbeg + r0 + lane;
+            const bool ok = i < n;
+            const uint32_t d = ok ? (uint32_t)(src[i] >> shift) & 255u : 0u;
+            const uint64_t peers = digit_peers(d, ok);
+            const unsigned leader = (unsigned)__ffsll((unsigned long long)peers) - 1u;
+            if (ok && lane == leader) cnt[w][d] += (uint32_t)__popcll(peers);
+        }
+        __syncthreads();
+        digit_bases(cnt, lds4);
+        const bool last = p == npass - 1;
+        for (uint32_t r0 = 0; r0 < chunk; r0 += 64) {                  // rank and move (cnt[w][d] is the running cursor)
+            const uint32_t i = wbeg + r0 + lane;
+            const bool ok = i < n;
+            const uint64_t kv = ok ? src[i] : 0ull;
+            const uint32_t d = (uint32_t)(kv >> shift) & 255u;
+            const uint64_t peers = digit_peers(d, ok);
+            const unsigned leader = (unsigned)__ffsll((unsigned long long)peers) - 1u;
+            uint32_t start = 0;
+            if (ok && lane == leader) { start = cnt[w][d]; cnt[w][d] = start + (uint32_t)__popcll(peers); }
+            start = __shfl(start, ok ? leader : lane, 64);
+            if (ok) {
+                const uint32_t pos = start + (uint32_t)__popcll(peers & lt);
+                if (last) point_list[beg + pos] = (uint32_t)kv;
+                else dst[pos] = kv;
+            }
+        }
+        // other waves of this workgroup read `dst` next pass: publish, then drop any stale L1 lines of it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        uint64_t* t = src; src = dst; dst = t;
+    }
 }
 
 }  // namespace
@@ -265,34 +374,36 @@ hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int 
     do { if (debug) { hipError_t e_ = hipStreamSynchronize(s); if (e_ != hipSuccess) return e_; \
                       e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } } while (0)
 
+uint32_t egs_bin_blocks(int P) { return (uint32_t)((P + EGS_BIN_GPB - 1) / EGS_BIN_GPB); }
+
 hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
                               hipStream_t s, int debug) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
-    hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s);
-    if (e != hipSuccess) return e;
-    if (R64 == 0 || P == 0) return hipSuccess;
+    const int n_tiles = gx * gy;
+    if (R64 == 0 || P == 0) return hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)n_tiles, s);
     const uint32_t R = (uint32_t)R64;
+    const uint32_t nblocks = egs_bin_blocks(P);
+    const size_t lds = (size_t)n_tiles * sizeof(uint32_t);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     egs_prof_start(EGS_K_DUPLICATE, s);
-    hipLaunchKernelGGL(k_duplicate, dim3((P + 255) / 256), dim3(256), 0, s, P, g.rec, g.rect, g.offsets, gx, b.keys_a, b.vals_a);
+    hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, b.table);
+    EGS_DBG(s);
+    hipError_t e = egs_launch_scan_u32(b.table, b.table, (size_t)n_tiles * nblocks, 0, b.spine, nullptr, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nblocks), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
+                       b.table, b.pairs);
     egs_prof_stop(EGS_K_DUPLICATE, s);
     EGS_DBG(s);
-    const uint32_t nblocks = (R + EGS_SORT_KPB - 1) / EGS_SORT_KPB;
-    uint64_t* kin = b.keys_a; uint64_t* kout = b.keys_b; uint32_t* vin = b.vals_a; uint32_t* vout = b.vals_b;
+    int index_bits = 0; while (((unsigned)(P - 1) >> index_bits) != 0) index_bits++;
     egs_prof_start(EGS_K_SORT, s);
-    for (int pass = 0; pass < b.passes; pass++) {
-        const int shift = pass * EGS_SORT_BITS;
-        hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(EGS_SORT_THREADS), 0, s, kin, R, shift, nblocks, b.hist);
-        e = egs_launch_scan_u32(b.hist, b.hist, (size_t)nblocks * EGS_SORT_BINS, 0, b.spine, nullptr, s);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(EGS_SORT_THREADS), 0, s, kin, vin, kout, vout, R, shift,
-                           nblocks, b.hist);
-        EGS_DBG(s);
-        uint64_t* tk = kin; kin = kout; kout = tk; uint32_t* tv = vin; vin = vout; vout = tv;
-    }
+    hipLaunchKernelGGL(k_tile_sort, dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, R, (index_bits + 7) / 8, b.pairs,
+                       b.scratch, b.point_list, im.ranges);
     egs_prof_stop(EGS_K_SORT, s);
-    egs_prof_start(EGS_K_RANGES, s);
-    hipLaunchKernelGGL(k_tile_ranges, dim3((R + 255) / 256), dim3(256), 0, s, R, kin, im.ranges);
-    egs_prof_stop(EGS_K_RANGES, s);
     EGS_DBG(s);
     return hipGetLastError();
 }

@@ -24,11 +24,29 @@ __device__ __forceinline__ void egs_load_rec(const float4* __restrict__ rec, uin
     }
 }
 
-// Does the record's pixel bounding box (c.z = x0 | x1<<16, c.w = y0 | y1<<16) intersect [qx0,qx1]x[qy0,qy1]?
-__device__ __forceinline__ bool egs_bbox_hits(const float4& c, uint32_t qx0, uint32_t qx1, uint32_t qy0, uint32_t qy1) {
-    const uint32_t bx = __float_as_uint(c.z), by = __float_as_uint(c.w);
+// Can the splat reach the pixel block [qx0,qx1] x [qy0,qy1] at all?  Two stages, both conservative (never a false "no"):
+//   1. the record's pixel bounding box (c2.z = x0 | x1<<16, c2.w = y0 | y1<<16) must intersect the block;
+//   2. exact: max over the block of the (concave) log2 falloff  qa dx^2 + qb dx dy + qc dy^2  must reach
+//      log2(1/(255 o)) -- below that, alpha < 1/255 for every pixel of the block.  If the centre is outside the
+//      block the maximum sits on one of the (at most two) edges facing the centre, at the clamped 1-D optimum.
+// Runs once per staged splat (one lane each), i.e. 1/64 of an instruction per candidate per wave, and removes the
+// (wave, splat) visits that a bounding box cannot: diagonal / elongated splats and block corners.
+__device__ __forceinline__ bool egs_block_hits(const float4& c0, const float4& c1, const float4& c2, uint32_t qx0,
+                                               uint32_t qx1, uint32_t qy0, uint32_t qy1) {
+    const uint32_t bx = __float_as_uint(c2.z), by = __float_as_uint(c2.w);
     const uint32_t x0 = bx & 0xffffu, x1 = bx >> 16, y0 = by & 0xffffu, y1 = by >> 16;
-    return x0 <= qx1 && x1 >= qx0 && y0 <= qy1 && y1 >= qy0;
+    if (!(x0 <= qx1 && x1 >= qx0 && y0 <= qy1 && y1 >= qy0)) return false;
+    const float cx = c0.x, cy = c0.y, qa = c0.z, qb = c0.w, qc = c1.x;
+    const float lx = (float)qx0 - cx, hx = (float)qx1 - cx, ly = (float)qy0 - cy, hy = (float)qy1 - cy;
+    const float dxe = fminf(fmaxf(0.f, lx), hx), dye = fminf(fmaxf(0.f, ly), hy);      // nearest block point to the centre
+    if (dxe == 0.f && dye == 0.f) return true;                                           // centre inside the block
+    if (!(qa < 0.f && qc < 0.f)) return true;                                            // not a proper ellipse: keep
+    const float dys = fminf(fmaxf(-0.5f * qb * dxe * __builtin_amdgcn_rcpf(qc), ly), hy);     // best dy on the line dx = dxe
+    const float dxs = fminf(fmaxf(-0.5f * qb * dye * __builtin_amdgcn_rcpf(qa), lx), hx);     // best dx on the line dy = dye
+    const float q1 = qa * dxe * dxe + qb * dxe * dys + qc * dys * dys;
+    const float q2 = qa * dxs * dxs + qb * dxs * dye + qc * dye * dye;
+    const float need = -__builtin_amdgcn_logf(255.f * c1.y) - 0.03f;                     // log2(1/(255 o)), with a rounding margin
+    return !(fmaxf(q1, q2) < need);                                                      // NaN anywhere -> keep
 }
 
 // log2 of the Gaussian falloff from the pre-scaled conic (egs_common.h): qa dx^2 + qb dx dy + qc dy^2.

@@ -28,19 +28,21 @@ struct EgsGeomPtrs {
     float4* rec; uint2* rect; uint32_t* offsets; uint8_t* clamped; uint32_t* scan_scratch; uint64_t* total;
 };
 struct EgsBinPtrs {
-    uint64_t* keys_a; uint64_t* keys_b; uint32_t* vals_a; uint32_t* vals_b; uint32_t* hist; uint32_t* spine;
-    int sorted_in_b, key_bits, passes;
+    uint64_t* pairs;        // [R] (depth<<32 | index), bucketed by tile
+    uint64_t* scratch;      // [R] ping-pong space for oversize buckets
+    uint32_t* point_list;   // [R] sorted Gaussian indices
+    uint32_t* table;        // [n_tiles][bin_blocks] per-(tile, block) instance counts, scanned in place
+    uint32_t* spine;        // scan scratch
 };
 struct EgsImgPtrs { uint2* ranges; float* final_T; uint32_t* n_contrib; };
 
 static inline size_t egs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// radix sort geometry (binning.hip)
-#define EGS_SORT_BITS 8
-#define EGS_SORT_BINS 256
-#define EGS_SORT_THREADS 256
-#define EGS_SORT_ITEMS 16
-#define EGS_SORT_KPB (EGS_SORT_THREADS * EGS_SORT_ITEMS)      // keys per block
+// binning geometry (binning.hip)
+#define EGS_BIN_GPB 1024                                       // Gaussians per bucketing workgroup
+#define EGS_BIN_THREADS 1024                                   // 16 waves, 64 Gaussians each
+#define EGS_MAX_TILES 36864                                    // one 4-byte LDS counter per tile must fit in 160 KiB
+uint32_t egs_bin_blocks(int P);
 #define EGS_SCAN_THREADS 256
 #define EGS_SCAN_ITEMS 8
 #define EGS_SCAN_EPB (EGS_SCAN_THREADS * EGS_SCAN_ITEMS)      // elements per block

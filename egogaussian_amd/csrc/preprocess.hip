@@ -112,15 +112,14 @@ __device__ __forceinline__ float sh_channel(int deg, const float* sh, int ch, fl
     return v + 0.5f;
 }
 
-__global__ __launch_bounds__(256) void k_preprocess(
-    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+// Returns the number of tiles the Gaussian touches (0 = culled).
+__device__ __forceinline__ uint32_t preprocess_one(
+    int i, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales, float mod,
     const float* __restrict__ rots, const float* __restrict__ cov3D_in, const float* __restrict__ V,
     const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
     uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     radii[i] = 0; tiles_touched[i] = 0;
 
@@ -135,13 +134,13 @@ __global__ __launch_bounds__(256) void k_preprocess(
         cov3d_from_scale_rot(s, mod, q, c6);
     }
     Ewa e; ewa_project(p, c6, V, W, H, tanfovx, tanfovy, e);
-    if (e.t[2] <= 0.2f) return;                                   // near-plane cull
+    if (e.t[2] <= 0.2f) return 0u;                                // near-plane cull
     float hom[4]; xform44(p, PM, hom);
     const float pw = 1.f / (hom[3] + 0.0000001f);
     const float ndc_x = hom[0] * pw, ndc_y = hom[1] * pw;
 
     const float det = e.a * e.c - e.b * e.b;
-    if (det == 0.f) return;
+    if (det == 0.f) return 0u;
     const float det_inv = 1.f / det;
     const float conA = e.c * det_inv, conB = -e.b * det_inv, conC = e.a * det_inv;
     const float mid = 0.5f * (e.a + e.c);
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
     const int ry0 = min(gy, max(0, (int)((py - (float)rad) / (float)EGS_TILE)));
     const int rx1 = min(gx, max(0, (int)((px + (float)rad + (float)(EGS_TILE - 1)) / (float)EGS_TILE)));
     const int ry1 = min(gy, max(0, (int)((py + (float)rad + (float)(EGS_TILE - 1)) / (float)EGS_TILE)));
-    if ((rx1 - rx0) * (ry1 - ry0) == 0) return;
+    if ((rx1 - rx0) * (ry1 - ry0) == 0) return 0u;
 
     float rgb[3]; uint32_t cl = 0;
     if (colors) {
@@ -206,6 +205,27 @@ __global__ __launch_bounds__(256) void k_preprocess(
     r[0] = make_float4(px, py, (-0.5f * EGS_LOG2E) * conA, -EGS_LOG2E * conB);
     r[1] = make_float4((-0.5f * EGS_LOG2E) * conC, o, rgb[0], rgb[1]);
     r[2] = make_float4(rgb[2], e.t[2], __uint_as_float(bbx), __uint_as_float(bby));
+    return (uint32_t)((rx1 - rx0) * (ry1 - ry0));
+}
+
+__global__ __launch_bounds__(256) void k_preprocess(
+    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales, float mod,
+    const float* __restrict__ rots, const float* __restrict__ cov3D_in, const float* __restrict__ V,
+    const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
+    int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
+    uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t wsum[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t my_tiles = 0;
+    if (i < P) my_tiles = preprocess_one(i, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D_in, V, PM, campos, W, H,
+                                         tanfovx, tanfovy, radii, rec, rect_out, tiles_touched, clamped_out);
+    // per-block instance count; the host adds the block sums to get R (no contended atomic, deterministic)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) my_tiles += (uint32_t)__shfl_xor((int)my_tiles, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = my_tiles;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 __global__ __launch_bounds__(256) void k_preprocess_backward(
@@ -407,7 +427,7 @@ hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, cons
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(k_preprocess, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, colors, opac, scales,
                        mod, rots, cov3D, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.tanfovx, cam.tanfovy, radii,
-                       g.rec, g.rect, g.offsets, g.clamped);
+                       g.rec, g.rect, g.offsets, g.clamped, g.scan_scratch);
     return hipGetLastError();
 }
 

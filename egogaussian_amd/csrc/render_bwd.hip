@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_render_backward(
         id_cur = id_next;
         id_next = b >= 2 ? list[(uint32_t)(b - 2) * 64 + lane] : 0u;
 
-        uint64_t mask = __ballot(have && egs_bbox_hits(c2, (uint32_t)qx0, qx1, (uint32_t)qy0, qy1));
+        uint64_t mask = __ballot(have && egs_block_hits(c0, c1, c2, (uint32_t)qx0, qx1, (uint32_t)qy0, qy1));
         if (mask == 0ull) continue;
         my[lane * 3 + 0] = c0; my[lane * 3 + 1] = c1; my[lane * 3 + 2] = c2;
         __builtin_amdgcn_wave_barrier();
@@ -118,30 +118,39 @@ __global__ __launch_bounds__(256) void k_render_backward(
             const float4 s0 = my[j * 3 + 0], s1 = my[j * 3 + 1];
             const float2 s2 = *reinterpret_cast<const float2*>(&my[j * 3 + 2]);
             const float dx = s0.x - pxf, dy = s0.y - pyf;
-            float G;
-            const float alpha = egs_alpha(dx, dy, s0.z, s0.w, s1.x, s1.y, G);
-            const float a = (base + (uint32_t)j + 1u <= last) ? alpha : 0.f;          // 0 = this pixel does not use the splat
-            if (__ballot(a > 0.f) == 0ull) continue;
+            // log2 falloff with its intermediates kept: t = qa dx + qb dy, n = qc dy   (same arithmetic as egs_alpha)
+            const float m = __fmul_rn(s0.z, dx);
+            const float t = __fmaf_rn(s0.w, dy, m);
+            const float nn = __fmul_rn(s1.x, dy);
+            const float p = __fmaf_rn(nn, dy, __fmul_rn(t, dx));
+            const float G = __builtin_amdgcn_exp2f(p);
+            float a = fminf(0.99f, __fmul_rn(s1.y, G));
+            a = p > 0.f ? 0.f : a;
+            a = a < (1.0f / 255.0f) ? 0.f : a;
+            a = (base + (uint32_t)j + 1u <= last) ? a : 0.f;            // 0 = this pixel does not use the splat
+            const bool contrib = a > 0.f;
+            if (__ballot(contrib) == 0ull) continue;
             const float rcp = __builtin_amdgcn_rcpf(1.f - a);
             const float Tn = T * rcp;                                   // transmittance in front of this splat
             const float w = a * Tn;
             const float u = fmaf(s1.z, g_r, fmaf(s1.w, g_g, fmaf(s2.x, g_b, fmaf(s2.y, g_d, g_a))));
             const float Un = fmaf(last_alpha, last_u - U, U);
-            const bool contrib = a > 0.f;
             float dLda = fmaf(bg_term, rcp, (u - Un) * Tn);
             dLda = contrib ? dLda : 0.f;
             T = Tn; U = contrib ? Un : U; last_u = contrib ? u : last_u; last_alpha = contrib ? a : last_alpha;
 
-            // conic in natural units: A = qa * (-2 ln2), B = qb * (-ln2), C = qc * (-2 ln2)
-            const float dL_dG = s1.y * dLda;
-            const float gdx = G * dx, gdy = G * dy;
-            const float gA = s0.z * (-2.f * EGS_LN2), gB = s0.w * (-EGS_LN2), gC = s1.x * (-2.f * EGS_LN2);
-            float v0 = dL_dG * (-gdx * gA - gdy * gB);                  // d/d mean2D.x (pixel units)
-            float v1 = dL_dG * (-gdy * gC - gdx * gB);                  // d/d mean2D.y
-            const float h = -0.5f * dL_dG;
-            float v2 = h * gdx * dx, v3 = h * gdx * dy, v4 = h * gdy * dy;   // conic xx, xy (half), yy
-            float v5 = G * dLda;                                        // opacity
-            float v6 = w * g_r, v7 = w * g_g, v8 = w * g_b, v9 = w * g_d;
+            // With the conic in log2 units (A = -2 ln2 qa, B = -ln2 qb, C = -2 ln2 qc):
+            //   dG/d(mean.x) = -G (A dx + B dy) = G ln2 (2 qa dx + qb dy) = G ln2 (t + m)
+            //   dG/d(mean.y) = -G (C dy + B dx) = G ln2 (2 qc dy + qb dx) = G ln2 (fma(qb, dx, n) + n)
+            const float kG = s1.y * dLda * G;                           // dL/dG * G
+            const float k = kG * EGS_LN2;
+            const float v0 = k * (t + m);
+            const float v1 = k * (fmaf(s0.w, dx, nn) + nn);
+            const float hG = -0.5f * kG;
+            const float ex = hG * dx, ey = hG * dy;
+            const float v2 = ex * dx, v3 = ex * dy, v4 = ey * dy;       // d/d conic xx, xy (half), yy
+            const float v5 = G * dLda;                                  // d/d opacity
+            const float v6 = w * g_r, v7 = w * g_g, v8 = w * g_b, v9 = w * g_d;
 
             // 64-lane sums of v0..v9, ten results in ten lanes
             const float s01 = fold32(v0, v1), s23 = fold32(v2, v3), s45 = fold32(v4, v5), s67 = fold32(v6, v7),

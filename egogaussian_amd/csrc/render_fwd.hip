@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
         egs_load_rec(rec, id_next, base + 64 + lane < n, r0, r1, r2);
         id_next = base + 128 + lane < n ? list[base + 128 + lane] : 0u;
 
-        uint64_t mask = __ballot(have && egs_bbox_hits(c2, (uint32_t)qx0, qx1, (uint32_t)qy0, qy1));
+        uint64_t mask = __ballot(have && egs_block_hits(c0, c1, c2, (uint32_t)qx0, qx1, (uint32_t)qy0, qy1));
         if (mask == 0ull) continue;
         my[lane * 3 + 0] = c0; my[lane * 3 + 1] = c1; my[lane * 3 + 2] = c2;
         __builtin_amdgcn_wave_barrier();

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libegs_raster.so")
+LIB_PATH = os.environ.get("EGS_RASTER_LIB", os.path.join(_HERE, "libegs_raster.so"))      # override for A/B builds
 ABI_VERSION = 1
 
 vp, f32, i32, i64 = C.c_void_p, C.c_float, C.c_int, C.c_int64
@@ -18,8 +18,8 @@ class GeomLayout(C.Structure):
 
 
 class BinningLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("keys_a", "keys_b", "vals_a", "vals_b", "hist", "spine")] + \
-               [(n, C.c_int) for n in ("sorted_in_b", "key_bits", "passes")]
+    _fields_ = [(n, C.c_size_t) for n in ("pairs", "scratch", "point_list", "table", "spine")] + \
+               [(n, C.c_int) for n in ("bin_blocks", "key_bits", "index_passes")]
 
 
 class ImageLayout(C.Structure):
@@ -32,11 +32,11 @@ SIGNATURES = {
     "egs_error_string": (C.c_char_p, [C.c_int]),
     "egs_device_info": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     "egs_geom_bytes": (C.c_size_t, [i32]),
-    "egs_binning_bytes": (C.c_size_t, [i64, i32, i32]),
+    "egs_binning_bytes": (C.c_size_t, [i32, i64, i32, i32]),
     "egs_image_bytes": (C.c_size_t, [i32, i32]),
     "egs_backward_scratch_bytes": (C.c_size_t, [i32]),
     "egs_get_geom_layout": (C.c_int, [i32, C.POINTER(GeomLayout)]),
-    "egs_get_binning_layout": (C.c_int, [i64, i32, i32, C.POINTER(BinningLayout)]),
+    "egs_get_binning_layout": (C.c_int, [i32, i64, i32, i32, C.POINTER(BinningLayout)]),
     "egs_get_image_layout": (C.c_int, [i32, i32, C.POINTER(ImageLayout)]),
     "egs_forward_geometry": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, f32, f32,
                                        i32, vp, vp, C.POINTER(i64), vp, i32]),

@@ -52,7 +52,7 @@ extern "C" {
 
 #define EGS_ERR_ARG        (-1)     /* NULL / inconsistent arguments */
 #define EGS_ERR_MODE       (-2)     /* colour or covariance mode not "exactly one of" */
-#define EGS_ERR_RANGE      (-3)     /* size outside supported range (image > 65535 px, R >= 2^32, degree > 3) */
+#define EGS_ERR_RANGE      (-3)     /* size outside supported range (image side > 65535 px or > 36864 tiles, R >= 2^31, degree > 3) */
 #define EGS_ERR_NO_DEVICE  (-4)     /* no HIP device / wrong architecture */
 
 int         egs_abi_version(void);
@@ -62,7 +62,7 @@ int         egs_device_info(char* name, int name_len, char* arch, int arch_len, 
 
 /* ---- buffer sizes (bytes) -------------------------------------------------------------------- */
 size_t egs_geom_bytes(int P);
-size_t egs_binning_bytes(int64_t R, int width, int height);
+size_t egs_binning_bytes(int P, int64_t R, int width, int height);
 size_t egs_image_bytes(int width, int height);
 size_t egs_backward_scratch_bytes(int P);
 
@@ -70,19 +70,20 @@ size_t egs_backward_scratch_bytes(int P);
 typedef struct egs_geom_layout {
     size_t rec;            /* float4[P][3]  packed splat record: (x, y, depth, opacity | conA, conB, conC, r | g, b, bbox_x, bbox_y) */
     size_t rect;           /* uint32[P][2]  tile rect: (x0 | x1<<16, y0 | y1<<16) */
-    size_t offsets;        /* uint32[P]     inclusive scan of tiles touched */
+    size_t offsets;        /* uint32[P]     tiles touched by each Gaussian (0 = culled) */
     size_t clamped;        /* uint8[P]      bit c set <=> colour channel c was clamped at 0 */
-    size_t scan_scratch;   /* uint32[..]    spine of the scan */
-    size_t total;          /* uint64[1]     R */
+    size_t scan_scratch;   /* uint32[ceil(P/256)] per-workgroup instance counts (their sum is R) */
+    size_t total;          /* reserved */
 } egs_geom_layout;
 typedef struct egs_binning_layout {
-    size_t keys_a, keys_b; /* uint64[R] ping / pong */
-    size_t vals_a, vals_b; /* uint32[R] ping / pong */
-    size_t hist;           /* uint32[..] per-block digit histograms */
-    size_t spine;          /* uint32[..] scan spine */
-    int    sorted_in_b;    /* 1 if the sorted result lives in (keys_b, vals_b) */
-    int    key_bits;       /* low key bits sorted: 32 + bits(tile count) */
-    int    passes;         /* radix passes */
+    size_t pairs;          /* uint64[R]  (float bits of depth << 32 | Gaussian index), bucketed by tile */
+    size_t scratch;        /* uint64[R]  ping-pong space for buckets too large for the in-register sort */
+    size_t point_list;     /* uint32[R]  Gaussian indices ordered by (tile, depth bits, index) */
+    size_t table;          /* uint32[tiles][bin_blocks] per-(tile, block) counts, exclusive-scanned in place */
+    size_t spine;          /* uint32[..] scan scratch */
+    int    bin_blocks;     /* workgroups of the bucketing kernels = ceil(P / 1024) */
+    int    key_bits;       /* significant bits of the canonical (tile<<32 | depth) key: 32 + bits(tile count) */
+    int    index_passes;   /* 8-bit radix passes spent on the Gaussian index inside the per-tile sort (+4 on depth) */
 } egs_binning_layout;
 typedef struct egs_image_layout {
     size_t ranges;         /* uint32[tiles][2] */
@@ -90,10 +91,10 @@ typedef struct egs_image_layout {
     size_t n_contrib;      /* uint32[H*W] */
 } egs_image_layout;
 int egs_get_geom_layout(int P, egs_geom_layout* out);
-int egs_get_binning_layout(int64_t R, int width, int height, egs_binning_layout* out);
+int egs_get_binning_layout(int P, int64_t R, int width, int height, egs_binning_layout* out);
 int egs_get_image_layout(int width, int height, egs_image_layout* out);
 
-/* ---- forward, part 1: per-Gaussian geometry + scan  (upstream: preprocess + InclusiveSum) ------ */
+/* ---- forward, part 1: per-Gaussian geometry + instance count  (upstream: preprocess + InclusiveSum) ------ */
 int egs_forward_geometry(
     int P, int sh_degree, int sh_coeffs /* M: coefficients per channel in `shs` */,
     const float* means3D /*[P,3]*/, const float* shs /*[P,M,3] or NULL*/, const float* colors_precomp /*[P,3] or NULL*/,
@@ -104,8 +105,8 @@ int egs_forward_geometry(
     int32_t* radii /*[P] out*/, void* geom_buffer, int64_t* num_rendered /*HOST out: R*/,
     void* stream, int debug);
 
-/* ---- forward, part 2: duplicate, sort, tile ranges, blend  (upstream: duplicateWithKeys,
- *      SortPairs, identifyTileRanges, render) -------------------------------------------------- */
+/* ---- forward, part 2: bucket instances by tile, sort each tile by (depth, index), blend
+ *      (upstream: duplicateWithKeys, SortPairs, identifyTileRanges, render) ------------------------ */
 int egs_forward_render(
     int P, int64_t R, const float* background /*[3]*/, int width, int height,
     const void* geom_buffer, void* binning_buffer, void* image_buffer,

@@ -32,16 +32,17 @@ def test_sizes_and_layouts():
     L = lib.load()
     assert L.egs_geom_bytes(0) >= 0 and L.egs_geom_bytes(1000) < L.egs_geom_bytes(2000)
     assert L.egs_geom_bytes(500000) >= 500000 * (48 + 8 + 4 + 1)
-    assert L.egs_binning_bytes(10**6, 960, 540) >= 10**6 * 24
+    assert L.egs_binning_bytes(500000, 10**6, 960, 540) >= 10**6 * 20
     assert L.egs_image_bytes(960, 540) >= 960 * 540 * 8 + 60 * 34 * 8
     assert L.egs_backward_scratch_bytes(1000) >= 48000
     g = lib.GeomLayout(); assert L.egs_get_geom_layout(1000, C.byref(g)) == 0
     offs = [g.rec, g.rect, g.offsets, g.clamped, g.scan_scratch, g.total]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs) and offs[-1] + 8 <= L.egs_geom_bytes(1000)
-    b = lib.BinningLayout(); assert L.egs_get_binning_layout(5000, 960, 540, C.byref(b)) == 0
-    assert b.key_bits == 32 + 11 and b.passes == 6 and b.sorted_in_b == 0          # 60 x 34 = 2040 tiles -> 11 bits
-    assert L.egs_get_binning_layout(5000, 1920, 1080, C.byref(b)) == 0 and b.key_bits == 45
-    assert L.egs_get_binning_layout(5000, 64, 64, C.byref(b)) == 0 and b.key_bits == 37 and b.passes == 5 and b.sorted_in_b == 1
+    b = lib.BinningLayout(); assert L.egs_get_binning_layout(500000, 5000, 960, 540, C.byref(b)) == 0
+    assert b.key_bits == 32 + 11 and b.index_passes == 3 and b.bin_blocks == 489     # 60 x 34 = 2040 tiles -> 11 bits; 19 index bits
+    assert b.pairs < b.scratch < b.point_list < b.table < b.spine
+    assert L.egs_get_binning_layout(1000000, 5000, 1920, 1080, C.byref(b)) == 0 and b.key_bits == 45 and b.index_passes == 3
+    assert L.egs_get_binning_layout(200, 5000, 64, 64, C.byref(b)) == 0 and b.key_bits == 37 and b.index_passes == 1 and b.bin_blocks == 1
     i = lib.ImageLayout(); assert L.egs_get_image_layout(100, 70, C.byref(i)) == 0 and i.ranges < i.final_T < i.n_contrib
 
 
@@ -58,6 +59,8 @@ def test_argument_errors_precede_device_work():
                                   none, none, C.byref(R), none, 0) == -1
     assert L.egs_forward_geometry(10, 0, 1, none, none, none, none, none, 1.0, none, none, none, none, none, 70000, 64, 1.0, 1.0,
                                   0, none, none, C.byref(R), none, 0) == -3
+    assert L.egs_forward_geometry(10, 0, 1, none, none, none, none, none, 1.0, none, none, none, none, none, 8192, 8192, 1.0, 1.0,
+                                  0, none, none, C.byref(R), none, 0) == -3      # 262144 tiles > 36864 (one LDS counter per tile)
     # P == 0 is a valid no-op
     assert L.egs_forward_geometry(0, 0, 0, none, none, none, none, none, 1.0, none, none, none, none, none, 64, 64, 1.0, 1.0, 0,
                                   none, none, C.byref(R), none, 0) == 0 and R.value == 0

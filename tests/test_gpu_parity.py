@@ -85,7 +85,7 @@ def test_forward_and_backward_parity(N, H, W, seed, deg, mode, smul):
     assert np.array_equal(radii.cpu().numpy(), st["radii"])
     gv = _C.geom_views(geom, N)
     vis = st["radii"] > 0
-    assert np.array_equal(gv["offsets"].cpu().numpy().view(np.uint32), st["offsets"])
+    assert np.array_equal(gv["offsets"].cpu().numpy().view(np.uint32), st["tiles_touched"])
     rec = gv["rec"].cpu().numpy()        # (x, y, qa, qb | qc, opacity, r, g | b, depth, bbox_x, bbox_y), egs_common.h
     assert np.array_equal(rec[vis, 0:2].view(np.uint32), st["xy"][vis].view(np.uint32)), "pixel centres not bit-exact"
     assert np.array_equal(rec[vis, 9].view(np.uint32), st["depths"][vis].view(np.uint32)), "depth not bit-exact"
@@ -99,10 +99,16 @@ def test_forward_and_backward_parity(N, H, W, seed, deg, mode, smul):
     rect = gv["rect"].cpu().numpy().view(np.uint32)
     rects_hip = np.stack([rect[:, 0] & 0xffff, rect[:, 1] & 0xffff, rect[:, 0] >> 16, rect[:, 1] >> 16], 1).astype(np.int32)
     assert np.array_equal(rects_hip[vis], st["rects"][vis])
-    bv = _C.binning_views(binning, R, W, H)
+    bv = _C.binning_views(binning, N, R, W, H)
     assert bv["key_bits"] == st["key_bits"]
-    assert np.array_equal(bv["keys"].cpu().numpy().view(np.uint64), st["keys"]), "sorted keys not bit-exact"
-    assert np.array_equal(bv["point_list"].cpu().numpy().view(np.uint32), st["point_list"]), "sorted values not bit-exact"
+    iv = _C.image_views(img, W, H)
+    pl = bv["point_list"].cpu().numpy().view(np.uint32)
+    assert np.array_equal(pl, st["point_list"]), "sorted instance list not bit-exact"
+    # rebuild the canonical 64-bit keys (tile << 32 | depth bits) from the HIP state and compare with the oracle's
+    rng = iv["ranges"].cpu().numpy().view(np.uint32)
+    tile_of = np.repeat(np.arange(rng.shape[0], dtype=np.uint64), (rng[:, 1] - rng[:, 0]).astype(np.int64))
+    keys_hip = (tile_of << np.uint64(32)) | rec[pl, 9].view(np.uint32).astype(np.uint64)
+    assert np.array_equal(keys_hip, st["keys"]), "sorted keys not bit-exact"
     iv = _C.image_views(img, W, H)
     assert np.array_equal(iv["ranges"].cpu().numpy().view(np.uint32), st["ranges"])
 
@@ -203,11 +209,13 @@ def test_image_invariants_at_full_size():
     d = make_inputs(N, H, W, 0, 0, "sh_cov")
     g, out = hip_forward(d, dev)
     R, color, depth, alpha, radii, geom, binning, img = out
-    iv = _C.image_views(img, W, H); bv = _C.binning_views(binning, R, W, H); gv = _C.geom_views(geom, N)
+    iv = _C.image_views(img, W, H); bv = _C.binning_views(binning, N, R, W, H); gv = _C.geom_views(geom, N)
     assert abs(float((alpha[0] + iv["final_T"] - 1).abs().max())) < 1e-4
-    keys = bv["keys"].cpu().numpy().view(np.uint64)
-    assert np.all(keys[1:] >= keys[:-1])
-    assert int(gv["offsets"][-1]) == R
+    rng = iv["ranges"].cpu().numpy().view(np.uint32); pl = bv["point_list"].cpu().numpy().view(np.uint32)
+    tile_of = np.repeat(np.arange(rng.shape[0], dtype=np.uint64), (rng[:, 1] - rng[:, 0]).astype(np.int64))
+    keys = (tile_of << np.uint64(52)) | (gv["rec"].cpu().numpy()[pl, 9].view(np.uint32).astype(np.uint64) << np.uint64(20)) | pl
+    assert len(keys) == R and np.all(keys[1:] > keys[:-1])          # strictly increasing in (tile, depth, index)
+    assert int(gv["offsets"].sum()) == R
     d0 = dict(d); d0["bg"] = torch.zeros(3)
     _, out0 = hip_forward(d0, dev)
     diff = color - out0[1]
