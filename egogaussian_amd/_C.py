@@ -14,7 +14,9 @@ import torch
 from . import lib as _lib
 
 
-stats = {"num_rendered": 0}       # R of the most recent forward (read by bench.py)
+stats = {"num_rendered": 0, "capacity": 0, "retries": 0}       # of the most recent forward (read by bench.py / tests)
+_capacity_hint = {}                # device index -> instance capacity the next forward is enqueued against
+_pinned_counts = {}                # device index -> page-locked host buffer for the per-workgroup instance counts
 
 
 def binning_passes(P, W, H):
@@ -71,15 +73,31 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         geom = torch.empty((L.egs_geom_bytes(P),), device=dev, dtype=torch.uint8)
         img = torch.empty((L.egs_image_bytes(W, H),), device=dev, dtype=torch.uint8)
         R = C.c_int64(0)
-        if P != 0:
-            _lib.check(L.egs_forward_geometry(
-                P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
-                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
-                _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom),
-                C.byref(R), _stream(), int(bool(debug))))
-        binning = torch.empty((L.egs_binning_bytes(P, R.value, W, H),), device=dev, dtype=torch.uint8)
-        _lib.check(L.egs_forward_render(P, R.value, _ptr(background), W, H, _ptr(geom), _ptr(binning), _ptr(img),
-                                        _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), _stream(), int(bool(debug))))
+        # The instance count R is data dependent.  Instead of stopping the GPU while the host reads it, the whole chain
+        # is enqueued against a capacity guess (1.25 x the largest R seen on this device); only a too-small guess costs
+        # a second binning + blend launch.
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        cap = _capacity_hint.get(key, 0)
+        nb = (P + 255) // 256
+        pinned = _pinned_counts.get(key)
+        if pinned is None or pinned.numel() < nb:
+            pinned = _pinned_counts[key] = torch.empty((max(nb, 4096),), dtype=torch.int32, pin_memory=True)
+        binning = torch.empty((L.egs_binning_bytes(P, cap, W, H),), device=dev, dtype=torch.uint8)
+        rc = L.egs_forward(P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
+                           float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+                           _ptr(campos), _ptr(background), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                           _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img), _ptr(out_color), _ptr(out_depth),
+                           _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _stream(), int(bool(debug)))
+        if rc == _lib.RETRY_LARGER:
+            cap = int(R.value * 1.25) + 65536
+            binning = torch.empty((L.egs_binning_bytes(P, cap, W, H),), device=dev, dtype=torch.uint8)
+            rc = L.egs_forward_render(P, cap, _ptr(background), W, H, _ptr(geom), _ptr(binning), _ptr(img), _ptr(out_color),
+                                      _ptr(out_depth), _ptr(out_alpha), _stream(), int(bool(debug)))
+            stats["retries"] += 1
+        _lib.check(rc)
+        if P:
+            _capacity_hint[key] = max(cap, 0) if R.value else _capacity_hint.get(key, 0)
+        stats["capacity"] = cap
     stats["num_rendered"] = int(R.value)
     return int(R.value), out_color, out_depth, out_alpha, radii, geom, binning, img
 
@@ -150,9 +168,10 @@ def geom_views(geom, P):
                 offsets=v(lay.offsets, P * 4, torch.int32), clamped=geom[lay.clamped:lay.clamped + P])
 
 
-def binning_views(binning, P, R, W, H):
+def binning_views(binning, P, R, W, H, capacity=None):
+    """Typed views; `capacity` = the size the buffer was laid out for (stats["capacity"] right after a forward)."""
     lay = _lib.BinningLayout()
-    _lib.check(_lib.load().egs_get_binning_layout(P, R, W, H, C.byref(lay)))
+    _lib.check(_lib.load().egs_get_binning_layout(P, R if capacity is None else capacity, W, H, C.byref(lay)))
     nt = ((W + 15) // 16) * ((H + 15) // 16)
     return dict(point_list=binning[lay.point_list:lay.point_list + R * 4].view(torch.int32),
                 pairs=binning[lay.pairs:lay.pairs + R * 8].view(torch.int64),

@@ -30,11 +30,11 @@ BinLayout bin_layout(int P, int64_t R, int W, int H) {
     L.o.bin_blocks = (int)nblocks;
     int ib = 0; while (P > 1 && (((unsigned)(P - 1)) >> ib) != 0) ib++;
     L.o.index_passes = (ib + 7) / 8;
+    L.o.point_list = off; off = egs_align(off + n * sizeof(uint32_t));          // first: the backward needs nothing else
     L.o.pairs = off;      off = egs_align(off + n * sizeof(uint64_t));
     L.o.scratch = off;    off = egs_align(off + n * sizeof(uint64_t));
-    L.o.point_list = off; off = egs_align(off + n * sizeof(uint32_t));
     L.o.table = off;      off = egs_align(off + (n ? tab : 0) * sizeof(uint32_t));
-    L.o.spine = off;      off = egs_align(off + (n ? egs_scan_scratch_elems(tab) : 0) * sizeof(uint32_t));
+    L.o.spine = off;      off = egs_align(off + (n ? egs_scan_scratch_elems(tab) + 64 : 0) * sizeof(uint32_t));
     L.bytes = off; return L;
 }
 ImgLayout img_layout(int W, int H) {
@@ -55,6 +55,7 @@ EgsBinPtrs bin_ptrs(void* buf, int P, int64_t R, int W, int H) {
     const BinLayout L = bin_layout(P, R, W, H); char* b = (char*)buf; EgsBinPtrs p;
     p.pairs = (uint64_t*)(b + L.o.pairs); p.scratch = (uint64_t*)(b + L.o.scratch);
     p.point_list = (uint32_t*)(b + L.o.point_list); p.table = (uint32_t*)(b + L.o.table); p.spine = (uint32_t*)(b + L.o.spine);
+    p.total = (uint64_t*)(p.spine + egs_scan_scratch_elems((size_t)((W + EGS_TILE - 1) / EGS_TILE) * ((H + EGS_TILE - 1) / EGS_TILE) * egs_bin_blocks(P > 0 ? P : 0)) + 32);
     return p;
 }
 EgsImgPtrs img_ptrs(void* buf, int W, int H) {
@@ -143,6 +144,7 @@ const char* egs_error_string(int code) {
         case EGS_ERR_MODE: return "egs: provide exactly one of {shs, colors_precomp} and exactly one of {cov3D_precomp, (scales, rotations)}";
         case EGS_ERR_RANGE: return "egs: size outside the supported range";
         case EGS_ERR_NO_DEVICE: return "egs: no usable HIP device";
+        case EGS_RETRY_LARGER: return "egs: binning capacity too small for this frame; call egs_forward_render with a buffer for R";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "egs: unknown error";
     }
 }
@@ -204,6 +206,59 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
     for (size_t k = 0; k < nb; k++) R += sums[k];
     if (R >= (1ull << 31)) return EGS_ERR_RANGE;
     *num_rendered = (int64_t)R;
+    return 0;
+}
+
+// One-call forward: preprocess, then -- without waiting for R -- the whole binning + blend chain is enqueued against
+// the caller's capacity guess while the host waits only for the copy of the per-block instance counts.  The GPU never
+// idles on the host round trip.  If the guess was too small nothing valid was produced: the true R is returned and the
+// caller finishes with egs_forward_render on a buffer of the right size.
+int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
+                int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
+                float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, int64_t* num_rendered,
+                void* stream, int debug) {
+    (void)prefiltered;
+    int rc = check_dims(P, width, height); if (rc) return rc;
+    if (!num_rendered || capacity < 0 || capacity >= (1ll << 31)) return EGS_ERR_ARG;
+    *num_rendered = 0;
+    if (!background || !image_buffer || !out_color || !out_depth || !out_alpha) return EGS_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) return egs_forward_render(0, 0, background, width, height, geom_buffer, binning_buffer, image_buffer, out_color,
+                                          out_depth, out_alpha, stream, debug);
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !pinned_host_counts)
+        return EGS_ERR_ARG;
+    if (capacity > 0 && !binning_buffer) return EGS_ERR_ARG;
+    rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp); if (rc) return rc;
+    if (shs && (sh_degree < 0 || sh_degree > EGS_MAX_SH_DEGREE || sh_coeffs < (sh_degree + 1) * (sh_degree + 1))) return EGS_ERR_RANGE;
+    static thread_local hipEvent_t ev = nullptr;
+    if (!ev) EGS_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    EgsGeomPtrs g = geom_ptrs(geom_buffer, P);
+    EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
+    egs_prof_start(EGS_K_PREPROCESS, s);
+    EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                                  rotations, cov3D_precomp, cam, radii, g, s));
+    egs_prof_stop(EGS_K_PREPROCESS, s);
+    const size_t nb = ((size_t)P + 255) / 256;
+    EGS_TRY(hipMemcpyAsync(pinned_host_counts, g.scan_scratch, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    EGS_TRY(hipEventRecord(ev, s));
+    if (capacity > 0) {                                              // speculative: sized by the caller's guess
+        EgsBinPtrs b = bin_ptrs(binning_buffer, P, capacity, width, height);
+        EgsImgPtrs im = img_ptrs(image_buffer, width, height);
+        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, s, 0));
+        egs_prof_start(EGS_K_RENDER_FWD, s);
+        EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, s));
+        egs_prof_stop(EGS_K_RENDER_FWD, s);
+    }
+    EGS_TRY(hipEventSynchronize(ev));
+    uint64_t R = 0;
+    for (size_t k = 0; k < nb; k++) R += pinned_host_counts[k];
+    if (R >= (1ull << 31)) return EGS_ERR_RANGE;
+    *num_rendered = (int64_t)R;
+    if ((int64_t)R > capacity || capacity == 0) return EGS_RETRY_LARGER;       // caller: egs_forward_render with a buffer for R
+    EGS_SYNC_IF_DEBUG(s);
     return 0;
 }
 

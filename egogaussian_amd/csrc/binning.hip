@@ -171,13 +171,13 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, const uint
 __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, const uint32_t* __restrict__ tiles_touched,
                                                       const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
                                                       int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
-                                                      uint64_t* __restrict__ pairs) {
+                                                      uint32_t cap, uint64_t* __restrict__ pairs) {
     uint32_t* cursor = dyn_lds;
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) cursor[t] = table_scanned[(size_t)t * nblocks + blockIdx.x];
     __syncthreads();
     for_each_instance(P, tiles_touched, rect, rec, gx, true, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
         const uint32_t pos = atomicAdd(&cursor[tile], 1u);
-        pairs[pos] = ((uint64_t)dbits << 32) | idx;
+        if (pos < cap) pairs[pos] = ((uint64_t)dbits << 32) | idx;      // cap < R only in a speculative launch that will be redone
     });
 }
 
@@ -211,7 +211,8 @@ __device__ __forceinline__ void digit_bases(uint32_t (*cnt)[256], uint32_t* lds4
 }
 
 __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
-                                                    uint32_t R, int index_passes, uint64_t* __restrict__ pairs,
+                                                    const uint64_t* __restrict__ total, uint32_t R /* capacity */,
+                                                    int index_passes, uint64_t* __restrict__ pairs,
                                                     uint64_t* __restrict__ scratch, uint32_t* __restrict__ point_list,
                                                     uint2* __restrict__ ranges) {
     __shared__ uint64_t xbuf[TS_CAP];
@@ -219,8 +220,8 @@ __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks
     __shared__ uint32_t lds4[4];
     const int tile = blockIdx.x;
     const uint32_t beg = table_scanned[(size_t)tile * nblocks];
-    const uint32_t end = tile + 1 < n_tiles ? table_scanned[(size_t)(tile + 1) * nblocks] : R;
-    const uint32_t n = end - beg;
+    const uint32_t end = tile + 1 < n_tiles ? table_scanned[(size_t)(tile + 1) * nblocks] : (uint32_t)*total;
+    const uint32_t n = end > R ? 0u : end - beg;                     // end > capacity: speculative launch that overflowed
     if (threadIdx.x == 0) ranges[tile] = n ? make_uint2(beg, end) : make_uint2(0u, 0u);
     if (n == 0) return;
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -393,15 +394,15 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     egs_prof_start(EGS_K_DUPLICATE, s);
     hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, b.table);
     EGS_DBG(s);
-    hipError_t e = egs_launch_scan_u32(b.table, b.table, (size_t)n_tiles * nblocks, 0, b.spine, nullptr, s);
+    hipError_t e = egs_launch_scan_u32(b.table, b.table, (size_t)n_tiles * nblocks, 0, b.spine, b.total, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_bin_scatter, dim3(nblocks), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
-                       b.table, b.pairs);
+                       b.table, R, b.pairs);
     egs_prof_stop(EGS_K_DUPLICATE, s);
     EGS_DBG(s);
     int index_bits = 0; while (((unsigned)(P - 1) >> index_bits) != 0) index_bits++;
     egs_prof_start(EGS_K_SORT, s);
-    hipLaunchKernelGGL(k_tile_sort, dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, R, (index_bits + 7) / 8, b.pairs,
+    hipLaunchKernelGGL(k_tile_sort, dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, b.total, R, (index_bits + 7) / 8, b.pairs,
                        b.scratch, b.point_list, im.ranges);
     egs_prof_stop(EGS_K_SORT, s);
     EGS_DBG(s);

@@ -33,6 +33,7 @@ struct EgsBinPtrs {
     uint32_t* point_list;   // [R] sorted Gaussian indices
     uint32_t* table;        // [n_tiles][bin_blocks] per-(tile, block) instance counts, scanned in place
     uint32_t* spine;        // scan scratch
+    uint64_t* total;        // [1] number of instances found by the scan (== R)
 };
 struct EgsImgPtrs { uint2* ranges; float* final_T; uint32_t* n_contrib; };
 

@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EGS_RASTER_LIB", os.path.join(_HERE, "libegs_raster.so"))      # override for A/B builds
 ABI_VERSION = 1
+RETRY_LARGER = -100
 
 vp, f32, i32, i64 = C.c_void_p, C.c_float, C.c_int, C.c_int64
 
@@ -18,7 +19,7 @@ class GeomLayout(C.Structure):
 
 
 class BinningLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("pairs", "scratch", "point_list", "table", "spine")] + \
+    _fields_ = [(n, C.c_size_t) for n in ("point_list", "pairs", "scratch", "table", "spine")] + \
                [(n, C.c_int) for n in ("bin_blocks", "key_bits", "index_passes")]
 
 
@@ -40,6 +41,8 @@ SIGNATURES = {
     "egs_get_image_layout": (C.c_int, [i32, i32, C.POINTER(ImageLayout)]),
     "egs_forward_geometry": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, f32, f32,
                                        i32, vp, vp, C.POINTER(i64), vp, i32]),
+    "egs_forward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, i64,
+                               vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp, i32]),
     "egs_forward_render": (C.c_int, [i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, f32, f32,
                                vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),

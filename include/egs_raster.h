@@ -54,6 +54,7 @@ extern "C" {
 #define EGS_ERR_MODE       (-2)     /* colour or covariance mode not "exactly one of" */
 #define EGS_ERR_RANGE      (-3)     /* size outside supported range (image side > 65535 px or > 36864 tiles, R >= 2^31, degree > 3) */
 #define EGS_ERR_NO_DEVICE  (-4)     /* no HIP device / wrong architecture */
+#define EGS_RETRY_LARGER   (-100)   /* egs_forward only: capacity guess too small, nothing rendered; *num_rendered holds R */
 
 int         egs_abi_version(void);
 const char* egs_error_string(int code);
@@ -76,9 +77,9 @@ typedef struct egs_geom_layout {
     size_t total;          /* reserved */
 } egs_geom_layout;
 typedef struct egs_binning_layout {
+    size_t point_list;     /* uint32[R]  Gaussian indices ordered by (tile, depth bits, index); ALWAYS at offset 0 */
     size_t pairs;          /* uint64[R]  (float bits of depth << 32 | Gaussian index), bucketed by tile */
     size_t scratch;        /* uint64[R]  ping-pong space for buckets too large for the in-register sort */
-    size_t point_list;     /* uint32[R]  Gaussian indices ordered by (tile, depth bits, index) */
     size_t table;          /* uint32[tiles][bin_blocks] per-(tile, block) counts, exclusive-scanned in place */
     size_t spine;          /* uint32[..] scan scratch */
     int    bin_blocks;     /* workgroups of the bucketing kernels = ceil(P / 1024) */
@@ -107,11 +108,30 @@ int egs_forward_geometry(
 
 /* ---- forward, part 2: bucket instances by tile, sort each tile by (depth, index), blend
  *      (upstream: duplicateWithKeys, SortPairs, identifyTileRanges, render) ------------------------ */
+/* R here (and in egs_backward) is the instance count the binning buffer was laid out for: the exact count from
+ * egs_forward_geometry, or the `capacity` given to egs_forward. */
 int egs_forward_render(
     int P, int64_t R, const float* background /*[3]*/, int width, int height,
     const void* geom_buffer, void* binning_buffer, void* image_buffer,
     float* out_color /*[3,H,W]*/, float* out_depth /*[1,H,W]*/, float* out_alpha /*[1,H,W]*/,
     void* stream, int debug);
+
+/* ---- forward in ONE call, without a GPU bubble.  Same work as egs_forward_geometry + egs_forward_render, but the
+ *      binning and blend kernels are enqueued against `capacity` (the caller's guess of R, e.g. 1.25 x the largest R seen
+ *      so far; layout = egs_binning_bytes(P, capacity, ...)) before R is known, and the host waits only for the copy of
+ *      the per-workgroup instance counts into `pinned_host_counts` (page-locked host memory, >= ceil(P/256) uint32).
+ *      Returns 0 with *num_rendered = R when R <= capacity.  Returns EGS_RETRY_LARGER with *num_rendered = R when the guess
+ *      was too small (or capacity == 0): nothing valid was rendered; allocate a binning buffer for >= R instances and call
+ *      egs_forward_render(P, that_size, ...).  Keeps one hipEvent per calling thread. */
+int egs_forward(
+    int P, int sh_degree, int sh_coeffs,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos, const float* background,
+    int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
+    int32_t* radii /*[P] out*/, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
+    float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts /*HOST, page-locked*/,
+    int64_t* num_rendered /*HOST out*/, void* stream, int debug);
 
 /* ---- backward  (upstream: render backward + computeCov2D backward + preprocess backward) ------- */
 int egs_backward(

@@ -40,7 +40,7 @@ def test_sizes_and_layouts():
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs) and offs[-1] + 8 <= L.egs_geom_bytes(1000)
     b = lib.BinningLayout(); assert L.egs_get_binning_layout(500000, 5000, 960, 540, C.byref(b)) == 0
     assert b.key_bits == 32 + 11 and b.index_passes == 3 and b.bin_blocks == 489     # 60 x 34 = 2040 tiles -> 11 bits; 19 index bits
-    assert b.pairs < b.scratch < b.point_list < b.table < b.spine
+    assert b.point_list == 0 < b.pairs < b.scratch < b.table < b.spine       # the backward only needs point_list (offset 0)
     assert L.egs_get_binning_layout(1000000, 5000, 1920, 1080, C.byref(b)) == 0 and b.key_bits == 45 and b.index_passes == 3
     assert L.egs_get_binning_layout(200, 5000, 64, 64, C.byref(b)) == 0 and b.key_bits == 37 and b.index_passes == 1 and b.bin_blocks == 1
     i = lib.ImageLayout(); assert L.egs_get_image_layout(100, 70, C.byref(i)) == 0 and i.ranges < i.final_T < i.n_contrib
@@ -72,7 +72,10 @@ def test_argument_errors_precede_device_work():
                                   none, 0) == -2      # scales without rotations
     assert L.egs_forward_geometry(10, 4, 25, p, p, none, p, none, 1.0, none, p, p, p, p, 64, 64, 1.0, 1.0, 0, p, p, C.byref(R),
                                   none, 0) == -3      # SH degree 4 unsupported
-    assert b"exactly one" in L.egs_error_string(-2)
+    assert b"exactly one" in L.egs_error_string(-2) and b"capacity" in L.egs_error_string(lib.RETRY_LARGER)
+    # one-call forward: argument errors before any device work
+    assert L.egs_forward(10, 0, 1, none, none, none, none, none, 1.0, none, none, none, none, none, none, 64, 64, 1.0, 1.0, 0,
+                         none, none, 100, none, none, none, none, none, none, C.byref(R), none, 0) == -1
     assert L.egs_mark_visible(5, none, none, none, none, none) == -1
 
 
@@ -99,6 +102,17 @@ def test_python_surface_validation_and_no_cpu_fallback():
     # CPU tensors: loud failure, never a silent fallback
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         r(means3D=x, means2D=x, opacities=o, shs=torch.zeros(4, 1, 3), cov3D_precomp=torch.zeros(4, 6))
+
+
+def test_library_is_not_older_than_its_sources():
+    """Guards against benchmarking a stale build: the .so must be newer than every file it is compiled from."""
+    lib_path = os.path.join(ROOT, "egogaussian_amd", "libegs_raster.so")
+    srcs = [os.path.join(ROOT, "include", "egs_raster.h")]
+    csrc = os.path.join(ROOT, "egogaussian_amd", "csrc")
+    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    newest = max(os.path.getmtime(f) for f in srcs)
+    if os.path.exists("/opt/rocm/bin/hipcc") and os.path.isdir("/root/reference"):      # build container: enforce
+        assert os.path.getmtime(lib_path) >= newest, "libegs_raster.so is stale: run python -c 'import __graft_entry__ as g; g.build()'"
 
 
 def test_product_never_imports_the_oracle():

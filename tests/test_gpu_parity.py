@@ -99,7 +99,7 @@ def test_forward_and_backward_parity(N, H, W, seed, deg, mode, smul):
     rect = gv["rect"].cpu().numpy().view(np.uint32)
     rects_hip = np.stack([rect[:, 0] & 0xffff, rect[:, 1] & 0xffff, rect[:, 0] >> 16, rect[:, 1] >> 16], 1).astype(np.int32)
     assert np.array_equal(rects_hip[vis], st["rects"][vis])
-    bv = _C.binning_views(binning, N, R, W, H)
+    bv = _C.binning_views(binning, N, R, W, H, _C.stats["capacity"])
     assert bv["key_bits"] == st["key_bits"]
     iv = _C.image_views(img, W, H)
     pl = bv["point_list"].cpu().numpy().view(np.uint32)
@@ -167,6 +167,43 @@ def test_empty_and_culled_inputs():
     assert hb[0].shape == (0, 3)
 
 
+def test_capacity_guess_paths_agree():
+    """The speculative one-call forward (capacity guess large enough), the retry path (guess too small) and the first
+    call (no guess) must produce identical results."""
+    from egogaussian_amd import _C
+    dev = _dev()
+    d = make_inputs(4000, 96, 128, 8, 0, "sh_cov", scale_mul=3.0)
+    key = torch.cuda.current_device()
+    outs = []
+    for hint in (0, 10, 10_000_000):                       # no guess / too small (retry) / ample
+        _C._capacity_hint[key] = hint
+        before = _C.stats["retries"]
+        g, out = hip_forward(d, dev)
+        assert (_C.stats["retries"] > before) == (hint < out[0])
+        bv = _C.binning_views(out[6], 4000, out[0], 128, 96, _C.stats["capacity"])
+        outs.append((out[0], out[1].clone(), out[2].clone(), out[3].clone(), bv["point_list"].clone()))
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and all(torch.equal(a, b) for a, b in zip(o[1:], outs[0][1:]))
+    assert _C._capacity_hint[key] >= outs[0][0]
+
+
+def test_depth_ties_keep_index_order():
+    """All Gaussians at the same depth: every tile list must come out in Gaussian-index order (oracle: stable sort)."""
+    from egogaussian_amd import _C
+    from egogaussian_amd.scene_synth import make_camera
+    dev = _dev()
+    d = make_inputs(3000, 64, 64, 5, 0, "col_sr", scale_mul=6.0)
+    d["means3D"][:, 2] = 5.0
+    cam = make_camera(0, 64, 64)
+    d.update(viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, campos=cam.camera_center)
+    o, st = oracle_forward(d)
+    g, out = hip_forward(d, dev)
+    bv = _C.binning_views(out[6], 3000, out[0], 64, 64, _C.stats["capacity"])
+    assert out[0] == st["R"] and st["R"] > 3000
+    assert np.array_equal(bv["point_list"].cpu().numpy().view(np.uint32), st["point_list"])
+    assert rel_err(out[1].cpu().numpy(), st["color"]) < 1e-5
+
+
 def test_mark_visible_matches_oracle():
     from egogaussian_amd import _C
     from oracle.oracle import Oracle
@@ -209,7 +246,7 @@ def test_image_invariants_at_full_size():
     d = make_inputs(N, H, W, 0, 0, "sh_cov")
     g, out = hip_forward(d, dev)
     R, color, depth, alpha, radii, geom, binning, img = out
-    iv = _C.image_views(img, W, H); bv = _C.binning_views(binning, N, R, W, H); gv = _C.geom_views(geom, N)
+    iv = _C.image_views(img, W, H); bv = _C.binning_views(binning, N, R, W, H, _C.stats["capacity"]); gv = _C.geom_views(geom, N)
     assert abs(float((alpha[0] + iv["final_T"] - 1).abs().max())) < 1e-4
     rng = iv["ranges"].cpu().numpy().view(np.uint32); pl = bv["point_list"].cpu().numpy().view(np.uint32)
     tile_of = np.repeat(np.arange(rng.shape[0], dtype=np.uint64), (rng[:, 1] - rng[:, 0]).astype(np.int64))
