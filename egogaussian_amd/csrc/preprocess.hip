@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     const float* __restrict__ scales, float mod, const float* __restrict__ rots, const float* __restrict__ cov3D_in,
     const float* __restrict__ V, const float* __restrict__ PM, const float* __restrict__ campos, int W, int H,
     float tanfovx, float tanfovy, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
-    const float* __restrict__ grad_acc, float* __restrict__ dmeans2D, float* __restrict__ dcolors,
+    const float4* __restrict__ rec, const float* __restrict__ grad_acc, float* __restrict__ dmeans2D, float* __restrict__ dcolors,
     float* __restrict__ dopac, float* __restrict__ dmeans3D, float* __restrict__ dcov3D, float* __restrict__ dsh,
     float* __restrict__ dscales, float* __restrict__ drots) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,8 +248,18 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
             acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
         }
     }
-    // the blend backward accumulates d/d(pixel position); the published op reports it in NDC units
-    acc[0] *= 0.5f * (float)W; acc[1] *= 0.5f * (float)H;
+    // acc[0..4] are moments of kG = dL/dG * G (egs_common.h); with the conic (A, B, C) of this Gaussian
+    //   dL/dmean2D = -(A Sx + B Sy, C Sy + B Sx)   and   dL/dconic = -0.5 (Sxx, Sxy, Syy)  (xy slot: half the derivative)
+    // The published op reports dL/dmean2D in NDC units (x 0.5 W, 0.5 H).
+    float gmx = 0.f, gmy = 0.f;
+    if (vis) {
+        const float4* r = rec + (size_t)i * EGS_SPLAT_REC_F4;
+        const float4 r0 = r[0], r1 = r[1];
+        const float cA = r0.z * (-2.f * EGS_LN2), cB = r0.w * (-EGS_LN2), cC = r1.x * (-2.f * EGS_LN2);
+        gmx = -(cA * acc[0] + cB * acc[1]); gmy = -(cC * acc[1] + cB * acc[0]);
+        acc[2] *= -0.5f; acc[3] *= -0.5f; acc[4] *= -0.5f;
+    }
+    acc[0] = gmx * (0.5f * (float)W); acc[1] = gmy * (0.5f * (float)H);
     dmeans2D[3 * i] = acc[0]; dmeans2D[3 * i + 1] = acc[1]; dmeans2D[3 * i + 2] = 0.f;
     dcolors[3 * i] = acc[6]; dcolors[3 * i + 1] = acc[7]; dcolors[3 * i + 2] = acc[8];
     dopac[i] = acc[5];
@@ -440,7 +450,7 @@ hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* mean
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(k_preprocess_backward, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D,
                        colors_given ? nullptr : shs, scales, mod, rots, cov3D, cam.view, cam.proj, cam.campos, cam.W,
-                       cam.H, cam.tanfovx, cam.tanfovy, radii, g.clamped, grad_acc, dmeans2D, dcolors, dopac, dmeans3D,
+                       cam.H, cam.tanfovx, cam.tanfovy, radii, g.clamped, g.rec, grad_acc, dmeans2D, dcolors, dopac, dmeans3D,
                        dcov3D, colors_given ? nullptr : dsh, cov3D ? nullptr : dscales, cov3D ? nullptr : drots);
     return hipGetLastError();
 }

@@ -139,18 +139,17 @@ __global__ __launch_bounds__(256) void k_render_backward(
             dLda = contrib ? dLda : 0.f;
             T = Tn; U = contrib ? Un : U; last_u = contrib ? u : last_u; last_alpha = contrib ? a : last_alpha;
 
-            // With the conic in log2 units (A = -2 ln2 qa, B = -ln2 qb, C = -2 ln2 qc):
-            //   dG/d(mean.x) = -G (A dx + B dy) = G ln2 (2 qa dx + qb dy) = G ln2 (t + m)
-            //   dG/d(mean.y) = -G (C dy + B dx) = G ln2 (2 qc dy + qb dx) = G ln2 (fma(qb, dx, n) + n)
-            const float kG = s1.y * dLda * G;                           // dL/dG * G
-            const float k = kG * EGS_LN2;
-            const float v0 = k * (t + m);
-            const float v1 = k * (fmaf(s0.w, dx, nn) + nn);
-            const float hG = -0.5f * kG;
-            const float ex = hG * dx, ey = hG * dy;
-            const float v2 = ex * dx, v3 = ex * dy, v4 = ey * dy;       // d/d conic xx, xy (half), yy
-            const float v5 = G * dLda;                                  // d/d opacity
+            // Per-splat sums published to the accumulator line are MOMENTS of kG = dL/dG * G over the pixels:
+            //   v0 = sum kG dx, v1 = sum kG dy, v2 = sum kG dx^2, v3 = sum kG dx dy, v4 = sum kG dy^2
+            // k_preprocess_backward turns them into d/d mean2D and d/d conic with the Gaussian's own conic
+            // (they are linear in these moments), which keeps that algebra out of the per-pixel loop.
+            const float gd = G * dLda;                                  // d/d opacity
+            const float kG = s1.y * gd;
+            const float v0 = kG * dx, v1 = kG * dy;
+            const float v2 = v0 * dx, v3 = v0 * dy, v4 = v1 * dy;
+            const float v5 = gd;
             const float v6 = w * g_r, v7 = w * g_g, v8 = w * g_b, v9 = w * g_d;
+            (void)t; (void)m; (void)nn;
 
             // 64-lane sums of v0..v9, ten results in ten lanes
             const float s01 = fold32(v0, v1), s23 = fold32(v2, v3), s45 = fold32(v4, v5), s67 = fold32(v6, v7),
