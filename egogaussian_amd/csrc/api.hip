@@ -137,6 +137,8 @@ const char* egs_profile_stage_name(int stage) {
 
 int egs_abi_version(void) { return EGS_ABI_VERSION; }
 
+int egs_debug_force_ballot_rank(int on) { const int old = egs_force_ballot_rank; egs_force_ballot_rank = on ? 1 : 0; return old; }
+
 const char* egs_error_string(int code) {
     switch (code) {
         case 0: return "ok";

@@ -25,6 +25,9 @@
 // 8 ballots ("same digit" peer mask) + popcount-below-lane, with per-wave LDS counters touched only by each peer
 // group's lowest lane.
 #include "egs_common.h"
+#include <atomic>
+
+int egs_force_ballot_rank = 0;      // test hook (egs_debug_force_ballot_rank): exercise the fallback ranking
 
 namespace {
 
@@ -210,6 +213,40 @@ __device__ __forceinline__ void digit_bases(uint32_t (*cnt)[256], uint32_t* lds4
     __syncthreads();
 }
 
+// Stable rank of a key inside its wave's quarter, by digit.  Two implementations:
+//   RANK_ATOMIC = true   one ds_add_rtn_u32 on the wave's counter of that digit.  This relies on the LDS resolving
+//                        same-address lanes of one wave-instruction in increasing lane order, which is what gfx950 does
+//                        (tools/ubench/lds_atomic_order.hip: 2.3e8 lane-operations, none out of order) but is not an
+//                        architectural promise -- egs_launch_binning verifies it on the device once per process
+//                        (k_check_lds_atomic_order) and otherwise uses
+//   RANK_ATOMIC = false  8 ballots build the "same digit" peer mask; all lanes read the counter, the lowest peer bumps it.
+template <bool RANK_ATOMIC>
+__device__ __forceinline__ uint32_t wave_digit_rank(uint32_t* cnt_w, uint32_t d, bool ok, unsigned lane, uint64_t lt) {
+    if (RANK_ATOMIC) return ok ? atomicAdd(&cnt_w[d], 1u) : 0u;
+    const uint64_t peers = digit_peers(d, ok);
+    const uint32_t start = cnt_w[d];
+    if (ok && lane == (unsigned)__ffsll((unsigned long long)peers) - 1u) cnt_w[d] = start + (uint32_t)__popcll(peers);
+    return start + (uint32_t)__popcll(peers & lt);
+}
+
+__global__ void k_check_lds_atomic_order(uint32_t* __restrict__ violations) {
+    __shared__ uint32_t cnt[4][256];
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t bad = 0, x = 2654435761u * (threadIdx.x + 1u);
+    for (int t = 0; t < 64; t++) {
+        for (int i = lane; i < 256; i += 64) cnt[w][i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        const uint32_t d = (x >> 8) % (t < 16 ? 2u : t < 32 ? 7u : t < 48 ? 37u : 256u);
+        const uint32_t r = atomicAdd(&cnt[w][d], 1u);
+        const uint64_t peers = digit_peers(d, true);
+        if (r != (uint32_t)__popcll(peers & lanemask_lt())) bad++;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (bad) atomicAdd(violations, bad);
+}
+
+template <bool RANK_ATOMIC>
 __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
                                                     const uint64_t* __restrict__ total, uint32_t R /* capacity */,
                                                     int index_passes, uint64_t* __restrict__ pairs,
@@ -258,13 +295,9 @@ __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks
                     if (r * 64u < chunk) {                              // wave-uniform
                         const uint32_t i = wbeg + r * 64 + lane;
                         const bool ok = i < n;
-                        const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
-                        const uint64_t peers = digit_peers(d, ok);
-                        // every lane reads the running count of its digit, the group's lowest lane bumps it
-                        // (LDS operations of one wave execute in order, so the next round sees the update)
-                        const uint32_t start = cnt[w][d];
-                        if (ok && lane == (unsigned)__ffsll((unsigned long long)peers) - 1u) cnt[w][d] = start + (uint32_t)__popcll(peers);
-                        rank[r] = start + (uint32_t)__popcll(peers & lt);
+                        // running count of this digit in the wave's quarter (LDS operations of one wave execute in
+                        // order, so round r+1 sees round r's update)
+                        rank[r] = wave_digit_rank<RANK_ATOMIC>(cnt[w], (uint32_t)(key[r] >> shift) & 255u, ok, lane, lt);
                     }
                 }
                 __syncthreads();
@@ -314,9 +347,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks
             const uint32_t i = wbeg + r0 + lane;
             const bool ok = i < n;
             const uint32_t d = ok ? (uint32_t)(src[i] >> shift) & 255u : 0u;
-            const uint64_t peers = digit_peers(d, ok);
-            const unsigned leader = (unsigned)__ffsll((unsigned long long)peers) - 1u;
-            if (ok && lane == leader) cnt[w][d] += (uint32_t)__popcll(peers);
+            if (ok) atomicAdd(&cnt[w][d], 1u);                          // counting only: order irrelevant
         }
         __syncthreads();
         digit_bases(cnt, lds4);
@@ -326,13 +357,9 @@ __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks
             const bool ok = i < n;
             const uint64_t kv = ok ? src[i] : 0ull;
             const uint32_t d = (uint32_t)(kv >> shift) & 255u;
-            const uint64_t peers = digit_peers(d, ok);
-            const unsigned leader = (unsigned)__ffsll((unsigned long long)peers) - 1u;
-            uint32_t start = 0;
-            if (ok && lane == leader) { start = cnt[w][d]; cnt[w][d] = start + (uint32_t)__popcll(peers); }
-            start = __shfl(start, ok ? leader : lane, 64);
+            const uint32_t posr = wave_digit_rank<RANK_ATOMIC>(cnt[w], d, ok, lane, lt);   // cnt[w][d] is the running cursor
             if (ok) {
-                const uint32_t pos = start + (uint32_t)__popcll(peers & lt);
+                const uint32_t pos = posr;
                 if (last) point_list[beg + pos] = (uint32_t)kv;
                 else dst[pos] = kv;
             }
@@ -401,9 +428,30 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     egs_prof_stop(EGS_K_DUPLICATE, s);
     EGS_DBG(s);
     int index_bits = 0; while (((unsigned)(P - 1) >> index_bits) != 0) index_bits++;
+    // One-time device check of the LDS lane-order property the fast ranking relies on (see wave_digit_rank).
+    static std::atomic<int> lds_rank_ok{-1};
+    int fast = lds_rank_ok.load();
+    if (fast < 0) {
+        uint32_t* flag = b.spine;                                   // free at this point (the scan is done with it)
+        hipError_t e2 = hipMemsetAsync(flag, 0, sizeof(uint32_t), s);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL(k_check_lds_atomic_order, dim3(64), dim3(256), 0, s, flag);
+        uint32_t bad = 1;
+        e2 = hipMemcpyAsync(&bad, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e2 != hipSuccess) return e2;
+        e2 = hipStreamSynchronize(s);
+        if (e2 != hipSuccess) return e2;
+        fast = bad == 0 ? 1 : 0;
+        lds_rank_ok.store(fast);
+    }
+    if (egs_force_ballot_rank) fast = 0;
     egs_prof_start(EGS_K_SORT, s);
-    hipLaunchKernelGGL(k_tile_sort, dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, b.total, R, (index_bits + 7) / 8, b.pairs,
-                       b.scratch, b.point_list, im.ranges);
+    if (fast)
+        hipLaunchKernelGGL(k_tile_sort<true>, dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, b.total, R,
+                           (index_bits + 7) / 8, b.pairs, b.scratch, b.point_list, im.ranges);
+    else
+        hipLaunchKernelGGL(k_tile_sort<false>, dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, b.total, R,
+                           (index_bits + 7) / 8, b.pairs, b.scratch, b.point_list, im.ranges);
     egs_prof_stop(EGS_K_SORT, s);
     EGS_DBG(s);
     return hipGetLastError();

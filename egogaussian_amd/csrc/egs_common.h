@@ -85,3 +85,4 @@ hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs
 // optional stage timing (api.hip); no-ops unless egs_profile_begin() was called
 void egs_prof_start(int stage, hipStream_t s);
 void egs_prof_stop(int stage, hipStream_t s);
+extern int egs_force_ballot_rank;

@@ -183,6 +183,10 @@ int egs_l1_ssim_backward(int channels, int height, int width, const float* img, 
                          const float* dm_dmu1, const float* dm_dexx, const float* dm_dexy, float* dL_dimg /*[C,H,W] out*/,
                          void* stream);
 
+/* Test hook: the per-tile sort ranks keys with an LDS atomic whose lane-order behaviour is verified on the device once per
+ * process; on != 0 forces the ballot-based fallback so that tests can cover it.  Returns the previous setting. */
+int egs_debug_force_ballot_rank(int on);
+
 /* ---- optional per-stage timing with HIP events on the caller's stream (bench / profiling aid) ------
  * The only process-wide state in the library; off by default.  egs_profile_begin allocates an event pool and
  * turns recording on; every stage launched afterwards is bracketed by two events on its stream;
