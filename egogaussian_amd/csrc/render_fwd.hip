@@ -17,6 +17,10 @@
 //     cross-wave exchange;
 //   * the next batch's ids and records are issued before the current batch is blended, so the gather
 //     latency hides under VALU work.
+// Tried and rejected (round 1, config C): feeding the per-splat record through the scalar path instead of LDS
+// (v_readlane id -> s_load_dwordx8 + x2 into SGPRs, VALU reads SGPR operands, no LDS in the loop).  Compiler-scheduled:
+// 100 us; hand-placed s_waitcnt with the next splat's s_load in flight during the blend: 86 us; LDS staging: 70 us.
+// One s_load per (wave, splat) pays an L2 round trip each, while the LDS design gathers 64 records at once a batch ahead.
 // Arithmetic: alpha evaluation is shared with the backward (blend_common.h) so both make identical
 // keep/skip decisions.
 #include "egs_common.h"
