@@ -90,10 +90,12 @@ def main():
         gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
         del tpc
     pc = SynthGaussians(student, device=dev, fused=not args.torch_host_ops)
-    opt = torch.optim.Adam([                                    # /root/reference/scene/gaussian_model.py:180-198 defaults
+    from egogaussian_amd.optim import FusedAdam
+    Adam = (lambda g, **kw: torch.optim.Adam(g, fused=True, **kw)) if args.torch_host_ops else FusedAdam
+    opt = Adam([                                                # /root/reference/scene/gaussian_model.py:180-198 defaults
         {"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3},
         {"params": [pc._opacity], "lr": 0.05}, {"params": [pc._scaling], "lr": 5e-3},
-        {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15, fused=True)
+        {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15)
 
     def eval_psnr():
         with torch.no_grad():
@@ -202,7 +204,7 @@ def main():
         "config": {"workload": f"S({N},{H},{W},seed0) teacher/student, 300-frame orbit, 1 frame per GPU per step; step = "
                                + ("rasterizer fwd+bwd only (seeded upstream grads on colour/depth/alpha)" if args.op_only else
                                   ("cov3D(torch) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) (torch) + bwd + Adam" if args.torch_host_ops else
-                                   "cov3D (HIP) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) (HIP) + bwd (HIP+autograd) + Adam")),
+                                   "cov3D (HIP) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) (HIP) + bwd (HIP+autograd) + Adam (HIP)")),
                    "gaussians": N, "image": [H, W], "sh_degree": 0, "instances_R": int(R_mean), "sort_passes": passes,
                    "parallelism": f"frames sharded over {world} GPU(s), scalar all-reduce only"},
         "psnr_db": round(psnr_e, 3), "psnr_db_before": round(psnr_s, 3), "mean_loss": round(mean_loss, 6),

@@ -1,0 +1,58 @@
+"""FusedAdam: torch.optim.Adam semantics with every parameter of every group stepped by ONE HIP kernel.
+
+Drop-in for the optimizer the reference builds in GaussianModel.training_setup
+(/root/reference/scene/gaussian_model.py:180-198: `torch.optim.Adam(l, lr=0.0, eps=1e-15)` with one named group per
+parameter).  The per-parameter state uses torch's own keys ("step", "exp_avg", "exp_avg_sq"), so the reference's
+densification code, which rewrites optimizer.state entries directly (gaussian_model.py:506-560), keeps working.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.load()
+        by_cfg = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or p.grad.is_sparse:
+                    raise RuntimeError("FusedAdam: dense float32 parameters on a HIP device only")
+                st = self.state[p]
+                if len(st) == 0 or "exp_avg" not in st:
+                    st["step"] = torch.zeros((), dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if "step" not in st:
+                    st["step"] = torch.zeros((), dtype=torch.float32)
+                st["step"] = st["step"] + 1 if torch.is_tensor(st["step"]) else st["step"] + 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if not (p.is_contiguous() and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
+                    raise RuntimeError("FusedAdam: parameters and optimizer state must be contiguous")
+                key = (p.device, group["betas"], group["eps"])
+                by_cfg.setdefault(key, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), int(st["step"])))
+        for (dev, betas, eps), items in by_cfg.items():
+            n = len(items)
+            PP = (C.c_void_p * n)(*[t[0].data_ptr() for t in items])
+            GG = (C.c_void_p * n)(*[t[1].data_ptr() for t in items])
+            MM = (C.c_void_p * n)(*[t[2].data_ptr() for t in items])
+            VV = (C.c_void_p * n)(*[t[3].data_ptr() for t in items])
+            NN = (C.c_int64 * n)(*[t[0].numel() for t in items])
+            LR = (C.c_float * n)(*[t[4] for t in items])
+            ST = (C.c_int64 * n)(*[t[5] for t in items])
+            with torch.cuda.device(dev):
+                _lib.check(L.egs_adam_step(n, PP, GG, MM, VV, NN, LR, ST, float(betas[0]), float(betas[1]), float(eps),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return loss

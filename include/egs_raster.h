@@ -183,6 +183,14 @@ int egs_l1_ssim_backward(int channels, int height, int width, const float* img, 
                          const float* dm_dmu1, const float* dm_dexx, const float* dm_dexy, float* dL_dimg /*[C,H,W] out*/,
                          void* stream);
 
+/* ---- f-4 (optimizer part): multi-tensor Adam step in one launch.  Same update as torch.optim.Adam(weight_decay=0,
+ *      amsgrad=False), which the reference builds at /root/reference/scene/gaussian_model.py:198 and steps at
+ *      /root/reference/trainers/train_static.py:137.  All array arguments are HOST arrays of length n_tensors holding
+ *      device pointers / sizes / per-tensor learning rate and 1-based step count. */
+int egs_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                  float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
+                  float beta1, float beta2, float eps, void* stream);
+
 /* Test hook: the per-tile sort ranks keys with an LDS atomic whose lane-order behaviour is verified on the device once per
  * process; on != 0 forces the ballot-based fallback so that tests can cover it.  Returns the previous setting. */
 int egs_debug_force_ballot_rank(int on);

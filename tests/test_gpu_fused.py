@@ -90,3 +90,39 @@ def test_fused_loss_matches_reference_fixture():
     assert _close(-a.grad, g["ssim_grad_a"], 1e-3)
     l1_only = l1_ssim_loss(a.detach(), b, 0.0)
     assert abs(l1_only.item() - float(g["l1"])) < 1e-6
+
+
+def test_fused_adam_matches_torch_adam():
+    from egogaussian_amd.optim import FusedAdam
+    gen = torch.Generator().manual_seed(0)
+    shapes = [(5000, 3), (5000, 1, 3), (5000, 1), (5000, 3), (5000, 4), (7,), (1025,)]
+    lrs = [1.6e-4, 2.5e-3, 0.05, 5e-3, 1e-3, 0.1, 0.01]
+    pa = [torch.randn(s, generator=gen).to(DEV).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = FusedAdam([{"params": [p], "lr": lr, "name": f"g{i}"} for i, (p, lr) in enumerate(zip(pa, lrs))], lr=0.0, eps=1e-15)
+    ob = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(pb, lrs)], lr=0.0, eps=1e-15)
+    for it in range(12):
+        for p, q in zip(pa, pb):
+            g = torch.randn(p.shape, generator=gen).to(DEV) * (10.0 ** (it % 4 - 2))
+            p.grad = g.clone(); q.grad = g.clone()
+        oa.step(); ob.step()
+    for p, q in zip(pa, pb):
+        assert _close(p, q, 2e-6, 1e-7)
+    st = oa.state[pa[0]]
+    assert set(st) >= {"step", "exp_avg", "exp_avg_sq"} and _close(st["exp_avg"], ob.state[pb[0]]["exp_avg"], 1e-5, 1e-9)
+    # state surgery as the reference's densification does it: replace the tensors, keep stepping
+    keep = torch.arange(0, 5000, 2, device=DEV)
+    for opt, params in ((oa, pa), (ob, pb)):
+        g0 = opt.param_groups[0]
+        old = g0["params"][0]
+        stored = opt.state.pop(old)
+        stored["exp_avg"] = stored["exp_avg"][keep].contiguous(); stored["exp_avg_sq"] = stored["exp_avg_sq"][keep].contiguous()
+        new = torch.nn.Parameter(old.detach()[keep].contiguous())
+        g0["params"][0] = new
+        opt.state[new] = stored
+        params[0] = new
+    for p, q in zip(pa, pb):
+        g = torch.randn(p.shape, generator=gen).to(DEV)
+        p.grad = g.clone(); q.grad = g.clone()
+    oa.step(); ob.step()
+    assert _close(pa[0], pb[0], 2e-6, 1e-7)
