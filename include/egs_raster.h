@@ -191,6 +191,11 @@ int egs_adam_step(int n_tensors, float* const* params, const float* const* grads
                   float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
                   float beta1, float beta2, float eps, void* stream);
 
+/* ---- f-2: mean squared distance of every point to its 3 nearest neighbours (self excluded by index).
+ *      Replaces simple_knn._C.distCUDA2 (un-vendored submodule, /root/reference/.gitmodules:4-6), imported at
+ *      /root/reference/scene/gaussian_model.py:21 and called at :301.  Exact (all pairs). */
+int egs_knn3_mean_dist2(int N, const float* points /*[N,3]*/, float* mean_dist2 /*[N] out*/, void* stream);
+
 /* Test hook: the per-tile sort ranks keys with an LDS atomic whose lane-order behaviour is verified on the device once per
  * process; on != 0 forces the ballot-based fallback so that tests can cover it.  Returns the previous setting. */
 int egs_debug_force_ballot_rank(int on);

@@ -126,3 +126,25 @@ def test_fused_adam_matches_torch_adam():
         p.grad = g.clone(); q.grad = g.clone()
     oa.step(); ob.step()
     assert _close(pa[0], pb[0], 2e-6, 1e-7)
+
+
+@pytest.mark.parametrize("N", [5, 1000, 20000])
+def test_knn_mean_dist2_matches_kdtree(N):
+    """distCUDA2 replacement against scipy's exact k-d tree (k = 4 including the point itself)."""
+    from scipy.spatial import cKDTree
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(N)
+    pts = rng.normal(size=(N, 3)).astype(np.float32)
+    pts[N // 2] = pts[0]                                     # an exact duplicate: neighbour at distance 0
+    got = distCUDA2(torch.tensor(pts, device=DEV)).cpu().numpy()
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    want = (d[:, 1:] ** 2).mean(1)
+    assert np.abs(got - want).max() <= 1e-5 * want.max() + 1e-7
+    assert got[0] < want.mean() and np.isfinite(got).all()
+
+
+def test_knn_fewer_than_four_points():
+    from simple_knn._C import distCUDA2
+    out = distCUDA2(torch.tensor([[0.0, 0, 0], [1.0, 0, 0]], device=DEV))
+    assert torch.isinf(out).all()                            # fewer than 3 neighbours: FLT_MAX slots overflow, as upstream
+    assert distCUDA2(torch.zeros((0, 3), device=DEV)).numel() == 0
