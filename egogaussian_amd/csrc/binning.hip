@@ -117,13 +117,22 @@ __global__ __launch_bounds__(EGS_SCAN_THREADS) void k_scan_apply(const uint32_t*
 // mapped back to its Gaussian by a 6-step search over the per-lane exclusive offsets, so lanes do equal work however
 // uneven the rectangles are.  `body(tile, gaussian_index, depth_bits)` runs once per instance.
 // ---------------------------------------------------------------------------------------------
+// Workgroup b runs on XCD b % 8 (observed, used for speed only).  The bucketed array interleaves, inside every tile's
+// region, the slices of consecutive table columns; giving each XCD a contiguous run of columns lets its private L2
+// merge the 8-byte stores of neighbouring slices into full lines before they leave for HBM.
+__device__ __forceinline__ unsigned bin_logical_block(unsigned nblocks) {
+    const unsigned per = (nblocks + 7) / 8;
+    const unsigned l = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    return l;                                                       // >= nblocks for the padding blocks of the grid
+}
+
 template <typename Body>
-__device__ __forceinline__ void for_each_instance(int P, const uint32_t* __restrict__ tiles_touched,
+__device__ __forceinline__ void for_each_instance(unsigned bid, int P, const uint32_t* __restrict__ tiles_touched,
                                                   const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
                                                   bool need_depth, Body body) {
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int per_wave = EGS_BIN_GPB / (EGS_BIN_THREADS / 64);
-    const int first = blockIdx.x * EGS_BIN_GPB + (int)w * per_wave;
+    const int first = (int)bid * EGS_BIN_GPB + (int)w * per_wave;
     for (int g0 = first; g0 < first + per_wave && g0 < P; g0 += 64) {
         const int i = g0 + (int)lane;
         const bool have = i < P;
@@ -162,23 +171,27 @@ extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
 __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, const uint32_t* __restrict__ tiles_touched,
                                                     const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
                                                     int n_tiles, uint32_t nblocks, uint32_t* __restrict__ table) {
+    const unsigned bid = bin_logical_block(nblocks);
+    if (bid >= nblocks) return;
     uint32_t* hist = dyn_lds;
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) hist[t] = 0;
     __syncthreads();
-    for_each_instance(P, tiles_touched, rect, rec, gx, false,
+    for_each_instance(bid, P, tiles_touched, rect, rec, gx, false,
                       [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); });
     __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) table[(size_t)t * nblocks + blockIdx.x] = hist[t];   // tile-major
+    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) table[(size_t)t * nblocks + bid] = hist[t];   // tile-major
 }
 
 __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, const uint32_t* __restrict__ tiles_touched,
                                                       const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
                                                       int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
                                                       uint32_t cap, uint64_t* __restrict__ pairs) {
+    const unsigned bid = bin_logical_block(nblocks);
+    if (bid >= nblocks) return;
     uint32_t* cursor = dyn_lds;
-    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) cursor[t] = table_scanned[(size_t)t * nblocks + blockIdx.x];
+    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) cursor[t] = table_scanned[(size_t)t * nblocks + bid];
     __syncthreads();
-    for_each_instance(P, tiles_touched, rect, rec, gx, true, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
+    for_each_instance(bid, P, tiles_touched, rect, rec, gx, true, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
         const uint32_t pos = atomicAdd(&cursor[tile], 1u);
         if (pos < cap) pairs[pos] = ((uint64_t)dbits << 32) | idx;      // cap < R only in a speculative launch that will be redone
     });
@@ -419,11 +432,11 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
         if (e != hipSuccess) return e;
     }
     egs_prof_start(EGS_K_DUPLICATE, s);
-    hipLaunchKernelGGL(k_bin_count, dim3(nblocks), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, b.table);
+    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, b.table);
     EGS_DBG(s);
     hipError_t e = egs_launch_scan_u32(b.table, b.table, (size_t)n_tiles * nblocks, 0, b.spine, b.total, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nblocks), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
+    hipLaunchKernelGGL(k_bin_scatter, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
                        b.table, R, b.pairs);
     egs_prof_stop(EGS_K_DUPLICATE, s);
     EGS_DBG(s);
