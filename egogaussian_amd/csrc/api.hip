@@ -43,6 +43,8 @@ ImgLayout img_layout(int W, int H) {
     L.o.ranges = off;    off = egs_align(off + gx * gy * sizeof(uint2));
     L.o.final_T = off;   off = egs_align(off + px * sizeof(float));
     L.o.n_contrib = off; off = egs_align(off + px * sizeof(uint32_t));
+    L.o.quad_work = off; off = egs_align(off + gx * gy * 4 * sizeof(uint32_t));
+    L.o.tile_order = off; off = egs_align(off + ((gx * gy + 7) / 8) * 8 * sizeof(uint32_t));
     L.bytes = off; return L;
 }
 EgsGeomPtrs geom_ptrs(void* buf, int P) {
@@ -61,7 +63,8 @@ EgsBinPtrs bin_ptrs(void* buf, int P, int64_t R, int W, int H) {
 EgsImgPtrs img_ptrs(void* buf, int W, int H) {
     const ImgLayout L = img_layout(W, H); char* b = (char*)buf; EgsImgPtrs p;
     p.ranges = (uint2*)(b + L.o.ranges); p.final_T = (float*)(b + L.o.final_T);
-    p.n_contrib = (uint32_t*)(b + L.o.n_contrib); return p;
+    p.n_contrib = (uint32_t*)(b + L.o.n_contrib); p.quad_work = (uint32_t*)(b + L.o.quad_work);
+    p.tile_order = (uint32_t*)(b + L.o.tile_order); return p;
 }
 
 int check_dims(int P, int W, int H) {

@@ -37,13 +37,21 @@ struct EgsBinPtrs {
     uint32_t* spine;        // scan scratch
     uint64_t* total;        // [1] number of instances found by the scan (== R)
 };
-struct EgsImgPtrs { uint2* ranges; float* final_T; uint32_t* n_contrib; };
+struct EgsImgPtrs { uint2* ranges; float* final_T; uint32_t* n_contrib; uint32_t* quad_work; uint32_t* tile_order; };
 
 static inline size_t egs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // binning geometry (binning.hip)
+#ifdef EGS_BIN_GPB_OVERRIDE
+#define EGS_BIN_GPB EGS_BIN_GPB_OVERRIDE
+#else
 #define EGS_BIN_GPB 1024                                       // Gaussians per bucketing workgroup
+#endif
+#ifdef EGS_BIN_THREADS_OVERRIDE
+#define EGS_BIN_THREADS EGS_BIN_THREADS_OVERRIDE
+#else
 #define EGS_BIN_THREADS 1024                                   // 16 waves, 64 Gaussians each
+#endif
 #define EGS_MAX_TILES 36864                                    // one 4-byte LDS counter per tile must fit in 160 KiB
 uint32_t egs_bin_blocks(int P);
 #define EGS_SCAN_THREADS 256

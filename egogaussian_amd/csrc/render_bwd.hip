@@ -44,13 +44,47 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
+// Work-aware placement of tiles for the backward blend.  All workgroups of that launch are resident at once (8 per CU),
+// so its duration is the busiest CU's total; with tiles dealt in index order the busiest CU carries 1.2-1.3x the mean.
+// Workgroup b runs on XCD b % 8 and, inside the XCD, on CU (b / 8) % 32 (tools/ubench/dispatch_map.hip; used for speed
+// only -- any placement gives the same results).  One workgroup per XCD band ranks the band's tiles by the replay depth
+// the forward recorded and deals them to the 32 CUs in snake order (rank r -> round r/32, CU r%32 or 31 - r%32).
+#define ORDER_MAX_BAND 2048
+__global__ __launch_bounds__(1024) void k_order_tiles(int n_tiles, const uint32_t* __restrict__ quad_work,
+                                                       uint32_t* __restrict__ tile_order) {
+    __shared__ uint32_t work[ORDER_MAX_BAND];
+    const int per = egs_tiles_per_xcd(n_tiles), x = blockIdx.x;
+    const int t0 = x * per, n = max(0, min(per, n_tiles - t0));
+    const int slots = ((per + 31) / 32) * 32;
+    if (per > ORDER_MAX_BAND) {                                      // very large images: keep index order
+        for (int sl = threadIdx.x; sl < per; sl += blockDim.x) tile_order[8 * sl + x] = sl < n ? (uint32_t)(t0 + sl) : 0xffffffffu;
+        return;
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint4 w4 = *reinterpret_cast<const uint4*>(quad_work + 4 * (size_t)(t0 + i));
+        work[i] = w4.x + w4.y + w4.z + w4.w;
+    }
+    for (int sl = threadIdx.x; sl < per; sl += blockDim.x) tile_order[8 * sl + x] = 0xffffffffu;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t wi = work[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) { const uint32_t wj = work[j]; rank += (wj > wi) || (wj == wi && j < i); }
+        const int round = rank / 32, pos = rank % 32;
+        int slot = round * 32 + ((round & 1) ? 31 - pos : pos);
+        if (slot >= per) slot = round * 32 + pos;                    // last, partial round: no room to mirror
+        if (slot >= per) slot = per - 1 - (slots - 1 - slot);        // (cannot happen when per is a multiple of 32)
+        tile_order[8 * slot + x] = (uint32_t)(t0 + i);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_render_backward(
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-    const float* __restrict__ dL_dalpha, float* __restrict__ grad_acc) {
+    const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ tile_order, float* __restrict__ grad_acc) {
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
-    const int tile = egs_tile_of_block(blockIdx.x, n_tiles);
+    const int tile = (int)tile_order[blockIdx.x];                   // 0xffffffff = padding workgroup
     if (tile < 0) return;
     const unsigned lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     float4* my = lds[q];
@@ -174,8 +208,9 @@ hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
     if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_order_tiles, dim3(EGS_XCDS), dim3(1024), 0, s, n_tiles, im.quad_work, im.tile_order);
     hipLaunchKernelGGL(k_render_backward, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                        im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
-                       grad_acc);
+                       im.tile_order, grad_acc);
     return hipGetLastError();
 }

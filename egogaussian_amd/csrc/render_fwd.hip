@@ -32,14 +32,14 @@ __global__ __launch_bounds__(256) void k_render_forward(
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib) {
+    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ quad_work) {
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
     const int tile = egs_tile_of_block(blockIdx.x, n_tiles);
     if (tile < 0) return;
     const unsigned lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     float4* my = lds[q];
     const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
-    if (qx0 >= W || qy0 >= H) return;                             // quadrant entirely outside the image
+    if (qx0 >= W || qy0 >= H) { if (lane == 0) quad_work[tile * 4 + q] = 0; return; }   // quadrant entirely outside the image
     const int px = qx0 + (int)(lane & 7), py = qy0 + (int)(lane >> 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
@@ -92,6 +92,12 @@ __global__ __launch_bounds__(256) void k_render_forward(
         __builtin_amdgcn_wave_barrier();
     }
     const float T = Tf;
+    {   // replay depth of this quadrant = work of its wave in the backward (used to balance that launch)
+        uint32_t wmax = last;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
+        if (lane == 0) quad_work[tile * 4 + q] = wmax;
+    }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         final_T[pix] = T; n_contrib[pix] = last;
@@ -110,6 +116,6 @@ hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs 
     const int n_tiles = gx * gy;
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_render_forward, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
-                       im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib);
+                       im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, im.quad_work);
     return hipGetLastError();
 }

@@ -24,7 +24,7 @@ class BinningLayout(C.Structure):
 
 
 class ImageLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("ranges", "final_T", "n_contrib")]
+    _fields_ = [(n, C.c_size_t) for n in ("ranges", "final_T", "n_contrib", "quad_work", "tile_order")]
 
 
 # name -> (restype, argtypes); every symbol include/egs_raster.h declares
