@@ -9,11 +9,16 @@
 //   * the colour / depth / alpha channels share ONE running accumulator: with u_j = c_j . dL/dC + d_j dL/dD
 //     + dL/dA the published per-channel recurrences collapse to U <- a_last u_last + (1 - a_last) U and
 //     dL/dalpha_j = T_j (u_j - U_j) - T_final/(1-a_j) bg . dL/dC   (algebraically identical);
-//   * the 10 per-splat partial sums (mean2D.xy, conic xx/xy/yy, opacity, rgb, depth) are reduced across the
-//     64 lanes with gfx950's v_permlane32_swap / v_permlane16_swap "transpose-and-add" (5+3 instructions
-//     fold ten registers into three) followed by four DPP row steps on those three -- 29 VALU instead of 60
-//     for ten independent butterflies -- and land in ten different lanes, which issue ONE global_atomic_add_f32
-//     instruction into the Gaussian's 48-byte accumulator line (egs_common.h) instead of ten.
+//   * the 10 per-splat partial sums (five moments of kG, opacity, rgb, depth) are reduced across the 64 lanes in three
+//     stages priced with tools/ubench/xlane_rate.hip (cycles per SIMD at 8 waves: plain VALU 2.4, DPP add 6.8,
+//     v_permlane{16,32}_swap 11.5, v_readlane 8, ds_bpermute 22):
+//       1. v_permlane32_swap "transpose-and-add" folds the ten registers into five (lanes 0-31: even value, 32-63: odd);
+//       2. the five registers go through a wave-private 1.25 KiB LDS slice (5 ds_write_b32), and lane 4v+g reads eight
+//          consecutive partials of value v (2 ds_read_b128) and adds them -- the LDS pipe is otherwise nearly idle here;
+//       3. two quad_perm DPP adds finish the sum in lanes 0, 4, ..., 36,
+//     about 100 VALU-cycles instead of 196 for swaps + DPP rows alone (and 408 for ten DPP butterflies);
+//   * those ten lanes issue ONE global_atomic_add_f32 instruction into the Gaussian's 48-byte accumulator line
+//     (egs_common.h) instead of ten.
 #include "egs_common.h"
 #include "blend_common.h"
 
@@ -84,10 +89,12 @@ __global__ __launch_bounds__(256) void k_render_backward(
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ tile_order, float* __restrict__ grad_acc) {
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
+    __shared__ __attribute__((aligned(16))) float red[4][5 * 64];
     const int tile = (int)tile_order[blockIdx.x];                   // 0xffffffff = padding workgroup
     if (tile < 0) return;
     const unsigned lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     float4* my = lds[q];
+    float* myred = red[q];
     const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
     if (qx0 >= W || qy0 >= H) return;
     const int px = qx0 + (int)(lane & 7), py = qy0 + (int)(lane >> 3);
@@ -113,15 +120,11 @@ __global__ __launch_bounds__(256) void k_render_backward(
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
     if (wmax == 0) return;
 
-    // which of the ten reduced sums this lane publishes (see the fold order below), or -1
-    int slot = -1;
-    {
-        const unsigned r = lane >> 4, c = lane & 15;
-        if (c == 0) slot = r == 0 ? 0 : r == 1 ? 2 : r == 2 ? 1 : 3;
-        else if (c == 1) slot = r == 0 ? 4 : r == 1 ? 6 : r == 2 ? 5 : 7;
-        else if (c == 2 && (r & 1) == 0) slot = r == 0 ? 8 : 9;
-    }
-    const unsigned csel = lane & 15;
+    // stage 2/3 of the reduction: lane 4v+g (v < 10) sums partials [8g, 8g+8) of value v; lane 4v publishes it.
+    // After the permlane32 fold, value v lives in register row v/2, lanes (v%2)*32 .. +31.
+    const unsigned rv = lane >> 2, rg = lane & 3;
+    const float4* red_src = reinterpret_cast<const float4*>(myred + (rv < 10 ? (rv >> 1) * 64 + (rv & 1) * 32 + rg * 8 : 0));
+    const int slot = (rg == 0 && rv < 10) ? (int)rv : -1;
 
     float T = T_final, U = 0.f, last_u = 0.f, last_alpha = 0.f;
 
@@ -185,14 +188,13 @@ __global__ __launch_bounds__(256) void k_render_backward(
             const float v6 = w * g_r, v7 = w * g_g, v8 = w * g_b, v9 = w * g_d;
             (void)t; (void)m; (void)nn;
 
-            // 64-lane sums of v0..v9, ten results in ten lanes
-            const float s01 = fold32(v0, v1), s23 = fold32(v2, v3), s45 = fold32(v4, v5), s67 = fold32(v6, v7),
-                        s89 = fold32(v8, v9);
-            float t0 = fold16(s01, s23);       // rows: v0 v2 v1 v3
-            float t1 = fold16(s45, s67);       // rows: v4 v6 v5 v7
-            float t2 = fold16(s89, s89);       // rows: v8 v8 v9 v9
-            t0 = row_sum(t0); t1 = row_sum(t1); t2 = row_sum(t2);
-            const float out = csel == 0 ? t0 : csel == 1 ? t1 : t2;
+            // 64-lane sums of v0..v9 (see the header): swap-fold, LDS regroup, quad DPP
+            myred[0 * 64 + lane] = fold32(v0, v1); myred[1 * 64 + lane] = fold32(v2, v3); myred[2 * 64 + lane] = fold32(v4, v5);
+            myred[3 * 64 + lane] = fold32(v6, v7); myred[4 * 64 + lane] = fold32(v8, v9);
+            const float4 pa = red_src[0], pb = red_src[1];
+            float out = ((pa.x + pa.y) + (pa.z + pa.w)) + ((pb.x + pb.y) + (pb.z + pb.w));
+            out = dpp_add<0xB1>(out);       // quad_perm [1,0,3,2]
+            out = dpp_add<0x4E>(out);       // quad_perm [2,3,0,1]
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)my_id, j);
             if (slot >= 0) unsafeAtomicAdd(grad_acc + (size_t)gid * EGS_GRAD_STRIDE + slot, out);
         }
