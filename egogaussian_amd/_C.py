@@ -26,6 +26,22 @@ def binning_passes(P, W, H):
     return int(lay.index_passes) + 4
 
 
+def last_instance_count(device=None, P=None):
+    """R of the most recent forward on `device`, summed from the page-locked per-workgroup counts.  Only meaningful after
+    the stream has been synchronised; this is how a graph-replayed step is checked against its capacity."""
+    key = torch.cuda.current_device() if device is None else torch.device(device).index
+    pinned = _pinned_counts.get(key)
+    if pinned is None:
+        return 0
+    P = stats.get("P", 0) if P is None else P
+    return int(_lib.load().egs_sum_counts(int(P), C.c_void_p(pinned.data_ptr())))
+
+
+def set_capacity_hint(instances, device=None):
+    key = torch.cuda.current_device() if device is None else torch.device(device).index
+    _capacity_hint[key] = int(instances)
+
+
 def _ptr(t):
     return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
 
@@ -83,11 +99,25 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         if pinned is None or pinned.numel() < nb:
             pinned = _pinned_counts[key] = torch.empty((max(nb, 4096),), dtype=torch.int32, pin_memory=True)
         binning = torch.empty((L.egs_binning_bytes(P, cap, W, H),), device=dev, dtype=torch.uint8)
-        rc = L.egs_forward(P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
-                           float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
-                           _ptr(campos), _ptr(background), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
-                           _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img), _ptr(out_color), _ptr(out_depth),
-                           _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _stream(), int(bool(debug)))
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            # hipGraph capture of a whole training step (egogaussian_amd/graph.py): nothing may wait on the host, so the
+            # chain is enqueued against the capacity established by earlier eager calls and R is checked after replays.
+            if cap <= 0 or P == 0:
+                raise RuntimeError("rasterize_gaussians under graph capture needs a capacity from an earlier eager call")
+            _lib.check(L.egs_forward_enqueue(
+                P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier),
+                _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), _ptr(background), W, H,
+                float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
+                _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), _stream()))
+            R = C.c_int64(cap)                      # layout size; the true count is last_instance_count() after a sync
+            rc = 0
+        else:
+            rc = L.egs_forward(P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
+                               float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+                               _ptr(campos), _ptr(background), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                               _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img), _ptr(out_color), _ptr(out_depth),
+                               _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _stream(), int(bool(debug)))
         if rc == _lib.RETRY_LARGER:
             cap = int(R.value * 1.25) + 65536
             binning = torch.empty((L.egs_binning_bytes(P, cap, W, H),), device=dev, dtype=torch.uint8)
@@ -95,10 +125,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                       _ptr(out_depth), _ptr(out_alpha), _stream(), int(bool(debug)))
             stats["retries"] += 1
         _lib.check(rc)
-        if P:
+        if P and not capturing:
             _capacity_hint[key] = max(cap, 0) if R.value else _capacity_hint.get(key, 0)
         stats["capacity"] = cap
     stats["num_rendered"] = int(R.value)
+    stats["P"] = P
+    if cap > 0:                                     # device-side instance count of this forward (int64[1] view, for graph replays)
+        lay = _lib.BinningLayout()
+        L.egs_get_binning_layout(P, cap, W, H, C.byref(lay))
+        stats["total_view"] = binning[lay.total:lay.total + 8].view(torch.int64)
     return int(R.value), out_color, out_depth, out_alpha, radii, geom, binning, img
 
 

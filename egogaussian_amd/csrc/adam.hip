@@ -17,6 +17,7 @@ struct AdamArgs {
     float* p[ADAM_MAX_TENSORS]; const float* g[ADAM_MAX_TENSORS]; float* m[ADAM_MAX_TENSORS]; float* v[ADAM_MAX_TENSORS];
     long long numel[ADAM_MAX_TENSORS]; unsigned block_start[ADAM_MAX_TENSORS + 1];
     float step_size[ADAM_MAX_TENSORS], inv_bc2_sqrt[ADAM_MAX_TENSORS];
+    const float* step_dev[ADAM_MAX_TENSORS]; const float* lr_dev[ADAM_MAX_TENSORS];   // capturable variant: read on the device
     int n; float b1, b2, eps;
 };
 
@@ -33,7 +34,12 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     const long long base = (long long)(blockIdx.x - a.block_start[t]) * ADAM_EPB;
     const long long n = a.numel[t];
     float* __restrict__ p = a.p[t]; const float* __restrict__ g = a.g[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
-    const float ss = a.step_size[t], ib = a.inv_bc2_sqrt[t];
+    float ss = a.step_size[t], ib = a.inv_bc2_sqrt[t];
+    if (a.step_dev[t]) {                                             // wave-uniform: hipGraph replays see the current step / lr
+        const float st = a.step_dev[t][0];
+        ss = a.lr_dev[t][0] / (1.f - powf(a.b1, st));
+        ib = 1.f / sqrtf(1.f - powf(a.b2, st));
+    }
     const bool vec = (((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -57,24 +63,30 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
 
 }  // namespace
 
-extern "C" int egs_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
-                             float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
-                             float beta1, float beta2, float eps, void* stream) {
+static int adam_impl(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                     float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
+                     const float* const* step_dev, const float* const* lr_dev, float beta1, float beta2, float eps, void* stream) {
     if (n_tensors < 0) return EGS_ERR_ARG;
-    if (n_tensors && (!params || !grads || !exp_avg || !exp_avg_sq || !numels || !lrs || !steps)) return EGS_ERR_ARG;
+    const bool dev = step_dev != nullptr;
+    if (n_tensors && (!params || !grads || !exp_avg || !exp_avg_sq || !numels)) return EGS_ERR_ARG;
+    if (n_tensors && (dev ? !lr_dev : (!lrs || !steps))) return EGS_ERR_ARG;
     for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MAX_TENSORS) {
         AdamArgs a; a.n = 0; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
         unsigned blocks = 0;
         for (int t = t0; t < n_tensors && a.n < ADAM_MAX_TENSORS; t++) {
             if (numels[t] <= 0) continue;
-            if (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t] || steps[t] < 1) return EGS_ERR_ARG;
+            if (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t]) return EGS_ERR_ARG;
+            if (dev ? (!step_dev[t] || !lr_dev[t]) : steps[t] < 1) return EGS_ERR_ARG;
             const int k = a.n++;
+            a.step_dev[k] = dev ? step_dev[t] : nullptr; a.lr_dev[k] = dev ? lr_dev[t] : nullptr;
             a.p[k] = params[t]; a.g[k] = grads[t]; a.m[k] = exp_avg[t]; a.v[k] = exp_avg_sq[t]; a.numel[k] = numels[t];
             a.block_start[k] = blocks;
             blocks += (unsigned)((numels[t] + ADAM_EPB - 1) / ADAM_EPB);
-            const double bc1 = 1.0 - pow((double)beta1, (double)steps[t]), bc2 = 1.0 - pow((double)beta2, (double)steps[t]);
-            a.step_size[k] = (float)((double)lrs[t] / bc1);
-            a.inv_bc2_sqrt[k] = (float)(1.0 / sqrt(bc2));
+            if (!dev) {
+                const double bc1 = 1.0 - pow((double)beta1, (double)steps[t]), bc2 = 1.0 - pow((double)beta2, (double)steps[t]);
+                a.step_size[k] = (float)((double)lrs[t] / bc1);
+                a.inv_bc2_sqrt[k] = (float)(1.0 / sqrt(bc2));
+            } else { a.step_size[k] = 0.f; a.inv_bc2_sqrt[k] = 0.f; }
         }
         a.block_start[a.n] = blocks;
         if (blocks == 0) continue;
@@ -83,4 +95,19 @@ extern "C" int egs_adam_step(int n_tensors, float* const* params, const float* c
         if (e != hipSuccess) return (int)e;
     }
     return 0;
+}
+
+extern "C" int egs_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                             float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
+                             float beta1, float beta2, float eps, void* stream) {
+    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, lrs, steps, nullptr, nullptr, beta1, beta2, eps, stream);
+}
+
+// hipGraph-capturable variant: the 1-based step count and the learning rate of every tensor are read from device
+// scalars (float[1]) at run time, so a captured step keeps working while the host advances them between replays.
+extern "C" int egs_adam_step_capturable(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                                        float* const* exp_avg_sq, const int64_t* numels, const float* const* step_dev,
+                                        const float* const* lr_dev, float beta1, float beta2, float eps, void* stream) {
+    if (n_tensors && !step_dev) return EGS_ERR_ARG;
+    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, nullptr, nullptr, step_dev, lr_dev, beta1, beta2, eps, stream);
 }

@@ -35,6 +35,7 @@ BinLayout bin_layout(int P, int64_t R, int W, int H) {
     L.o.scratch = off;    off = egs_align(off + n * sizeof(uint64_t));
     L.o.table = off;      off = egs_align(off + (n ? tab : 0) * sizeof(uint32_t));
     L.o.spine = off;      off = egs_align(off + (n ? egs_scan_scratch_elems(tab) + 64 : 0) * sizeof(uint32_t));
+    L.o.total = L.o.spine + (egs_scan_scratch_elems(tab) + 32) * sizeof(uint32_t);
     L.bytes = off; return L;
 }
 ImgLayout img_layout(int W, int H) {
@@ -57,7 +58,7 @@ EgsBinPtrs bin_ptrs(void* buf, int P, int64_t R, int W, int H) {
     const BinLayout L = bin_layout(P, R, W, H); char* b = (char*)buf; EgsBinPtrs p;
     p.pairs = (uint64_t*)(b + L.o.pairs); p.scratch = (uint64_t*)(b + L.o.scratch);
     p.point_list = (uint32_t*)(b + L.o.point_list); p.table = (uint32_t*)(b + L.o.table); p.spine = (uint32_t*)(b + L.o.spine);
-    p.total = (uint64_t*)(p.spine + egs_scan_scratch_elems((size_t)((W + EGS_TILE - 1) / EGS_TILE) * ((H + EGS_TILE - 1) / EGS_TILE) * egs_bin_blocks(P > 0 ? P : 0)) + 32);
+    p.total = (uint64_t*)(b + L.o.total);
     return p;
 }
 EgsImgPtrs img_ptrs(void* buf, int W, int H) {
@@ -218,7 +219,7 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
 // the caller's capacity guess while the host waits only for the copy of the per-block instance counts.  The GPU never
 // idles on the host round trip.  If the guess was too small nothing valid was produced: the true R is returned and the
 // caller finishes with egs_forward_render on a buffer of the right size.
-int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* colors_precomp,
+static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* colors_precomp,
                 const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
                 const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
@@ -236,10 +237,11 @@ int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const
     if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !pinned_host_counts)
         return EGS_ERR_ARG;
     if (capacity > 0 && !binning_buffer) return EGS_ERR_ARG;
+    if (!wait_for_count && capacity <= 0) return EGS_ERR_ARG;
     rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp); if (rc) return rc;
     if (shs && (sh_degree < 0 || sh_degree > EGS_MAX_SH_DEGREE || sh_coeffs < (sh_degree + 1) * (sh_degree + 1))) return EGS_ERR_RANGE;
     static thread_local hipEvent_t ev = nullptr;
-    if (!ev) EGS_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (wait_for_count && !ev) EGS_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     EgsGeomPtrs g = geom_ptrs(geom_buffer, P);
     EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
     egs_prof_start(EGS_K_PREPROCESS, s);
@@ -248,7 +250,7 @@ int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const
     egs_prof_stop(EGS_K_PREPROCESS, s);
     const size_t nb = ((size_t)P + 255) / 256;
     EGS_TRY(hipMemcpyAsync(pinned_host_counts, g.scan_scratch, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    EGS_TRY(hipEventRecord(ev, s));
+    if (wait_for_count) EGS_TRY(hipEventRecord(ev, s));
     if (capacity > 0) {                                              // speculative: sized by the caller's guess
         EgsBinPtrs b = bin_ptrs(binning_buffer, P, capacity, width, height);
         EgsImgPtrs im = img_ptrs(image_buffer, width, height);
@@ -257,6 +259,7 @@ int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const
         EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, s));
         egs_prof_stop(EGS_K_RENDER_FWD, s);
     }
+    if (!wait_for_count) { *num_rendered = -1; return 0; }              // graph-capturable: no host wait at all
     EGS_TRY(hipEventSynchronize(ev));
     uint64_t R = 0;
     for (size_t k = 0; k < nb; k++) R += pinned_host_counts[k];
@@ -265,6 +268,42 @@ int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const
     if ((int64_t)R > capacity || capacity == 0) return EGS_RETRY_LARGER;       // caller: egs_forward_render with a buffer for R
     EGS_SYNC_IF_DEBUG(s);
     return 0;
+}
+
+int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
+                int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
+                float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, int64_t* num_rendered,
+                void* stream, int debug) {
+    return forward_impl(1, P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                        cov3D_precomp, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
+                        radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
+                        pinned_host_counts, num_rendered, stream, debug);
+}
+
+// Same chain with NO host wait: everything (including the copy of the instance counts into pinned_host_counts) is only
+// enqueued, so the call can be captured into a hipGraph.  The caller sums pinned_host_counts after it has synchronised
+// (egs_sum_counts) and must discard the frame if the sum exceeds `capacity`.
+int egs_forward_enqueue(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                        const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
+                        int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
+                        float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, void* stream) {
+    int64_t unused = 0;
+    return forward_impl(0, P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                        cov3D_precomp, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
+                        radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
+                        pinned_host_counts, &unused, stream, 0);
+}
+
+int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts) {
+    if (P <= 0 || !pinned_host_counts) return 0;
+    uint64_t R = 0;
+    for (size_t k = 0, nb = ((size_t)P + 255) / 256; k < nb; k++) R += pinned_host_counts[k];
+    return (int64_t)R;
 }
 
 int egs_forward_render(int P, int64_t R, const float* background, int width, int height, const void* geom_buffer,
@@ -311,7 +350,7 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
     EgsBinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), P, R, width, height);
     EgsImgPtrs im = img_ptrs(const_cast<void*>(image_buffer), width, height);
     float* grad_acc = (float*)scratch;
-    EGS_TRY(hipMemsetAsync(grad_acc, 0, (size_t)P * EGS_GRAD_STRIDE * sizeof(float), s));
+    EGS_TRY(egs_launch_zero_f4((float4*)grad_acc, (size_t)P * EGS_GRAD_STRIDE / 4, s));      // a kernel, not a memset node (see egs_launch_zero_f4)
     if (R > 0) {
         const uint32_t* point_list = b.point_list;
         egs_prof_start(EGS_K_RENDER_BWD, s);

@@ -398,7 +398,7 @@ size_t egs_scan_scratch_elems(size_t n) {
 
 hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int inclusive, uint32_t* scratch,
                                uint64_t* total, hipStream_t s) {
-    if (n == 0) { return total ? hipMemsetAsync(total, 0, sizeof(uint64_t), s) : hipSuccess; }
+    if (n == 0) { return total ? egs_launch_zero_u32((uint32_t*)total, 2, s) : hipSuccess; }
     if (n <= EGS_SCAN_EPB) {
         hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(EGS_SCAN_THREADS), 0, s, in, out, n, inclusive, total);
         return hipGetLastError();
@@ -421,7 +421,7 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
                               hipStream_t s, int debug) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
-    if (R64 == 0 || P == 0) return hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)n_tiles, s);
+    if (R64 == 0 || P == 0) return egs_launch_zero_u32((uint32_t*)im.ranges, 2 * (size_t)n_tiles, s);
     const uint32_t R = (uint32_t)R64;
     const uint32_t nblocks = egs_bin_blocks(P);
     const size_t lds = (size_t)n_tiles * sizeof(uint32_t);
@@ -446,7 +446,7 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     int fast = lds_rank_ok.load();
     if (fast < 0) {
         uint32_t* flag = b.spine;                                   // free at this point (the scan is done with it)
-        hipError_t e2 = hipMemsetAsync(flag, 0, sizeof(uint32_t), s);
+        hipError_t e2 = egs_launch_zero_u32(flag, 1, s);
         if (e2 != hipSuccess) return e2;
         hipLaunchKernelGGL(k_check_lds_atomic_order, dim3(64), dim3(256), 0, s, flag);
         uint32_t bad = 1;

@@ -155,7 +155,7 @@ int egs_cov3d_backward(int N, const float* scaling, float scale_modifier, const 
                        const uint8_t* selected, float row0_grad_mult, const float* dL_dcov6, float* dL_dscaling,
                        float* dL_drotation, float* dL_dM9, void* stream) {
     if (N < 0) return EGS_ERR_ARG;
-    if (dL_dM9) { hipError_t e = hipMemsetAsync(dL_dM9, 0, 9 * sizeof(float), (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
+    if (dL_dM9) { hipError_t e = egs_launch_zero_u32((uint32_t*)dL_dM9, 9, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     if (N == 0) return 0;
     if (!scaling || !rotation || !dL_dcov6 || !dL_dscaling || !dL_drotation) return EGS_ERR_ARG;
     hipLaunchKernelGGL(k_cov3d_backward, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling, scale_modifier,

@@ -90,6 +90,11 @@ hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
                                       const float* dL_dalpha, float* grad_acc, hipStream_t s);
 
+// Zero-fill by a kernel.  hipMemsetAsync is avoided inside the per-step chain: captured into a hipGraph it becomes a memset
+// node, and on ROCm 7.2 replays of the training-step graph intermittently saw stale accumulator contents with it.
+hipError_t egs_launch_zero_f4(float4* p, size_t n4, hipStream_t s);
+hipError_t egs_launch_zero_u32(uint32_t* p, size_t n, hipStream_t s);
+
 // optional stage timing (api.hip); no-ops unless egs_profile_begin() was called
 void egs_prof_start(int stage, hipStream_t s);
 void egs_prof_stop(int stage, hipStream_t s);

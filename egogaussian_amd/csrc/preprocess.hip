@@ -429,7 +429,30 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
     present[i] = t[2] > 0.2f ? 1 : 0;
 }
 
+__global__ __launch_bounds__(256) void k_zero_f4(float4* __restrict__ p, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 }  // namespace
+
+namespace {
+__global__ void k_zero_u32(uint32_t* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+}  // namespace
+hipError_t egs_launch_zero_u32(uint32_t* p, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_zero_u32, dim3(blocks), dim3(256), 0, s, p, n);
+    return hipGetLastError();
+}
+
+hipError_t egs_launch_zero_f4(float4* p, size_t n4, hipStream_t s) {
+    if (n4 == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_zero_f4, dim3(blocks), dim3(256), 0, s, p, n4);
+    return hipGetLastError();
+}
 
 hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
                                  const float* opac, const float* scales, float mod, const float* rots,

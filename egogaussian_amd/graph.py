@@ -1,0 +1,103 @@
+"""Whole-training-step hipGraph capture (PyTorch's torch.cuda.graph on ROCm = hipGraph).
+
+Once the kernels are fast the iteration of /root/reference/trainers/train_static.py:67-138 is bound by the host: ~60
+kernel launches, three Python autograd Functions and the optimizer cost ~0.75 ms of CPU per step against ~0.55 ms of GPU
+work at 500k Gaussians.  The step has static shapes (the data-dependent instance count is handled by the capacity-bounded
+`egs_forward_enqueue`, the optimizer by `FusedAdam(capturable=True)`), so it is captured ONCE -- covariance, render
+forward, loss, backward, Adam -- and replayed with one launch per iteration; per-iteration inputs (camera matrices and
+ground-truth image) are copied into static device tensors first.
+
+Validity: a replayed frame whose instance count exceeded the captured capacity is clipped, hence wrong.  The graph
+tracks the running maximum of R on the device (`max_instances()`); callers check it at their next synchronisation point
+(the reference synchronises every iteration anyway through `loss.item()`, trainers/train_static.py:112) and re-capture
+with a larger capacity if needed (`recapture()`).
+"""
+import torch
+
+from . import _C
+from .fused import l1_ssim_loss
+from .renderer import render
+from .scene_synth import Pipe
+
+
+class _StaticCamera:
+    """Camera whose tensors are fixed device buffers; `load(cam)` copies another camera of the same intrinsics in."""
+
+    def __init__(self, cam):
+        self.image_height, self.image_width, self.FoVx, self.FoVy = cam.image_height, cam.image_width, cam.FoVx, cam.FoVy
+        self.world_view_transform = cam.world_view_transform.clone()
+        self.full_proj_transform = cam.full_proj_transform.clone()
+        self.camera_center = cam.camera_center.clone()
+
+    def load(self, cam):
+        same = (cam.image_height, cam.image_width, cam.FoVx, cam.FoVy) == (self.image_height, self.image_width, self.FoVx, self.FoVy)
+        assert same, "a captured step is specific to one image size and field of view"
+        self.world_view_transform.copy_(cam.world_view_transform, non_blocking=True)
+        self.full_proj_transform.copy_(cam.full_proj_transform, non_blocking=True)
+        self.camera_center.copy_(cam.camera_center, non_blocking=True)
+
+
+class GraphedTrainStep:
+    def __init__(self, pc, optimizer, bg, lambda_dssim=0.2, pipe=Pipe, render_kwargs=None):
+        if not getattr(optimizer, "capturable", False):
+            raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True)")
+        self.pc, self.opt, self.bg, self.lam, self.pipe = pc, optimizer, bg, lambda_dssim, pipe
+        self.render_kwargs = render_kwargs or {}
+        self.graph = None
+        self._max_r = None
+
+    def _body(self):
+        out = render(self.cam, self.pc, self.pipe, self.bg, **self.render_kwargs)
+        if self._max_r is not None:                                  # running maximum of R over all replays, on the device
+            self._max_r.copy_(torch.maximum(self._max_r, _C.stats["total_view"].to(torch.float32).reshape(())))
+        loss = l1_ssim_loss(out["render"], self.gt, self.lam)
+        loss.backward()
+        self.opt.step()
+        return loss.detach(), out
+
+    def capture(self, cam, gt, warmup=3, capacity_margin=1.25):
+        """Runs `warmup` eager iterations on (cam, gt) -- they are real training steps -- then records (without executing) one
+        more into the graph."""
+        dev = gt.device
+        self.cam, self.gt = _StaticCamera(cam), gt.clone()
+        P = self.pc.get_xyz.shape[0]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):                          # eager: sets the capacity hint, allocator pools, lazy state
+                self.opt.zero_grad(set_to_none=True)
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.capacity = max(int(_C.stats["num_rendered"] * capacity_margin), _C.stats["capacity"])
+        _C.set_capacity_hint(self.capacity, dev)
+        self.P = P
+        self._max_r = torch.zeros((), dtype=torch.float32, device=dev)
+        self.opt.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, out = self._body()
+            self.image = out["render"].detach()
+            self.radii = out["radii"]
+            self.viewspace_grad = out["viewspace_points"].grad
+        torch.cuda.synchronize(dev)
+        return self
+
+    def __call__(self, cam, gt):
+        """One training iteration: copy inputs in, replay.  Returns the (device, static) loss tensor."""
+        self.cam.load(cam)
+        self.gt.copy_(gt, non_blocking=True)
+        self.graph.replay()
+        return self.loss
+
+    def last_instance_count(self):
+        """R of the most recent replay; call after synchronising.  R > capacity means that frame was clipped."""
+        return _C.last_instance_count(self.gt.device, self.P)
+
+    def max_instances(self):
+        """Largest R over every replay so far (reads a device scalar: synchronises)."""
+        return int(self._max_r.item())
+
+    def ok(self):
+        """True if no replayed frame exceeded the captured capacity (i.e. every one of them was rendered completely)."""
+        return self.max_instances() <= self.capacity

@@ -19,7 +19,7 @@ class GeomLayout(C.Structure):
 
 
 class BinningLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("point_list", "pairs", "scratch", "table", "spine")] + \
+    _fields_ = [(n, C.c_size_t) for n in ("point_list", "pairs", "scratch", "table", "spine", "total")] + \
                [(n, C.c_int) for n in ("bin_blocks", "key_bits", "index_passes")]
 
 
@@ -43,6 +43,9 @@ SIGNATURES = {
                                        i32, vp, vp, C.POINTER(i64), vp, i32]),
     "egs_forward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, i64,
                                vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp, i32]),
+    "egs_forward_enqueue": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp,
+                                       i64, vp, vp, vp, vp, vp, vp, vp]),
+    "egs_sum_counts": (C.c_int64, [i32, vp]),
     "egs_forward_render": (C.c_int, [i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, f32, f32,
                                vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
@@ -53,6 +56,7 @@ SIGNATURES = {
     "egs_l1_ssim_forward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_l1_ssim_backward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_adam_step": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
+    "egs_adam_step_capturable": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
     "egs_knn3_mean_dist2": (C.c_int, [i32, vp, vp, vp]),
     "egs_debug_force_ballot_rank": (C.c_int, [i32]),
     "egs_profile_begin": (C.c_int, [i32]),

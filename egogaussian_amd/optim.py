@@ -13,8 +13,55 @@ from . import lib as _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """capturable=True keeps the step count and every group's learning rate in device scalars that the kernel reads, so
+    `step()` can be captured into a hipGraph and replayed while `param_groups[i]["lr"]` keeps being edited on the host
+    (call `sync_lr()` before a replay to push the edits)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.capturable = capturable
+        self._lr_dev = {}
+
+    def sync_lr(self):
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                t = self._lr_dev.get((gi, id(p)))
+                if t is None:
+                    self._lr_dev[(gi, id(p))] = torch.full((1,), float(group["lr"]), device=p.device)
+                elif float(group["lr"]) != getattr(t, "_host_value", None):
+                    t.fill_(float(group["lr"]))
+                self._lr_dev[(gi, id(p))]._host_value = float(group["lr"])
+
+    @torch.no_grad()
+    def _step_capturable(self):
+        L = _lib.load()
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        by_cfg = {}
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if not (torch.is_tensor(st.get("step")) and st["step"].is_cuda):
+                    st["step"] = torch.full((1,), float(st.get("step", 0)), device=p.device)
+                st["step"].add_(1.0)
+                lr_t = self._lr_dev.get((gi, id(p)))
+                if lr_t is None:
+                    lr_t = self._lr_dev[(gi, id(p))] = torch.full((1,), float(group["lr"]), device=p.device)
+                    lr_t._host_value = float(group["lr"])
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                by_cfg.setdefault((p.device, group["betas"], group["eps"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"], st["step"], lr_t))
+        for (dev, betas, eps), items in by_cfg.items():
+            n = len(items)
+            arr = lambda k: (C.c_void_p * n)(*[t[k].data_ptr() for t in items])
+            NN = (C.c_int64 * n)(*[t[0].numel() for t in items])
+            with torch.cuda.device(dev):
+                _lib.check(L.egs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), NN, arr(4), arr(5), float(betas[0]),
+                                                      float(betas[1]), float(eps), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -22,6 +69,9 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self.capturable:
+            self._step_capturable()
+            return loss
         L = _lib.load()
         by_cfg = {}
         for group in self.param_groups:

@@ -82,6 +82,7 @@ typedef struct egs_binning_layout {
     size_t scratch;        /* uint64[R]  ping-pong space for buckets too large for the in-register sort */
     size_t table;          /* uint32[tiles][bin_blocks] per-(tile, block) counts, exclusive-scanned in place */
     size_t spine;          /* uint32[..] scan scratch */
+    size_t total;          /* uint64[1]  instance count found by the bucketing scan (== R; may exceed a speculative capacity) */
     int    bin_blocks;     /* workgroups of the bucketing kernels = ceil(P / 1024) */
     int    key_bits;       /* significant bits of the canonical (tile<<32 | depth) key: 32 + bits(tile count) */
     int    index_passes;   /* 8-bit radix passes spent on the Gaussian index inside the per-tile sort (+4 on depth) */
@@ -134,6 +135,20 @@ int egs_forward(
     int32_t* radii /*[P] out*/, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
     float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts /*HOST, page-locked*/,
     int64_t* num_rendered /*HOST out*/, void* stream, int debug);
+
+/* ---- the same chain with NO host wait, for hipGraph capture of a whole training step: everything, including the copy
+ *      of the per-workgroup instance counts into `pinned_host_counts`, is only enqueued (capacity must be > 0).  After
+ *      the caller has synchronised it reads R = egs_sum_counts(P, pinned_host_counts); a frame with R > capacity is
+ *      invalid (its kernels were clipped to the capacity) and must be redone with a larger buffer. */
+int egs_forward_enqueue(
+    int P, int sh_degree, int sh_coeffs,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos, const float* background,
+    int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
+    int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
+    float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, void* stream);
+int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts /*HOST*/);
 
 /* ---- backward  (upstream: render backward + computeCov2D backward + preprocess backward) ------- */
 int egs_backward(
@@ -192,6 +207,10 @@ int egs_l1_ssim_backward(int channels, int height, int width, const float* img, 
 int egs_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                   float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
                   float beta1, float beta2, float eps, void* stream);
+/* hipGraph-capturable variant: step count and learning rate of each tensor are device float[1] scalars read by the kernel. */
+int egs_adam_step_capturable(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                             float* const* exp_avg_sq, const int64_t* numels, const float* const* step_dev /*HOST array of device ptrs*/,
+                             const float* const* lr_dev /*HOST array of device ptrs*/, float beta1, float beta2, float eps, void* stream);
 
 /* ---- f-2: mean squared distance of every point to its 3 nearest neighbours (self excluded by index).
  *      Replaces simple_knn._C.distCUDA2 (un-vendored submodule, /root/reference/.gitmodules:4-6), imported at

@@ -148,3 +148,47 @@ def test_knn_fewer_than_four_points():
     out = distCUDA2(torch.tensor([[0.0, 0, 0], [1.0, 0, 0]], device=DEV))
     assert torch.isinf(out).all()                            # fewer than 3 neighbours: FLT_MAX slots overflow, as upstream
     assert distCUDA2(torch.zeros((0, 3), device=DEV)).numel() == 0
+
+
+def test_graphed_train_step_matches_eager():
+    """A hipGraph-captured training step (covariance, render, loss, backward, Adam) replayed K times leaves the parameters
+    where K eager steps leave them."""
+    import math
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.fused import l1_ssim_loss
+    from egogaussian_amd.optim import FusedAdam
+    from egogaussian_amd.graph import GraphedTrainStep
+    N, H, W, K = 20000, 96, 160, 6
+    teacher = make_scene(N, H, W, 0); teacher["log_scale"] += math.log(2.0)
+    student = perturb_student(teacher)
+    cams = [make_camera(k, H, W, device=DEV) for k in (0, 30, 60, 90)]
+    bg = torch.zeros(3, device=DEV)
+    with torch.no_grad():
+        tpc = SynthGaussians(teacher, device=DEV, requires_grad=False)
+        gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
+
+    def groups(pc):
+        return [{"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3}, {"params": [pc._opacity], "lr": 0.05},
+                {"params": [pc._scaling], "lr": 5e-3}, {"params": [pc._rotation], "lr": 1e-3}]
+    WARM = 3
+    # eager reference: WARM steps on frame 0 (what capture() runs eagerly; the capture pass itself only records), then K steps
+    pa = SynthGaussians(student, device=DEV)
+    oa = FusedAdam(groups(pa), lr=0.0, eps=1e-15)
+    seq = [0] * WARM + [k % 4 for k in range(1, K + 1)]
+    for k in seq:
+        out = render(cams[k], pa, Pipe, bg)
+        l1_ssim_loss(out["render"], gts[k], 0.2).backward()
+        oa.step(); oa.zero_grad(set_to_none=True)
+    pb = SynthGaussians(student, device=DEV)
+    ob = FusedAdam(groups(pb), lr=0.0, eps=1e-15, capturable=True)
+    step = GraphedTrainStep(pb, ob, bg).capture(cams[0], gts[0], warmup=WARM)
+    losses = []
+    for k in range(1, K + 1):
+        losses.append(step(cams[k % 4], gts[k % 4]).clone())
+    torch.cuda.synchronize()
+    assert step.ok() and 0 < step.last_instance_count() <= step.capacity
+    assert all(torch.isfinite(l) for l in losses) and float(losses[-1]) < float(losses[0]) * 1.5
+    for a, b in zip(pa.parameters(), pb.parameters()):
+        if a.numel():
+            assert _close(b, a, 5e-4, 1e-6), "graph-replayed parameters drifted from the eager ones"
