@@ -67,9 +67,11 @@ def main():
     rank, world, local_rank = egs_dist.env_world()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
+    if os.environ.get("EGS_BENCH_SHARE_DEVICE0"):               # test hook: several ranks on one GPU (RCCL refuses that; use gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    egs_dist.init("nccl", dev)                                 # "nccl" is RCCL on ROCm
+    egs_dist.init(os.environ.get("EGS_BENCH_BACKEND", "nccl"), dev)        # "nccl" is RCCL on ROCm
 
     from egogaussian_amd import lib as egs_lib, _C
     from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe, N_FRAMES

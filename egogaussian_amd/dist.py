@@ -34,6 +34,8 @@ def shard_frames(n_frames, rank, world):
 
 def reduce_scalars(values, device="cpu", op="sum"):
     """All-reduce a short list of python floats; returns python floats.  Identity when not distributed."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op])
