@@ -20,7 +20,8 @@ _pinned_counts = {}                # device index -> page-locked host buffer for
 
 
 def binning_passes(P, W, H):
-    """8-bit radix passes of the per-tile (depth, index) sort for P Gaussians."""
+    """Upper bound on the 9-bit radix passes of the per-tile (depth, index) sort for P Gaussians (a tile runs
+    ceil(bits(depth range) / 9) depth passes, and the index passes only if two of its entries share a depth)."""
     lay = _lib.BinningLayout()
     _lib.check(_lib.load().egs_get_binning_layout(int(P), 0, int(W), int(H), C.byref(lay)))
     return int(lay.index_passes) + 4
@@ -161,8 +162,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dmeans2D, dcolors, dopacity, dmeans3D, dcov3D = e(P, 3), e(P, 3), e(P, 1), e(P, 3), e(P, 6)
         dsh = e(P, M, 3) if sh is not None else e(0, 0, 3)
         own_cov = cov3D_precomp is None
-        dscales = e(P, 3) if own_cov else torch.zeros((P, 3), device=dev)
-        drots = e(P, 4) if own_cov else torch.zeros((P, 4), device=dev)
+        dscales = e(P, 3) if own_cov else e(0, 3)          # absent inputs get empty gradients (the autograd Function maps them to None)
+        drots = e(P, 4) if own_cov else e(0, 4)
         if P != 0:
             scratch = torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
             _lib.check(L.egs_backward(

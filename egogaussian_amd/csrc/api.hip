@@ -29,7 +29,7 @@ BinLayout bin_layout(int P, int64_t R, int W, int H) {
     L.o.key_bits = egs_key_bits_for_tiles((int)(gx * gy));
     L.o.bin_blocks = (int)nblocks;
     int ib = 0; while (P > 1 && (((unsigned)(P - 1)) >> ib) != 0) ib++;
-    L.o.index_passes = (ib + 7) / 8;
+    L.o.index_passes = (ib + 8) / 9;
     L.o.point_list = off; off = egs_align(off + n * sizeof(uint32_t));          // first: the backward needs nothing else
     L.o.pairs = off;      off = egs_align(off + n * sizeof(uint64_t));
     L.o.scratch = off;    off = egs_align(off + n * sizeof(uint64_t));
@@ -350,12 +350,13 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
     EgsBinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), P, R, width, height);
     EgsImgPtrs im = img_ptrs(const_cast<void*>(image_buffer), width, height);
     float* grad_acc = (float*)scratch;
-    EGS_TRY(egs_launch_zero_f4((float4*)grad_acc, (size_t)P * EGS_GRAD_STRIDE / 4, s));      // a kernel, not a memset node (see egs_launch_zero_f4)
+    // the accumulator is cleared by a kernel, not a memset node (see egs_launch_zero_f4): fused into the blend's prologue
+    if (R == 0) EGS_TRY(egs_launch_zero_f4((float4*)grad_acc, (size_t)P * EGS_GRAD_STRIDE / 4, s));
     if (R > 0) {
         const uint32_t* point_list = b.point_list;
         egs_prof_start(EGS_K_RENDER_BWD, s);
         EGS_TRY(egs_launch_render_backward(width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth,
-                                           dL_dout_alpha, grad_acc, s));
+                                           dL_dout_alpha, grad_acc, (size_t)P * EGS_GRAD_STRIDE, s));
         egs_prof_stop(EGS_K_RENDER_BWD, s);
         EGS_SYNC_IF_DEBUG(s);
     }

@@ -111,6 +111,30 @@ __global__ __launch_bounds__(EGS_SCAN_THREADS) void k_scan_apply(const uint32_t*
     if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == EGS_SCAN_THREADS - 1) *total = run;
 }
 
+// Two-kernel scan for a short spine: every block adds up the raw sums of the blocks before it (L2-resident, at most
+// EGS_SCAN_SPINE_MAX words) instead of waiting for a third kernel to scan them.
+#define EGS_SCAN_SPINE_MAX 4096
+__global__ __launch_bounds__(EGS_SCAN_THREADS) void k_scan_apply_sum(const uint32_t* __restrict__ in,
+                                                                      uint32_t* __restrict__ out, size_t n, int inclusive,
+                                                                      const uint32_t* __restrict__ block_sums,
+                                                                      uint64_t* __restrict__ total) {
+    __shared__ uint32_t lds4[4];
+    uint32_t before = 0;
+    for (unsigned k = threadIdx.x; k < blockIdx.x; k += EGS_SCAN_THREADS) before += block_sums[k];
+    const size_t base = (size_t)blockIdx.x * EGS_SCAN_EPB + (size_t)threadIdx.x * EGS_SCAN_ITEMS;
+    uint32_t v[EGS_SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < EGS_SCAN_ITEMS; k++) { v[k] = base + k < n ? in[base + k] : 0u; s += v[k]; }
+    uint32_t carry; block_excl_scan(before, lds4, &carry);
+    uint32_t tot; uint32_t run = block_excl_scan(s, lds4, &tot) + carry;
+#pragma unroll
+    for (int k = 0; k < EGS_SCAN_ITEMS; k++) {
+        const uint32_t ex = run; run += v[k];
+        if (base + k < n) out[base + k] = inclusive ? run : ex;
+    }
+    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == EGS_SCAN_THREADS - 1) *total = run;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tile bucketing.  A workgroup (16 waves) owns EGS_BIN_GPB consecutive Gaussians, 64 per wave.  For
 // each group of 64 Gaussians the wave deals their instance slots to lanes: slot s of the group's contiguous span is
@@ -198,31 +222,62 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, const ui
 }
 
 // ---------------------------------------------------------------------------------------------
-// Per-tile sort of (depth<<32 | index) pairs.  LSD radix, 8-bit digits, only the digits that can differ:
-// ceil(index_bits / 8) low passes + the 4 depth bytes.  Stable ranking as in a global radix pass, but the whole
-// bucket belongs to one workgroup: wave w owns the contiguous quarter [w*chunk, (w+1)*chunk) in rounds of 64.
+// Per-tile sort of (depth<<32 | index) pairs.  LSD radix with 9-bit digits over only the bits that can differ:
+//   depth   the tile's smallest depth word is subtracted first (positive floats order like their bit patterns), so a
+//           tile whose depths span [zmin, zmax] needs ceil(bits(zmax - zmin) / 9) passes -- three for any range up to
+//           2^27 ulps, which covers every scene with z in [0.2, 1e3]; four only beyond that
+//   index   ceil(index_bits / 9) passes, run only when two entries of the tile share a depth (see below)
+// Stable ranking as in a global radix pass, but the whole bucket belongs to one workgroup: wave w owns the contiguous
+// quarter [w*chunk, (w+1)*chunk) in rounds of 64.
 // ---------------------------------------------------------------------------------------------
 #define TS_ITEMS 16
 #define TS_CAP (256 * TS_ITEMS)       // 4096 pairs held in registers, one 32 KiB LDS exchange buffer
+#define TS_DBITS 9
+#define TS_DIGITS (1 << TS_DBITS)
 
 __device__ __forceinline__ uint64_t digit_peers(uint32_t d, bool ok) {
     uint64_t peers = __ballot(ok);
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < TS_DBITS; b++) {
         const uint64_t m = __ballot((d >> b) & 1u);
         peers &= ((d >> b) & 1u) ? m : ~m;
     }
     return peers;
 }
 
-// After every wave has accumulated cnt[w][d] (count of digit d in wave w's quarter): turn them into exclusive
-// positions: cnt[w][d] <- (#keys with digit < d) + (#keys with digit d in waves < w).  256 threads, thread d.
-__device__ __forceinline__ void digit_bases(uint32_t (*cnt)[256], uint32_t* lds4) {
-    const unsigned d = threadIdx.x;
-    const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+// Digit `pass` of a pair: passes [0, index_passes) walk the index word, the rest walk (depth - dmin).
+__device__ __forceinline__ uint32_t ts_digit(uint64_t kv, int pass, int index_passes, uint32_t dmin) {
+    const uint32_t word = pass < index_passes ? (uint32_t)kv : (uint32_t)(kv >> 32) - dmin;
+    const int sh = TS_DBITS * (pass < index_passes ? pass : pass - index_passes);
+    return (word >> sh) & (TS_DIGITS - 1);
+}
+
+// Register path: a wave's quarter holds at most 1024 pairs, so two digit counters share one LDS word (16 bits each).
+// After every wave has accumulated its counts: turn them into exclusive positions
+//   pos[w][d] = (#keys with digit < d) + (#keys with digit d in waves < w).       256 threads, thread t owns digits 2t, 2t+1.
+__device__ __forceinline__ void digit_bases_packed(uint32_t (*cnt)[256], uint32_t* lds4) {
+    const unsigned t = threadIdx.x;
+    const uint32_t c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
+    const uint32_t s = c0 + c1 + c2 + c3;                               // halves add independently (each total <= 4096)
+    const uint32_t lo = s & 0xffffu, hi = s >> 16;
     uint32_t tot;
-    const uint32_t base = block_excl_scan(c0 + c1 + c2 + c3, lds4, &tot);
-    cnt[0][d] = base; cnt[1][d] = base + c0; cnt[2][d] = base + c0 + c1; cnt[3][d] = base + c0 + c1 + c2;
+    const uint32_t base = block_excl_scan(lo + hi, lds4, &tot);
+    const uint32_t b0 = base | ((base + lo) << 16);                     // wave 0: digit 2t starts at base, digit 2t+1 after all of 2t
+    cnt[0][t] = b0; cnt[1][t] = b0 + c0; cnt[2][t] = b0 + c0 + c1; cnt[3][t] = b0 + c0 + c1 + c2;
+    __syncthreads();
+}
+
+// Oversize path: full-width counters, thread t owns digits 2t and 2t+1.
+__device__ __forceinline__ void digit_bases_wide(uint32_t (*cnt)[TS_DIGITS], uint32_t* lds4) {
+    const unsigned t = threadIdx.x;
+    uint32_t a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { a[k] = cnt[k][2 * t]; b[k] = cnt[k][2 * t + 1]; }
+    const uint32_t sa = a[0] + a[1] + a[2] + a[3], sb = b[0] + b[1] + b[2] + b[3];
+    uint32_t tot;
+    uint32_t ba = block_excl_scan(sa + sb, lds4, &tot), bb = ba + sa;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { cnt[k][2 * t] = ba; cnt[k][2 * t + 1] = bb; ba += a[k]; bb += b[k]; }
     __syncthreads();
 }
 
@@ -232,31 +287,50 @@ __device__ __forceinline__ void digit_bases(uint32_t (*cnt)[256], uint32_t* lds4
 //                        (tools/ubench/lds_atomic_order.hip: 2.3e8 lane-operations, none out of order) but is not an
 //                        architectural promise -- egs_launch_binning verifies it on the device once per process
 //                        (k_check_lds_atomic_order) and otherwise uses
-//   RANK_ATOMIC = false  8 ballots build the "same digit" peer mask; all lanes read the counter, the lowest peer bumps it.
-template <bool RANK_ATOMIC>
+//   RANK_ATOMIC = false  ballots build the "same digit" peer mask; all lanes read the counter, the lowest peer bumps it.
+// `PACKED`: the counter of digit d is the 16-bit half (d & 1) of word d >> 1.
+template <bool RANK_ATOMIC, bool PACKED>
 __device__ __forceinline__ uint32_t wave_digit_rank(uint32_t* cnt_w, uint32_t d, bool ok, unsigned lane, uint64_t lt) {
-    if (RANK_ATOMIC) return ok ? atomicAdd(&cnt_w[d], 1u) : 0u;
+    uint32_t* word = PACKED ? cnt_w + (d >> 1) : cnt_w + d;
+    const uint32_t sh = PACKED ? 16u * (d & 1u) : 0u;
+    const uint32_t mask = PACKED ? 0xffffu : 0xffffffffu;
+    if (RANK_ATOMIC) return ok ? (atomicAdd(word, 1u << sh) >> sh) & mask : 0u;
     const uint64_t peers = digit_peers(d, ok);
-    const uint32_t start = cnt_w[d];
-    if (ok && lane == (unsigned)__ffsll((unsigned long long)peers) - 1u) cnt_w[d] = start + (uint32_t)__popcll(peers);
+    const uint32_t start = (*word >> sh) & mask;                        // every lane reads before any leader adds (in-order LDS)
+    if (ok && lane == (unsigned)__ffsll((unsigned long long)peers) - 1u) atomicAdd(word, (uint32_t)__popcll(peers) << sh);
     return start + (uint32_t)__popcll(peers & lt);
 }
 
 __global__ void k_check_lds_atomic_order(uint32_t* __restrict__ violations) {
-    __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t cnt[4][TS_DIGITS];
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t bad = 0, x = 2654435761u * (threadIdx.x + 1u);
     for (int t = 0; t < 64; t++) {
-        for (int i = lane; i < 256; i += 64) cnt[w][i] = 0;
+        for (int i = lane; i < TS_DIGITS; i += 64) cnt[w][i] = 0;
         __builtin_amdgcn_wave_barrier();
         x ^= x << 13; x ^= x >> 17; x ^= x << 5;
-        const uint32_t d = (x >> 8) % (t < 16 ? 2u : t < 32 ? 7u : t < 48 ? 37u : 256u);
+        const uint32_t d = (x >> 8) % (t < 16 ? 2u : t < 32 ? 7u : t < 48 ? 37u : (uint32_t)TS_DIGITS);
         const uint32_t r = atomicAdd(&cnt[w][d], 1u);
         const uint64_t peers = digit_peers(d, true);
         if (r != (uint32_t)__popcll(peers & lanemask_lt())) bad++;
         __builtin_amdgcn_wave_barrier();
     }
     if (bad) atomicAdd(violations, bad);
+}
+
+// min and max over the workgroup of one value per thread (both returned to every thread)
+__device__ __forceinline__ void block_min_max(uint32_t& mn, uint32_t& mx, uint32_t* lds8) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    }
+    const unsigned w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { lds8[w] = mn; lds8[4 + w] = mx; }
+    __syncthreads();
+    mn = min(min(lds8[0], lds8[1]), min(lds8[2], lds8[3]));
+    mx = max(max(lds8[4], lds8[5]), max(lds8[6], lds8[7]));
+    __syncthreads();
 }
 
 template <bool RANK_ATOMIC>
@@ -267,7 +341,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks
                                                     uint2* __restrict__ ranges) {
     __shared__ uint64_t xbuf[TS_CAP];
     __shared__ uint32_t cnt[4][256];
-    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t lds8[8];
     const int tile = blockIdx.x;
     const uint32_t beg = table_scanned[(size_t)tile * nblocks];
     const uint32_t end = tile + 1 < n_tiles ? table_scanned[(size_t)(tile + 1) * nblocks] : (uint32_t)*total;
@@ -278,28 +352,27 @@ __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks
     const uint64_t lt = lanemask_lt();
     const uint32_t chunk = ((n + 3) / 4 + 63) & ~63u;               // per-wave quarter, multiple of 64
     const uint32_t wbeg = w * chunk;
-    const int npass = index_passes + 4;
 
     if (n <= TS_CAP) {
         // ---- register path ----
-        // Depth ties inside a tile are rare, so the bucket is first sorted on the four depth bytes only; if two
-        // neighbours then share a depth the index bytes are sorted and the depth bytes redone (LSD order), which
+        // Depth ties inside a tile are rare, so the bucket is first sorted on the depth digits only; if two
+        // neighbours then share a depth the index digits are sorted and the depth digits redone (LSD order), which
         // restores the canonical (depth, index) order.  `phase` 0: depth only; 1: index then depth.
         uint64_t key[TS_ITEMS];
+        uint32_t dmin = 0xffffffffu, dmax = 0u;
 #pragma unroll
         for (int r = 0; r < TS_ITEMS; r++) {
             const uint32_t i = wbeg + r * 64 + lane;
-            key[r] = (r * 64u < chunk && i < n) ? pairs[beg + i] : ~0ull;
+            const bool ok = r * 64u < chunk && i < n;
+            key[r] = ok ? pairs[beg + i] : ~0ull;
+            if (ok) { const uint32_t dw = (uint32_t)(key[r] >> 32); dmin = min(dmin, dw); dmax = max(dmax, dw); }
         }
-#ifndef TS_MAXPASS
-#define TS_MAXPASS 99
-#endif
-        for (int phase = 0; phase < 2; phase++) {
-            const int first_pass = phase == 0 ? index_passes : 0;
-            for (int p = first_pass; p < npass && p < first_pass + TS_MAXPASS; p++) {
-                const int shift = p < index_passes ? 8 * p : 32 + 8 * (p - index_passes);
-#pragma unroll
-                for (int k = 0; k < 4; k++) cnt[k][threadIdx.x] = 0;
+        block_min_max(dmin, dmax, lds8);
+        const int depth_passes = (32 - __clz((int)(dmax - dmin)) + TS_DBITS - 1) / TS_DBITS;     // 0 when every depth is equal
+        const int npass = index_passes + depth_passes;
+        for (int phase = depth_passes ? 0 : 1; phase < 2; phase++) {
+            for (int p = phase == 0 ? index_passes : 0; p < npass; p++) {
+                cnt[0][threadIdx.x] = 0; cnt[1][threadIdx.x] = 0; cnt[2][threadIdx.x] = 0; cnt[3][threadIdx.x] = 0;
                 __syncthreads();
                 uint32_t rank[TS_ITEMS];
 #pragma unroll
@@ -307,18 +380,20 @@ __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks
                     rank[r] = 0;
                     if (r * 64u < chunk) {                              // wave-uniform
                         const uint32_t i = wbeg + r * 64 + lane;
-                        const bool ok = i < n;
                         // running count of this digit in the wave's quarter (LDS operations of one wave execute in
                         // order, so round r+1 sees round r's update)
-                        rank[r] = wave_digit_rank<RANK_ATOMIC>(cnt[w], (uint32_t)(key[r] >> shift) & 255u, ok, lane, lt);
+                        rank[r] = wave_digit_rank<RANK_ATOMIC, true>(cnt[w], ts_digit(key[r], p, index_passes, dmin), i < n, lane, lt);
                     }
                 }
                 __syncthreads();
-                digit_bases(cnt, lds4);
+                digit_bases_packed(cnt, lds8);
 #pragma unroll
                 for (int r = 0; r < TS_ITEMS; r++) {
                     const uint32_t i = wbeg + r * 64 + lane;
-                    if (r * 64u < chunk && i < n) xbuf[cnt[w][(uint32_t)(key[r] >> shift) & 255u] + rank[r]] = key[r];
+                    if (r * 64u < chunk && i < n) {
+                        const uint32_t d = ts_digit(key[r], p, index_passes, dmin);
+                        xbuf[((cnt[w][d >> 1] >> (16u * (d & 1u))) & 0xffffu) + rank[r]] = key[r];
+                    }
                 }
                 __syncthreads();
 #pragma unroll
@@ -328,17 +403,15 @@ __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks
                 }
                 // xbuf stays intact until the next pass writes it (after two barriers), so it can be read below
             }
-            // sorted by depth (phase 0) or by (depth, index) (phase 1): any equal-depth neighbours?
+            if (phase == 1) break;
+            // sorted by depth: any equal-depth neighbours?
             bool tie = false;
-            if (phase == 0) {
 #pragma unroll
-                for (int r = 0; r < TS_ITEMS; r++) {
-                    const uint32_t i = wbeg + r * 64 + lane;
-                    if (r * 64u < chunk && i + 1 < n) tie = tie || (uint32_t)(key[r] >> 32) == (uint32_t)(xbuf[i + 1] >> 32);
-                }
+            for (int r = 0; r < TS_ITEMS; r++) {
+                const uint32_t i = wbeg + r * 64 + lane;
+                if (r * 64u < chunk && i + 1 < n) tie = tie || (uint32_t)(key[r] >> 32) == (uint32_t)(xbuf[i + 1] >> 32);
             }
-            const int any_tie = __syncthreads_or(tie ? 1 : 0);
-            if (!any_tie) break;
+            if (!__syncthreads_or(tie ? 1 : 0)) break;
         }
 #pragma unroll
         for (int r = 0; r < TS_ITEMS; r++) {
@@ -348,31 +421,31 @@ __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks
         return;
     }
 
-    // ---- oversize bucket: same algorithm, keys stay in global memory (ping-pong with `scratch`) ----
+    // ---- oversize bucket: same digits, keys stay in global memory (ping-pong with `scratch`), full (index, depth) order ----
+    uint32_t (*wide)[TS_DIGITS] = reinterpret_cast<uint32_t (*)[TS_DIGITS]>(xbuf);     // xbuf is idle on this path
     uint64_t* src = pairs + beg;
     uint64_t* dst = scratch + beg;
+    uint32_t dmin = 0xffffffffu, dmax = 0u;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) { const uint32_t dw = (uint32_t)(src[i] >> 32); dmin = min(dmin, dw); dmax = max(dmax, dw); }
+    block_min_max(dmin, dmax, lds8);
+    const int depth_passes = (32 - __clz((int)(dmax - dmin)) + TS_DBITS - 1) / TS_DBITS;
+    const int npass = index_passes + depth_passes;
     for (int p = 0; p < npass; p++) {
-        const int shift = p < index_passes ? 8 * p : 32 + 8 * (p - index_passes);
-#pragma unroll
-        for (int k = 0; k < 4; k++) cnt[k][threadIdx.x] = 0;
+        for (int k = threadIdx.x; k < 4 * TS_DIGITS; k += 256) reinterpret_cast<uint32_t*>(xbuf)[k] = 0;
         __syncthreads();
         for (uint32_t r0 = 0; r0 < chunk; r0 += 64) {                  // count
             const uint32_t i = wbeg + r0 + lane;
-            const bool ok = i < n;
-            const uint32_t d = ok ? (uint32_t)(src[i] >> shift) & 255u : 0u;
-            if (ok) atomicAdd(&cnt[w][d], 1u);                          // counting only: order irrelevant
+            if (i < n) atomicAdd(&wide[w][ts_digit(src[i], p, index_passes, dmin)], 1u);     // counting only: order irrelevant
         }
         __syncthreads();
-        digit_bases(cnt, lds4);
+        digit_bases_wide(wide, lds8);
         const bool last = p == npass - 1;
-        for (uint32_t r0 = 0; r0 < chunk; r0 += 64) {                  // rank and move (cnt[w][d] is the running cursor)
+        for (uint32_t r0 = 0; r0 < chunk; r0 += 64) {                  // rank and move (wide[w][d] is the running cursor)
             const uint32_t i = wbeg + r0 + lane;
             const bool ok = i < n;
             const uint64_t kv = ok ? src[i] : 0ull;
-            const uint32_t d = (uint32_t)(kv >> shift) & 255u;
-            const uint32_t posr = wave_digit_rank<RANK_ATOMIC>(cnt[w], d, ok, lane, lt);   // cnt[w][d] is the running cursor
+            const uint32_t pos = wave_digit_rank<RANK_ATOMIC, false>(wide[w], ts_digit(kv, p, index_passes, dmin), ok, lane, lt);
             if (ok) {
-                const uint32_t pos = posr;
                 if (last) point_list[beg + pos] = (uint32_t)kv;
                 else dst[pos] = kv;
             }
@@ -405,6 +478,10 @@ hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int 
     }
     const size_t nb = (n + EGS_SCAN_EPB - 1) / EGS_SCAN_EPB;
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(EGS_SCAN_THREADS), 0, s, in, n, scratch);
+    if (nb <= EGS_SCAN_SPINE_MAX) {
+        hipLaunchKernelGGL(k_scan_apply_sum, dim3((unsigned)nb), dim3(EGS_SCAN_THREADS), 0, s, in, out, n, inclusive, scratch, total);
+        return hipGetLastError();
+    }
     hipError_t e = egs_launch_scan_u32(scratch, scratch, nb, 0, scratch + ((nb + 63) & ~(size_t)63), nullptr, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(EGS_SCAN_THREADS), 0, s, in, out, n, inclusive, scratch, total);
@@ -461,10 +538,10 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     egs_prof_start(EGS_K_SORT, s);
     if (fast)
         hipLaunchKernelGGL(k_tile_sort<true>, dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, b.total, R,
-                           (index_bits + 7) / 8, b.pairs, b.scratch, b.point_list, im.ranges);
+                           (index_bits + TS_DBITS - 1) / TS_DBITS, b.pairs, b.scratch, b.point_list, im.ranges);
     else
         hipLaunchKernelGGL(k_tile_sort<false>, dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, b.total, R,
-                           (index_bits + 7) / 8, b.pairs, b.scratch, b.point_list, im.ranges);
+                           (index_bits + TS_DBITS - 1) / TS_DBITS, b.pairs, b.scratch, b.point_list, im.ranges);
     egs_prof_stop(EGS_K_SORT, s);
     EGS_DBG(s);
     return hipGetLastError();

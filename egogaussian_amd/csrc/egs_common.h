@@ -88,7 +88,7 @@ hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs 
                                      hipStream_t s);
 hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
-                                      const float* dL_dalpha, float* grad_acc, hipStream_t s);
+                                      const float* dL_dalpha, float* grad_acc, size_t acc_floats, hipStream_t s);
 
 // Zero-fill by a kernel.  hipMemsetAsync is avoided inside the per-step chain: captured into a hipGraph it becomes a memset
 // node, and on ROCm 7.2 replays of the training-step graph intermittently saw stale accumulator contents with it.

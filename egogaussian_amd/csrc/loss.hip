@@ -137,6 +137,18 @@ __global__ __launch_bounds__(256) void k_l1_ssim_backward(int H, int W, const fl
     dimg[p] = g;
 }
 
+// Adds up the per-block partial sums and assembles the scalar loss (one workgroup; deterministic order).
+__global__ __launch_bounds__(256) void k_l1_ssim_finish(size_t nblocks, const float* __restrict__ partial, float w_l1, float w_ssim,
+                                                         float lambda, float* __restrict__ loss) {
+    __shared__ float red[8];
+    float a = 0.f, b = 0.f;
+    for (size_t i = threadIdx.x; i < nblocks; i += 256) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+    const float ta = block_sum_256(a, red);
+    __syncthreads();
+    const float tb = block_sum_256(b, red + 4);
+    if (threadIdx.x == 0) loss[0] = w_l1 * ta + lambda - w_ssim * tb;         // (1-l) mean|x-y| + l (1 - mean SSIM)
+}
+
 }  // namespace
 
 extern "C" {
@@ -145,13 +157,16 @@ size_t egs_l1_ssim_partial_count(int channels, int height, int width) {
     return (size_t)channels * ((height + LT - 1) / LT) * ((width + LT - 1) / LT) * 2;
 }
 
-int egs_l1_ssim_forward(int channels, int height, int width, const float* img, const float* gt, float* partial_sums,
-                        float* dm_dmu1, float* dm_dexx, float* dm_dexy, void* stream) {
-    if (channels <= 0 || height <= 0 || width <= 0 || !img || !gt || !partial_sums || !dm_dmu1 || !dm_dexx || !dm_dexy)
+int egs_l1_ssim_forward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
+                        float* partial_sums, float* dm_dmu1, float* dm_dexx, float* dm_dexy, float* loss, void* stream) {
+    if (channels <= 0 || height <= 0 || width <= 0 || !img || !gt || !partial_sums || !dm_dmu1 || !dm_dexx || !dm_dexy || !loss)
         return EGS_ERR_ARG;
     dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, channels);
     hipLaunchKernelGGL(k_l1_ssim_forward, grid, dim3(256), 0, (hipStream_t)stream, height, width, img, gt, partial_sums,
                        dm_dmu1, dm_dexx, dm_dexy);
+    const float n = (float)channels * (float)height * (float)width;
+    hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, (size_t)grid.x * grid.y * grid.z, partial_sums,
+                       (1.f - lambda_dssim) / n, lambda_dssim / n, lambda_dssim, loss);
     return (int)hipGetLastError();
 }
 

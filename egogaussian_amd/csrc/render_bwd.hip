@@ -21,6 +21,7 @@
 //     (egs_common.h) instead of ten.
 #include "egs_common.h"
 #include "blend_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -54,10 +55,16 @@ __device__ __forceinline__ float row_sum(float v) {
 // Workgroup b runs on XCD b % 8 and, inside the XCD, on CU (b / 8) % 32 (tools/ubench/dispatch_map.hip; used for speed
 // only -- any placement gives the same results).  One workgroup per XCD band ranks the band's tiles by the replay depth
 // the forward recorded and deals them to the 32 CUs in snake order (rank r -> round r/32, CU r%32 or 31 - r%32).
+// The same launch clears the gradient accumulator (workgroups 8..): two short kernels cost more than one.
 #define ORDER_MAX_BAND 2048
-__global__ __launch_bounds__(1024) void k_order_tiles(int n_tiles, const uint32_t* __restrict__ quad_work,
-                                                       uint32_t* __restrict__ tile_order) {
-    __shared__ uint32_t work[ORDER_MAX_BAND];
+__global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const uint32_t* __restrict__ quad_work,
+                                                             uint32_t* __restrict__ tile_order, float4* __restrict__ acc4, size_t n4) {
+    if (blockIdx.x >= EGS_XCDS) {
+        const size_t stride = (size_t)(gridDim.x - EGS_XCDS) * 1024;
+        for (size_t i = (size_t)(blockIdx.x - EGS_XCDS) * 1024 + threadIdx.x; i < n4; i += stride) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) uint32_t work[ORDER_MAX_BAND];
     const int per = egs_tiles_per_xcd(n_tiles), x = blockIdx.x;
     const int t0 = x * per, n = max(0, min(per, n_tiles - t0));
     const int slots = ((per + 31) / 32) * 32;
@@ -65,16 +72,24 @@ __global__ __launch_bounds__(1024) void k_order_tiles(int n_tiles, const uint32_
         for (int sl = threadIdx.x; sl < per; sl += blockDim.x) tile_order[8 * sl + x] = sl < n ? (uint32_t)(t0 + sl) : 0xffffffffu;
         return;
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint4 w4 = *reinterpret_cast<const uint4*>(quad_work + 4 * (size_t)(t0 + i));
-        work[i] = w4.x + w4.y + w4.z + w4.w;
+    const int n_pad = (n + 3) & ~3;
+    for (int i = threadIdx.x; i < n_pad; i += blockDim.x) {
+        uint32_t wsum = 0;                                           // padding entries never outrank a real one
+        if (i < n) { const uint4 w4 = *reinterpret_cast<const uint4*>(quad_work + 4 * (size_t)(t0 + i)); wsum = w4.x + w4.y + w4.z + w4.w; }
+        work[i] = wsum;
     }
     for (int sl = threadIdx.x; sl < per; sl += blockDim.x) tile_order[8 * sl + x] = 0xffffffffu;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const uint32_t wi = work[i];
         int rank = 0;
-        for (int j = 0; j < n; j++) { const uint32_t wj = work[j]; rank += (wj > wi) || (wj == wi && j < i); }
+        for (int j = 0; j < n_pad; j += 4) {
+            const uint4 wj = *reinterpret_cast<const uint4*>(work + j);
+            rank += (wj.x > wi) || (wj.x == wi && j < i);
+            rank += (wj.y > wi) || (wj.y == wi && j + 1 < i);
+            rank += (wj.z > wi) || (wj.z == wi && j + 2 < i);
+            rank += (wj.w > wi) || (wj.w == wi && j + 3 < i);
+        }
         const int round = rank / 32, pos = rank % 32;
         int slot = round * 32 + ((round & 1) ? 31 - pos : pos);
         if (slot >= per) slot = round * 32 + pos;                    // last, partial round: no room to mirror
@@ -206,11 +221,14 @@ __global__ __launch_bounds__(256) void k_render_backward(
 
 hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
-                                      const float* dL_dalpha, float* grad_acc, hipStream_t s) {
+                                      const float* dL_dalpha, float* grad_acc, size_t acc_floats, hipStream_t s) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
-    if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_order_tiles, dim3(EGS_XCDS), dim3(1024), 0, s, n_tiles, im.quad_work, im.tile_order);
+    if (n_tiles == 0) return egs_launch_zero_f4((float4*)grad_acc, acc_floats / 4, s);
+    const size_t n4 = acc_floats / 4;
+    const unsigned zero_blocks = (unsigned)std::min<size_t>((n4 + 1023) / 1024, 1024);
+    hipLaunchKernelGGL(k_backward_prologue, dim3(EGS_XCDS + zero_blocks), dim3(1024), 0, s, n_tiles, im.quad_work, im.tile_order,
+                       (float4*)grad_acc, n4);
     hipLaunchKernelGGL(k_render_backward, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                        im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
                        im.tile_order, grad_acc);

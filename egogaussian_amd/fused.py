@@ -100,11 +100,10 @@ class _L1SSIM(torch.autograd.Function):
         dev = img.device
         partial = torch.empty(L.egs_l1_ssim_partial_count(Cc, H, W), device=dev)
         maps = torch.empty((3, Cc, H, W), device=dev)
+        loss = torch.empty((), device=dev)
         with torch.cuda.device(dev):
-            _lib.check(L.egs_l1_ssim_forward(Cc, H, W, _p(img), _p(gt), _p(partial), _p(maps[0]), _p(maps[1]), _p(maps[2]), _stream()))
-        sums = partial.view(-1, 2).sum(0)
-        n = float(Cc * H * W)
-        loss = (1.0 - lambda_dssim) * (sums[0] / n) + lambda_dssim * (1.0 - sums[1] / n)
+            _lib.check(L.egs_l1_ssim_forward(Cc, H, W, _p(img), _p(gt), float(lambda_dssim), _p(partial), _p(maps[0]), _p(maps[1]),
+                                             _p(maps[2]), _p(loss), _stream()))
         ctx.save_for_backward(img, gt, maps, gate if gate is not None else torch.empty(0))
         ctx.lam, ctx.has_gate = float(lambda_dssim), gate is not None
         return loss
@@ -115,7 +114,9 @@ class _L1SSIM(torch.autograd.Function):
         img, gt, maps, gate = ctx.saved_tensors
         gate = gate.float().contiguous() if ctx.has_gate else None
         Cc, H, W = img.shape
-        g = g.reshape(1).float().contiguous()
+        g = g.reshape(1)
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.float().contiguous()
         dimg = torch.empty_like(img)
         with torch.cuda.device(img.device):
             _lib.check(L.egs_l1_ssim_backward(Cc, H, W, _p(img), _p(gt), ctx.lam, _p(g), _p(gate), _p(maps[0]), _p(maps[1]),

@@ -53,7 +53,7 @@ SIGNATURES = {
     "egs_cov3d_forward": (C.c_int, [i32, vp, f32, vp, vp, vp, vp, vp]),
     "egs_cov3d_backward": (C.c_int, [i32, vp, f32, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
     "egs_l1_ssim_partial_count": (C.c_size_t, [i32, i32, i32]),
-    "egs_l1_ssim_forward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "egs_l1_ssim_forward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
     "egs_l1_ssim_backward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_adam_step": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
     "egs_adam_step_capturable": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),

@@ -24,11 +24,7 @@ def get_raster_settings(viewpoint_camera, pc, bg_color, scaling_modifier=1.0):
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, rot_cov=False,
            accum_R=None, which_object=None, during_training=False):
     xyz = pc.get_xyz
-    screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0       # harvests d loss / d mean2D
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True)           # leaf that harvests d loss / d mean2D
     rasterizer = GaussianRasterizer(raster_settings=get_raster_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
 
     scales = rotations = cov3D_precomp = None

@@ -85,7 +85,8 @@ typedef struct egs_binning_layout {
     size_t total;          /* uint64[1]  instance count found by the bucketing scan (== R; may exceed a speculative capacity) */
     int    bin_blocks;     /* workgroups of the bucketing kernels = ceil(P / 1024) */
     int    key_bits;       /* significant bits of the canonical (tile<<32 | depth) key: 32 + bits(tile count) */
-    int    index_passes;   /* 8-bit radix passes spent on the Gaussian index inside the per-tile sort (+4 on depth) */
+    int    index_passes;   /* 9-bit radix passes on the Gaussian index inside the per-tile sort, run only for tiles with depth ties
+                             (+ up to 4 on depth: ceil(bits(zmax - zmin of the tile) / 9)) */
 } egs_binning_layout;
 typedef struct egs_image_layout {
     size_t ranges;         /* uint32[tiles][2] */
@@ -188,13 +189,14 @@ int egs_cov3d_backward(int N, const float* scaling, float scale_modifier, const 
 
 /* ---- f-3: fused image loss (1 - lambda) * L1 + lambda * (1 - SSIM), 11x11 Gaussian window sigma 1.5, zero padding.
  *      Replaces l1_loss + ssim (/root/reference/utils/loss_utils.py:57-107) as combined at
- *      /root/reference/trainers/train_static.py:92-95.  The forward writes per-block partial sums
- *      (pairs: sum|x-y|, sum SSIM_map; egs_l1_ssim_partial_count floats) for the caller to add up, and three
- *      derivative maps [C,H,W] the backward consumes.  `gate` (optional, [H,W]) multiplies the image gradient
+ *      /root/reference/trainers/train_static.py:92-95.  The forward writes the scalar loss (device float[1]), using
+ *      egs_l1_ssim_partial_count floats of scratch for per-block partial sums, and three derivative maps [C,H,W] the
+ *      backward consumes.  `gate` (optional, [H,W]) multiplies the image gradient
  *      per pixel -- the hand-mask hook of train_static.py:91. */
 size_t egs_l1_ssim_partial_count(int channels, int height, int width);
 int egs_l1_ssim_forward(int channels, int height, int width, const float* img /*[C,H,W]*/, const float* gt /*[C,H,W]*/,
-                        float* partial_sums, float* dm_dmu1, float* dm_dexx, float* dm_dexy, void* stream);
+                        float lambda_dssim, float* partial_sums /*scratch*/, float* dm_dmu1, float* dm_dexx, float* dm_dexy,
+                        float* loss /*device [1] out*/, void* stream);
 int egs_l1_ssim_backward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
                          const float* upstream_grad /*device [1]*/, const float* gate /*[H,W] or NULL*/,
                          const float* dm_dmu1, const float* dm_dexx, const float* dm_dexy, float* dL_dimg /*[C,H,W] out*/,
