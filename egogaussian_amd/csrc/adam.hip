@@ -17,7 +17,8 @@ struct AdamArgs {
     float* p[ADAM_MAX_TENSORS]; const float* g[ADAM_MAX_TENSORS]; float* m[ADAM_MAX_TENSORS]; float* v[ADAM_MAX_TENSORS];
     long long numel[ADAM_MAX_TENSORS]; unsigned block_start[ADAM_MAX_TENSORS + 1];
     float step_size[ADAM_MAX_TENSORS], inv_bc2_sqrt[ADAM_MAX_TENSORS];
-    const float* step_dev[ADAM_MAX_TENSORS]; const float* lr_dev[ADAM_MAX_TENSORS];   // capturable variant: read on the device
+    float* step_dev[ADAM_MAX_TENSORS]; const float* lr_dev[ADAM_MAX_TENSORS];         // capturable variant: read on the device
+    unsigned* ticket;                                                                  // capturable variant: workgroups-finished counter
     int n; float b1, b2, eps;
 };
 
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     float* __restrict__ p = a.p[t]; const float* __restrict__ g = a.g[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
     float ss = a.step_size[t], ib = a.inv_bc2_sqrt[t];
     if (a.step_dev[t]) {                                             // wave-uniform: hipGraph replays see the current step / lr
-        const float st = a.step_dev[t][0];
+        const float st = a.step_dev[t][0] + 1.f;                     // steps taken so far + this one
         ss = a.lr_dev[t][0] / (1.f - powf(a.b1, st));
         ib = 1.f / sqrtf(1.f - powf(a.b2, st));
     }
@@ -59,19 +60,34 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
             }
         }
     }
+    if (a.ticket) {
+        // The workgroup that finishes last advances every step counter: all the others have read theirs by then, so
+        // no separate "step += 1" launch per parameter is needed (five tiny kernels per iteration in the reference's
+        // optimizer layout).  The ticket returns to zero for the next launch.  No fence: nothing this workgroup WROTE is
+        // read by the last one (an agent-scope release here would write back the XCD's whole L2 per workgroup, 3x the
+        // kernel's time); its read of the counter has been consumed by the stores above before the barrier.
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (atomicAdd(a.ticket, 1u) == gridDim.x - 1) {
+                for (int k = 0; k < a.n; k++) a.step_dev[k][0] += 1.f;
+                *a.ticket = 0u;
+            }
+        }
+    }
 }
 
 }  // namespace
 
 static int adam_impl(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
-                     const float* const* step_dev, const float* const* lr_dev, float beta1, float beta2, float eps, void* stream) {
+                     float* const* step_dev, const float* const* lr_dev, unsigned* ticket, float beta1, float beta2, float eps,
+                     void* stream) {
     if (n_tensors < 0) return EGS_ERR_ARG;
     const bool dev = step_dev != nullptr;
     if (n_tensors && (!params || !grads || !exp_avg || !exp_avg_sq || !numels)) return EGS_ERR_ARG;
-    if (n_tensors && (dev ? !lr_dev : (!lrs || !steps))) return EGS_ERR_ARG;
+    if (n_tensors && (dev ? (!lr_dev || !ticket) : (!lrs || !steps))) return EGS_ERR_ARG;
     for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MAX_TENSORS) {
-        AdamArgs a; a.n = 0; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+        AdamArgs a; a.n = 0; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.ticket = dev ? ticket : nullptr;
         unsigned blocks = 0;
         for (int t = t0; t < n_tensors && a.n < ADAM_MAX_TENSORS; t++) {
             if (numels[t] <= 0) continue;
@@ -100,14 +116,17 @@ static int adam_impl(int n_tensors, float* const* params, const float* const* gr
 extern "C" int egs_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                              float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
                              float beta1, float beta2, float eps, void* stream) {
-    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, lrs, steps, nullptr, nullptr, beta1, beta2, eps, stream);
+    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, lrs, steps, nullptr, nullptr, nullptr, beta1, beta2, eps, stream);
 }
 
-// hipGraph-capturable variant: the 1-based step count and the learning rate of every tensor are read from device
-// scalars (float[1]) at run time, so a captured step keeps working while the host advances them between replays.
+// hipGraph-capturable variant: the number of steps already taken and the learning rate of every tensor are read from
+// device scalars (float[1], one per tensor, not shared between tensors) at run time; the launch itself adds one to every
+// step scalar when its last workgroup retires (`ticket`: a device uint32 that is zero between launches).  A captured
+// step therefore keeps counting across replays with no other kernel, and the host may edit the learning rates between them.
 extern "C" int egs_adam_step_capturable(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
-                                        float* const* exp_avg_sq, const int64_t* numels, const float* const* step_dev,
-                                        const float* const* lr_dev, float beta1, float beta2, float eps, void* stream) {
+                                        float* const* exp_avg_sq, const int64_t* numels, float* const* step_dev,
+                                        const float* const* lr_dev, uint32_t* ticket, float beta1, float beta2, float eps,
+                                        void* stream) {
     if (n_tensors && !step_dev) return EGS_ERR_ARG;
-    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, nullptr, nullptr, step_dev, lr_dev, beta1, beta2, eps, stream);
+    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, nullptr, nullptr, step_dev, lr_dev, ticket, beta1, beta2, eps, stream);
 }

@@ -138,15 +138,20 @@ __global__ __launch_bounds__(256) void k_l1_ssim_backward(int H, int W, const fl
 }
 
 // Adds up the per-block partial sums and assembles the scalar loss (one workgroup; deterministic order).
-__global__ __launch_bounds__(256) void k_l1_ssim_finish(size_t nblocks, const float* __restrict__ partial, float w_l1, float w_ssim,
-                                                         float lambda, float* __restrict__ loss) {
-    __shared__ float red[8];
+__global__ __launch_bounds__(1024) void k_l1_ssim_finish(size_t nblocks, const float* __restrict__ partial, float w_l1, float w_ssim,
+                                                          float lambda, float* __restrict__ loss) {
+    __shared__ float red[2][16];
     float a = 0.f, b = 0.f;
-    for (size_t i = threadIdx.x; i < nblocks; i += 256) { a += partial[2 * i]; b += partial[2 * i + 1]; }
-    const float ta = block_sum_256(a, red);
+    for (size_t i = threadIdx.x; i < nblocks; i += 1024) { const float2 v = reinterpret_cast<const float2*>(partial)[i]; a += v.x; b += v.y; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
     __syncthreads();
-    const float tb = block_sum_256(b, red + 4);
-    if (threadIdx.x == 0) loss[0] = w_l1 * ta + lambda - w_ssim * tb;         // (1-l) mean|x-y| + l (1 - mean SSIM)
+    if (threadIdx.x == 0) {
+        float ta = 0.f, tb = 0.f;
+        for (int k = 0; k < 16; k++) { ta += red[0][k]; tb += red[1][k]; }
+        loss[0] = w_l1 * ta + lambda - w_ssim * tb;                           // (1-l) mean|x-y| + l (1 - mean SSIM)
+    }
 }
 
 }  // namespace
@@ -165,7 +170,7 @@ int egs_l1_ssim_forward(int channels, int height, int width, const float* img, c
     hipLaunchKernelGGL(k_l1_ssim_forward, grid, dim3(256), 0, (hipStream_t)stream, height, width, img, gt, partial_sums,
                        dm_dmu1, dm_dexx, dm_dexy);
     const float n = (float)channels * (float)height * (float)width;
-    hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, (size_t)grid.x * grid.y * grid.z, partial_sums,
+    hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, (size_t)grid.x * grid.y * grid.z, partial_sums,
                        (1.f - lambda_dssim) / n, lambda_dssim / n, lambda_dssim, loss);
     return (int)hipGetLastError();
 }

@@ -25,13 +25,18 @@ class _StaticCamera:
 
     def __init__(self, cam):
         self.image_height, self.image_width, self.FoVx, self.FoVy = cam.image_height, cam.image_width, cam.FoVx, cam.FoVy
-        self.world_view_transform = cam.world_view_transform.clone()
-        self.full_proj_transform = cam.full_proj_transform.clone()
-        self.camera_center = cam.camera_center.clone()
+        self.packed = torch.cat([cam.world_view_transform.reshape(-1), cam.full_proj_transform.reshape(-1), cam.camera_center.reshape(-1)])
+        self.world_view_transform = self.packed[0:16].view(4, 4)
+        self.full_proj_transform = self.packed[16:32].view(4, 4)
+        self.camera_center = self.packed[32:35]
 
     def load(self, cam):
         same = (cam.image_height, cam.image_width, cam.FoVx, cam.FoVy) == (self.image_height, self.image_width, self.FoVx, self.FoVy)
         assert same, "a captured step is specific to one image size and field of view"
+        packed = getattr(cam, "packed", None)
+        if packed is not None and packed.shape == self.packed.shape:   # cameras that keep the three in one block: one copy
+            self.packed.copy_(packed, non_blocking=True)
+            return
         self.world_view_transform.copy_(cam.world_view_transform, non_blocking=True)
         self.full_proj_transform.copy_(cam.full_proj_transform, non_blocking=True)
         self.camera_center.copy_(cam.camera_center, non_blocking=True)
@@ -49,7 +54,7 @@ class GraphedTrainStep:
     def _body(self):
         out = render(self.cam, self.pc, self.pipe, self.bg, **self.render_kwargs)
         if self._max_r is not None:                                  # running maximum of R over all replays, on the device
-            self._max_r.copy_(torch.maximum(self._max_r, _C.stats["total_view"].to(torch.float32).reshape(())))
+            torch.maximum(self._max_r, _C.stats["total_view"], out=self._max_r)
         loss = l1_ssim_loss(out["render"], self.gt, self.lam)
         loss.backward()
         self.opt.step()
@@ -72,7 +77,7 @@ class GraphedTrainStep:
         self.capacity = max(int(_C.stats["num_rendered"] * capacity_margin), _C.stats["capacity"])
         _C.set_capacity_hint(self.capacity, dev)
         self.P = P
-        self._max_r = torch.zeros((), dtype=torch.float32, device=dev)
+        self._max_r = torch.zeros(1, dtype=torch.int64, device=dev)
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

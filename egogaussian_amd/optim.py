@@ -21,6 +21,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.capturable = capturable
         self._lr_dev = {}
+        self._ticket = {}                 # device -> uint32 scalar the capturable kernel counts finished workgroups in
 
     def sync_lr(self):
         for gi, group in enumerate(self.param_groups):
@@ -48,7 +49,6 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 if not (torch.is_tensor(st.get("step")) and st["step"].is_cuda):
                     st["step"] = torch.full((1,), float(st.get("step", 0)), device=p.device)
-                st["step"].add_(1.0)
                 lr_t = self._lr_dev.get((gi, id(p)))
                 if lr_t is None:
                     lr_t = self._lr_dev[(gi, id(p))] = torch.full((1,), float(group["lr"]), device=p.device)
@@ -59,9 +59,12 @@ class FusedAdam(torch.optim.Optimizer):
             n = len(items)
             arr = lambda k: (C.c_void_p * n)(*[t[k].data_ptr() for t in items])
             NN = (C.c_int64 * n)(*[t[0].numel() for t in items])
-            with torch.cuda.device(dev):
-                _lib.check(L.egs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), NN, arr(4), arr(5), float(betas[0]),
-                                                      float(betas[1]), float(eps), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            if dev not in self._ticket:
+                self._ticket[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):                             # the kernel itself advances every st["step"] by one
+                _lib.check(L.egs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), NN, arr(4), arr(5),
+                                                      C.c_void_p(self._ticket[dev].data_ptr()), float(betas[0]), float(betas[1]),
+                                                      float(eps), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     @torch.no_grad()
     def step(self, closure=None):

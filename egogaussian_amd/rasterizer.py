@@ -49,6 +49,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img,
                               alpha)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)        # unused depth/alpha outputs arrive as None in backward, not as zero images
         return color, radii, depth, alpha
 
     @staticmethod

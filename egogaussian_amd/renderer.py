@@ -21,10 +21,25 @@ def get_raster_settings(viewpoint_camera, pc, bg_color, scaling_modifier=1.0):
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
 
 
+_zero_points = {}
+
+
+def _screenspace_leaf(xyz):
+    """Fresh autograd leaf of zeros shaped like `xyz` whose only job is to collect d loss / d mean2D in `.grad`
+    (/root/reference/gaussian_renderer/__init__.py:27-31 allocates and zero-fills one per call).  Nothing ever writes
+    its values, so every call's leaf aliases one cached block of zeros per (device, shape): no fill kernel per render."""
+    key = (xyz.device, tuple(xyz.shape), xyz.dtype)
+    base = _zero_points.get(key)
+    if base is None:
+        _zero_points.clear()                                  # one live shape at a time (the count changes at densification)
+        base = _zero_points[key] = torch.zeros_like(xyz, requires_grad=False)
+    return base.detach().requires_grad_(True)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, rot_cov=False,
            accum_R=None, which_object=None, during_training=False):
     xyz = pc.get_xyz
-    screenspace_points = torch.zeros_like(xyz, requires_grad=True)           # leaf that harvests d loss / d mean2D
+    screenspace_points = _screenspace_leaf(xyz)
     rasterizer = GaussianRasterizer(raster_settings=get_raster_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
 
     scales = rotations = cov3D_precomp = None

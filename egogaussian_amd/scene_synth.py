@@ -58,6 +58,11 @@ class SynthCamera:
         self.full_proj_transform = (self.world_view_transform.unsqueeze(0)
                                     .bmm(self.projection_matrix.unsqueeze(0))).squeeze(0).contiguous()
         self.camera_center = self.world_view_transform.inverse()[3, :3].contiguous()
+        # the three tensors render() reads, also as views of one block so that a captured step refreshes them in one copy
+        self.packed = torch.cat([self.world_view_transform.reshape(-1), self.full_proj_transform.reshape(-1), self.camera_center])
+        self.world_view_transform = self.packed[0:16].view(4, 4)
+        self.full_proj_transform = self.packed[16:32].view(4, 4)
+        self.camera_center = self.packed[32:35]
 
 
 def fov_pair(H, W, fovx_deg=60.0):

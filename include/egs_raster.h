@@ -209,10 +209,14 @@ int egs_l1_ssim_backward(int channels, int height, int width, const float* img, 
 int egs_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                   float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
                   float beta1, float beta2, float eps, void* stream);
-/* hipGraph-capturable variant: step count and learning rate of each tensor are device float[1] scalars read by the kernel. */
+/* hipGraph-capturable variant: `step_dev[t]` (device float[1], one per tensor, never shared) holds the number of steps
+ * tensor t has ALREADY taken and `lr_dev[t]` (device float[1]) its learning rate; both are read by the kernel.  The launch
+ * adds one to every step scalar as its last workgroup retires, using `ticket` (device uint32, zero between launches), so
+ * a captured iteration needs no other kernel to keep count. */
 int egs_adam_step_capturable(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
-                             float* const* exp_avg_sq, const int64_t* numels, const float* const* step_dev /*HOST array of device ptrs*/,
-                             const float* const* lr_dev /*HOST array of device ptrs*/, float beta1, float beta2, float eps, void* stream);
+                             float* const* exp_avg_sq, const int64_t* numels, float* const* step_dev /*HOST array of device ptrs*/,
+                             const float* const* lr_dev /*HOST array of device ptrs*/, uint32_t* ticket, float beta1, float beta2,
+                             float eps, void* stream);
 
 /* ---- f-2: mean squared distance of every point to its 3 nearest neighbours (self excluded by index).
  *      Replaces simple_knn._C.distCUDA2 (un-vendored submodule, /root/reference/.gitmodules:4-6), imported at
