@@ -27,6 +27,13 @@ def binning_passes(P, W, H):
     return int(lay.index_passes) + 4
 
 
+def set_tile_culling(on):
+    """Tile culling of never-contributing instances (include/egs_raster.h, egs_debug_set_tile_culling): on by default;
+    off keeps the reference's full rectangles so that the internal lists match the reference algorithm's bit for bit.
+    Returns the previous setting."""
+    return bool(_lib.load().egs_debug_set_tile_culling(int(bool(on))))
+
+
 def last_instance_count(device=None, P=None):
     """R of the most recent forward on `device`, summed from the page-locked per-workgroup counts.  Only meaningful after
     the stream has been synchronised; this is how a graph-replayed step is checked against its capacity."""
@@ -221,4 +228,5 @@ def image_views(img, W, H):
     nt = ((W + 15) // 16) * ((H + 15) // 16)
     return dict(ranges=img[lay.ranges:lay.ranges + nt * 8].view(torch.int32).view(nt, 2),
                 final_T=img[lay.final_T:lay.final_T + H * W * 4].view(torch.float32).view(H, W),
-                n_contrib=img[lay.n_contrib:lay.n_contrib + H * W * 4].view(torch.int32).view(H, W))
+                n_contrib=img[lay.n_contrib:lay.n_contrib + H * W * 4].view(torch.int32).view(H, W),
+                quad_work=img[lay.quad_work:lay.quad_work + nt * 16].view(torch.int32).view(nt, 4))

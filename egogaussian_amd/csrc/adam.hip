@@ -37,9 +37,12 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     float* __restrict__ p = a.p[t]; const float* __restrict__ g = a.g[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
     float ss = a.step_size[t], ib = a.inv_bc2_sqrt[t];
     if (a.step_dev[t]) {                                             // wave-uniform: hipGraph replays see the current step / lr
-        const float st = a.step_dev[t][0] + 1.f;                     // steps taken so far + this one
-        ss = a.lr_dev[t][0] / (1.f - powf(a.b1, st));
-        ib = 1.f / sqrtf(1.f - powf(a.b2, st));
+        // same double-precision expressions as the host computes for the non-capturable launch, so both variants take
+        // bit-identical steps (the float powf route differs by ~1e-5 relative, which Adam's eps = 1e-15 turns into visibly
+        // different trajectories for parameters whose gradients are at rounding level)
+        const double st = (double)a.step_dev[t][0] + 1.0;            // steps taken so far + this one
+        ss = (float)((double)a.lr_dev[t][0] / (1.0 - pow((double)a.b1, st)));
+        ib = (float)(1.0 / sqrt(1.0 - pow((double)a.b2, st)));
     }
     const bool vec = (((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0;
 #pragma unroll

@@ -141,6 +141,7 @@ const char* egs_profile_stage_name(int stage) {
 
 int egs_abi_version(void) { return EGS_ABI_VERSION; }
 
+int egs_debug_set_tile_culling(int on) { const int old = egs_tile_culling; egs_tile_culling = on ? 1 : 0; return old; }
 int egs_debug_force_ballot_rank(int on) { const int old = egs_force_ballot_rank; egs_force_ballot_rank = on ? 1 : 0; return old; }
 
 const char* egs_error_string(int code) {

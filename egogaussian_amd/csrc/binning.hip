@@ -25,8 +25,10 @@
 // 8 ballots ("same digit" peer mask) + popcount-below-lane, with per-wave LDS counters touched only by each peer
 // group's lowest lane.
 #include "egs_common.h"
+#include "blend_common.h"
 #include <atomic>
 
+int egs_tile_culling = 1;           // egs_debug_set_tile_culling: 0 keeps every instance of the reference's rectangles
 int egs_force_ballot_rank = 0;      // test hook (egs_debug_force_ballot_rank): exercise the fallback ranking
 
 namespace {
@@ -150,11 +152,19 @@ __device__ __forceinline__ unsigned bin_logical_block(unsigned nblocks) {
     return l;                                                       // >= nblocks for the padding blocks of the grid
 }
 
+//
+// Tile culling (`cull`): the rectangle is the reference's 3-sigma bounding square, so many of its tiles hold no pixel the
+// splat can reach with alpha >= 1/255 (corners of elongated splats, faint splats).  Such an instance can never
+// contribute -- the reference skips it at every pixel -- so dropping it here changes no output bit; it only shortens the
+// sort and the lists the blend kernels scan (config C: 2.94M -> 1.87M instances).  The test is the exact, conservative
+// ellipse-vs-block test the blend kernels apply per 8x8 quadrant (blend_common.h), on the whole 16x16 tile; the wave
+// parks its 64 splats' ellipse parameters in a private LDS slice and each slot-lane reads its own.
 template <typename Body>
 __device__ __forceinline__ void for_each_instance(unsigned bid, int P, const uint32_t* __restrict__ tiles_touched,
                                                   const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
-                                                  bool need_depth, Body body) {
+                                                  bool need_depth, bool cull, int W, int H, float4* __restrict__ stage, Body body) {
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    stage += w * 128;                                                  // 64 x 2 float4 per wave
     const int per_wave = EGS_BIN_GPB / (EGS_BIN_THREADS / 64);
     const int first = (int)bid * EGS_BIN_GPB + (int)w * per_wave;
     for (int g0 = first; g0 < first + per_wave && g0 < P; g0 += 64) {
@@ -167,6 +177,11 @@ __device__ __forceinline__ void for_each_instance(unsigned bid, int P, const uin
         const uint32_t excl = have ? incl - cnt : 0xffffffffu;       // span start; invalid lanes sort to the end
         uint2 rc = make_uint2(0u, 0u); uint32_t dbits = 0;
         if (cnt) { rc = rect[i]; if (need_depth) dbits = __float_as_uint(rec[(size_t)i * EGS_SPLAT_REC_F4 + 2].y); }
+        if (cull) {
+            __builtin_amdgcn_wave_barrier();                            // earlier readers of the slice are done
+            if (cnt) { stage[2 * lane] = rec[(size_t)i * EGS_SPLAT_REC_F4]; stage[2 * lane + 1] = rec[(size_t)i * EGS_SPLAT_REC_F4 + 1]; }
+            __builtin_amdgcn_wave_barrier();
+        }
         for (uint32_t s0 = 0; s0 < total; s0 += 64) {
             const uint32_t s = s0 + lane;
             int lo = 0;                                              // last lane whose span starts at or before s
@@ -184,7 +199,13 @@ __device__ __forceinline__ void for_each_instance(unsigned bid, int P, const uin
                 const uint32_t x0 = orc.x & 0xffffu, x1 = orc.x >> 16, y0 = orc.y & 0xffffu;
                 const uint32_t wd = x1 - x0;
                 const uint32_t ty = y0 + k / wd, tx = x0 + k % wd;
-                body(ty * (uint32_t)gx + tx, (uint32_t)(g0 + lo), odb);
+                bool keep = true;
+                if (cull) {
+                    const float4 e0 = stage[2 * lo], e1 = stage[2 * lo + 1];             // (x, y, qa, qb), (qc, opacity, ..)
+                    keep = egs_ellipse_hits(e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, tx * EGS_TILE, min(tx * EGS_TILE + EGS_TILE - 1, (uint32_t)W - 1),
+                                            ty * EGS_TILE, min(ty * EGS_TILE + EGS_TILE - 1, (uint32_t)H - 1));
+                }
+                if (keep) body(ty * (uint32_t)gx + tx, (uint32_t)(g0 + lo), odb);
             }
         }
     }
@@ -194,13 +215,15 @@ extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
 
 __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, const uint32_t* __restrict__ tiles_touched,
                                                     const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
-                                                    int n_tiles, uint32_t nblocks, uint32_t* __restrict__ table) {
+                                                    int n_tiles, uint32_t nblocks, int cull, int W, int H,
+                                                    uint32_t* __restrict__ table) {
     const unsigned bid = bin_logical_block(nblocks);
     if (bid >= nblocks) return;
     uint32_t* hist = dyn_lds;
+    float4* stage = reinterpret_cast<float4*>(dyn_lds + ((n_tiles + 3) & ~3));
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) hist[t] = 0;
     __syncthreads();
-    for_each_instance(bid, P, tiles_touched, rect, rec, gx, false,
+    for_each_instance(bid, P, tiles_touched, rect, rec, gx, false, cull != 0, W, H, stage,
                       [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); });
     __syncthreads();
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) table[(size_t)t * nblocks + bid] = hist[t];   // tile-major
@@ -208,14 +231,16 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, const uint
 
 __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, const uint32_t* __restrict__ tiles_touched,
                                                       const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
-                                                      int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
+                                                      int n_tiles, uint32_t nblocks, int cull, int W, int H,
+                                                      const uint32_t* __restrict__ table_scanned,
                                                       uint32_t cap, uint64_t* __restrict__ pairs) {
     const unsigned bid = bin_logical_block(nblocks);
     if (bid >= nblocks) return;
     uint32_t* cursor = dyn_lds;
+    float4* stage = reinterpret_cast<float4*>(dyn_lds + ((n_tiles + 3) & ~3));
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) cursor[t] = table_scanned[(size_t)t * nblocks + bid];
     __syncthreads();
-    for_each_instance(bid, P, tiles_touched, rect, rec, gx, true, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
+    for_each_instance(bid, P, tiles_touched, rect, rec, gx, true, cull != 0, W, H, stage, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
         const uint32_t pos = atomicAdd(&cursor[tile], 1u);
         if (pos < cap) pairs[pos] = ((uint64_t)dbits << 32) | idx;      // cap < R only in a speculative launch that will be redone
     });
@@ -230,8 +255,12 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, const ui
 // Stable ranking as in a global radix pass, but the whole bucket belongs to one workgroup: wave w owns the contiguous
 // quarter [w*chunk, (w+1)*chunk) in rounds of 64.
 // ---------------------------------------------------------------------------------------------
-#define TS_ITEMS 16
-#define TS_CAP (256 * TS_ITEMS)       // 4096 pairs held in registers, one 32 KiB LDS exchange buffer
+#ifndef TS_WAVES
+#define TS_WAVES 8                    // waves per workgroup (one tile each)
+#endif
+#define TS_THREADS (64 * TS_WAVES)
+#define TS_CAP 4096                   // pairs held in registers, one 32 KiB LDS exchange buffer
+#define TS_ITEMS (TS_CAP / TS_THREADS)
 #define TS_DBITS 9
 #define TS_DIGITS (1 << TS_DBITS)
 
@@ -252,32 +281,52 @@ __device__ __forceinline__ uint32_t ts_digit(uint64_t kv, int pass, int index_pa
     return (word >> sh) & (TS_DIGITS - 1);
 }
 
-// Register path: a wave's quarter holds at most 1024 pairs, so two digit counters share one LDS word (16 bits each).
+// Exclusive scan of one value per thread over the FIRST 256 threads of the workgroup (every thread must call).
+__device__ __forceinline__ uint32_t scan_first_256(uint32_t v, uint32_t* lds4) {
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(v);
+    if (lane == 63 && w < 4) lds4[w] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) if (k < (int)w) base += lds4[k];
+    __syncthreads();
+    return base + incl - v;
+}
+
+// Register path: a wave's share holds at most 1024 pairs, so two digit counters share one LDS word (16 bits each).
 // After every wave has accumulated its counts: turn them into exclusive positions
-//   pos[w][d] = (#keys with digit < d) + (#keys with digit d in waves < w).       256 threads, thread t owns digits 2t, 2t+1.
+//   pos[w][d] = (#keys with digit < d) + (#keys with digit d in waves < w).       thread t < 256 owns digits 2t, 2t+1.
 __device__ __forceinline__ void digit_bases_packed(uint32_t (*cnt)[256], uint32_t* lds4) {
     const unsigned t = threadIdx.x;
-    const uint32_t c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
-    const uint32_t s = c0 + c1 + c2 + c3;                               // halves add independently (each total <= 4096)
+    uint32_t c[TS_WAVES], s = 0;
+    if (t < 256) {
+#pragma unroll
+        for (int k = 0; k < TS_WAVES; k++) { c[k] = cnt[k][t]; s += c[k]; }        // halves add independently (each total <= 4096)
+    }
     const uint32_t lo = s & 0xffffu, hi = s >> 16;
-    uint32_t tot;
-    const uint32_t base = block_excl_scan(lo + hi, lds4, &tot);
-    const uint32_t b0 = base | ((base + lo) << 16);                     // wave 0: digit 2t starts at base, digit 2t+1 after all of 2t
-    cnt[0][t] = b0; cnt[1][t] = b0 + c0; cnt[2][t] = b0 + c0 + c1; cnt[3][t] = b0 + c0 + c1 + c2;
+    const uint32_t base = scan_first_256(lo + hi, lds4);
+    if (t < 256) {
+        uint32_t b = base | ((base + lo) << 16);                        // wave 0: digit 2t starts at base, digit 2t+1 after all of 2t
+#pragma unroll
+        for (int k = 0; k < TS_WAVES; k++) { cnt[k][t] = b; b += c[k]; }
+    }
     __syncthreads();
 }
 
-// Oversize path: full-width counters, thread t owns digits 2t and 2t+1.
+// Oversize path: full-width counters, thread t < 256 owns digits 2t and 2t+1.
 __device__ __forceinline__ void digit_bases_wide(uint32_t (*cnt)[TS_DIGITS], uint32_t* lds4) {
     const unsigned t = threadIdx.x;
-    uint32_t a[4], b[4];
+    uint32_t a[TS_WAVES], b[TS_WAVES], sa = 0, sb = 0;
+    if (t < 256) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) { a[k] = cnt[k][2 * t]; b[k] = cnt[k][2 * t + 1]; }
-    const uint32_t sa = a[0] + a[1] + a[2] + a[3], sb = b[0] + b[1] + b[2] + b[3];
-    uint32_t tot;
-    uint32_t ba = block_excl_scan(sa + sb, lds4, &tot), bb = ba + sa;
+        for (int k = 0; k < TS_WAVES; k++) { a[k] = cnt[k][2 * t]; b[k] = cnt[k][2 * t + 1]; sa += a[k]; sb += b[k]; }
+    }
+    uint32_t ba = scan_first_256(sa + sb, lds4), bb = ba + sa;
+    if (t < 256) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) { cnt[k][2 * t] = ba; cnt[k][2 * t + 1] = bb; ba += a[k]; bb += b[k]; }
+        for (int k = 0; k < TS_WAVES; k++) { cnt[k][2 * t] = ba; cnt[k][2 * t + 1] = bb; ba += a[k]; bb += b[k]; }
+    }
     __syncthreads();
 }
 
@@ -319,29 +368,29 @@ __global__ void k_check_lds_atomic_order(uint32_t* __restrict__ violations) {
 }
 
 // min and max over the workgroup of one value per thread (both returned to every thread)
-__device__ __forceinline__ void block_min_max(uint32_t& mn, uint32_t& mx, uint32_t* lds8) {
+__device__ __forceinline__ void block_min_max(uint32_t& mn, uint32_t& mx, uint32_t* lds2w) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
     }
     const unsigned w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { lds8[w] = mn; lds8[4 + w] = mx; }
+    if ((threadIdx.x & 63) == 0) { lds2w[w] = mn; lds2w[TS_WAVES + w] = mx; }
     __syncthreads();
-    mn = min(min(lds8[0], lds8[1]), min(lds8[2], lds8[3]));
-    mx = max(max(lds8[4], lds8[5]), max(lds8[6], lds8[7]));
+#pragma unroll
+    for (int k = 0; k < TS_WAVES; k++) { mn = min(mn, lds2w[k]); mx = max(mx, lds2w[TS_WAVES + k]); }
     __syncthreads();
 }
 
 template <bool RANK_ATOMIC>
-__global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
+__global__ __launch_bounds__(TS_THREADS) void k_tile_sort(int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
                                                     const uint64_t* __restrict__ total, uint32_t R /* capacity */,
                                                     int index_passes, uint64_t* __restrict__ pairs,
                                                     uint64_t* __restrict__ scratch, uint32_t* __restrict__ point_list,
                                                     uint2* __restrict__ ranges) {
     __shared__ uint64_t xbuf[TS_CAP];
-    __shared__ uint32_t cnt[4][256];
-    __shared__ uint32_t lds8[8];
+    __shared__ uint32_t cnt[TS_WAVES][256];
+    __shared__ uint32_t lds8[2 * TS_WAVES];
     const int tile = blockIdx.x;
     const uint32_t beg = table_scanned[(size_t)tile * nblocks];
     const uint32_t end = tile + 1 < n_tiles ? table_scanned[(size_t)(tile + 1) * nblocks] : (uint32_t)*total;
@@ -350,7 +399,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks
     if (n == 0) return;
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
-    const uint32_t chunk = ((n + 3) / 4 + 63) & ~63u;               // per-wave quarter, multiple of 64
+    const uint32_t chunk = ((n + TS_WAVES - 1) / TS_WAVES + 63) & ~63u;       // per-wave share, multiple of 64
     const uint32_t wbeg = w * chunk;
 
     if (n <= TS_CAP) {
@@ -372,7 +421,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks
         const int npass = index_passes + depth_passes;
         for (int phase = depth_passes ? 0 : 1; phase < 2; phase++) {
             for (int p = phase == 0 ? index_passes : 0; p < npass; p++) {
-                cnt[0][threadIdx.x] = 0; cnt[1][threadIdx.x] = 0; cnt[2][threadIdx.x] = 0; cnt[3][threadIdx.x] = 0;
+                for (int k = threadIdx.x; k < TS_WAVES * 256; k += TS_THREADS) cnt[0][k] = 0;
                 __syncthreads();
                 uint32_t rank[TS_ITEMS];
 #pragma unroll
@@ -426,12 +475,12 @@ __global__ __launch_bounds__(256) void k_tile_sort(int n_tiles, uint32_t nblocks
     uint64_t* src = pairs + beg;
     uint64_t* dst = scratch + beg;
     uint32_t dmin = 0xffffffffu, dmax = 0u;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) { const uint32_t dw = (uint32_t)(src[i] >> 32); dmin = min(dmin, dw); dmax = max(dmax, dw); }
+    for (uint32_t i = threadIdx.x; i < n; i += TS_THREADS) { const uint32_t dw = (uint32_t)(src[i] >> 32); dmin = min(dmin, dw); dmax = max(dmax, dw); }
     block_min_max(dmin, dmax, lds8);
     const int depth_passes = (32 - __clz((int)(dmax - dmin)) + TS_DBITS - 1) / TS_DBITS;
     const int npass = index_passes + depth_passes;
     for (int p = 0; p < npass; p++) {
-        for (int k = threadIdx.x; k < 4 * TS_DIGITS; k += 256) reinterpret_cast<uint32_t*>(xbuf)[k] = 0;
+        for (int k = threadIdx.x; k < TS_WAVES * TS_DIGITS; k += TS_THREADS) reinterpret_cast<uint32_t*>(xbuf)[k] = 0;
         __syncthreads();
         for (uint32_t r0 = 0; r0 < chunk; r0 += 64) {                  // count
             const uint32_t i = wbeg + r0 + lane;
@@ -501,7 +550,10 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     if (R64 == 0 || P == 0) return egs_launch_zero_u32((uint32_t*)im.ranges, 2 * (size_t)n_tiles, s);
     const uint32_t R = (uint32_t)R64;
     const uint32_t nblocks = egs_bin_blocks(P);
-    const size_t lds = (size_t)n_tiles * sizeof(uint32_t);
+    int cull = egs_tile_culling;
+    // per-tile counters, then (16-byte aligned) one 2 KiB ellipse-parameter slice per wave
+    size_t lds = (size_t)((n_tiles + 3) & ~3) * sizeof(uint32_t) + (size_t)(EGS_BIN_THREADS / 64) * 128 * sizeof(float4);
+    if (lds > 160 * 1024) { cull = 0; lds = (size_t)n_tiles * sizeof(uint32_t); }     // > 30k tiles: counters alone fill the LDS
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -509,12 +561,12 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
         if (e != hipSuccess) return e;
     }
     egs_prof_start(EGS_K_DUPLICATE, s);
-    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, b.table);
+    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, W, H, b.table);
     EGS_DBG(s);
     hipError_t e = egs_launch_scan_u32(b.table, b.table, (size_t)n_tiles * nblocks, 0, b.spine, b.total, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_bin_scatter, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
-                       b.table, R, b.pairs);
+                       cull, W, H, b.table, R, b.pairs);
     egs_prof_stop(EGS_K_DUPLICATE, s);
     EGS_DBG(s);
     int index_bits = 0; while (((unsigned)(P - 1) >> index_bits) != 0) index_bits++;
@@ -537,10 +589,10 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     if (egs_force_ballot_rank) fast = 0;
     egs_prof_start(EGS_K_SORT, s);
     if (fast)
-        hipLaunchKernelGGL(k_tile_sort<true>, dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, b.total, R,
+        hipLaunchKernelGGL(k_tile_sort<true>, dim3(n_tiles), dim3(TS_THREADS), 0, s, n_tiles, nblocks, b.table, b.total, R,
                            (index_bits + TS_DBITS - 1) / TS_DBITS, b.pairs, b.scratch, b.point_list, im.ranges);
     else
-        hipLaunchKernelGGL(k_tile_sort<false>, dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, b.total, R,
+        hipLaunchKernelGGL(k_tile_sort<false>, dim3(n_tiles), dim3(TS_THREADS), 0, s, n_tiles, nblocks, b.table, b.total, R,
                            (index_bits + TS_DBITS - 1) / TS_DBITS, b.pairs, b.scratch, b.point_list, im.ranges);
     egs_prof_stop(EGS_K_SORT, s);
     EGS_DBG(s);

@@ -30,13 +30,10 @@ __device__ __forceinline__ void egs_load_rec(const float4* __restrict__ rec, uin
 //      log2(1/(255 o)) -- below that, alpha < 1/255 for every pixel of the block.  If the centre is outside the
 //      block the maximum sits on one of the (at most two) edges facing the centre, at the clamped 1-D optimum.
 // Runs once per staged splat (one lane each), i.e. 1/64 of an instruction per candidate per wave, and removes the
-// (wave, splat) visits that a bounding box cannot: diagonal / elongated splats and block corners.
-__device__ __forceinline__ bool egs_block_hits(const float4& c0, const float4& c1, const float4& c2, uint32_t qx0,
-                                               uint32_t qx1, uint32_t qy0, uint32_t qy1) {
-    const uint32_t bx = __float_as_uint(c2.z), by = __float_as_uint(c2.w);
-    const uint32_t x0 = bx & 0xffffu, x1 = bx >> 16, y0 = by & 0xffffu, y1 = by >> 16;
-    if (!(x0 <= qx1 && x1 >= qx0 && y0 <= qy1 && y1 >= qy0)) return false;
-    const float cx = c0.x, cy = c0.y, qa = c0.z, qb = c0.w, qc = c1.x;
+// (wave, splat) visits that a bounding box cannot: diagonal / elongated splats and block corners.  The ellipse stage alone
+// is also what the tile bucketing applies to whole 16x16 tiles (binning.hip).
+__device__ __forceinline__ bool egs_ellipse_hits(float cx, float cy, float qa, float qb, float qc, float opacity, uint32_t qx0,
+                                                 uint32_t qx1, uint32_t qy0, uint32_t qy1) {
     const float lx = (float)qx0 - cx, hx = (float)qx1 - cx, ly = (float)qy0 - cy, hy = (float)qy1 - cy;
     const float dxe = fminf(fmaxf(0.f, lx), hx), dye = fminf(fmaxf(0.f, ly), hy);      // nearest block point to the centre
     if (dxe == 0.f && dye == 0.f) return true;                                           // centre inside the block
@@ -45,8 +42,16 @@ __device__ __forceinline__ bool egs_block_hits(const float4& c0, const float4& c
     const float dxs = fminf(fmaxf(-0.5f * qb * dye * __builtin_amdgcn_rcpf(qa), lx), hx);     // best dx on the line dy = dye
     const float q1 = qa * dxe * dxe + qb * dxe * dys + qc * dys * dys;
     const float q2 = qa * dxs * dxs + qb * dxs * dye + qc * dye * dye;
-    const float need = -__builtin_amdgcn_logf(255.f * c1.y) - 0.03f;                     // log2(1/(255 o)), with a rounding margin
+    const float need = -__builtin_amdgcn_logf(255.f * opacity) - 0.03f;                  // log2(1/(255 o)), with a rounding margin
     return !(fmaxf(q1, q2) < need);                                                      // NaN anywhere -> keep
+}
+
+__device__ __forceinline__ bool egs_block_hits(const float4& c0, const float4& c1, const float4& c2, uint32_t qx0,
+                                               uint32_t qx1, uint32_t qy0, uint32_t qy1) {
+    const uint32_t bx = __float_as_uint(c2.z), by = __float_as_uint(c2.w);
+    const uint32_t x0 = bx & 0xffffu, x1 = bx >> 16, y0 = by & 0xffffu, y1 = by >> 16;
+    if (!(x0 <= qx1 && x1 >= qx0 && y0 <= qy1 && y1 >= qy0)) return false;
+    return egs_ellipse_hits(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, qx0, qx1, qy0, qy1);
 }
 
 // log2 of the Gaussian falloff from the pre-scaled conic (egs_common.h): qa dx^2 + qb dx dy + qc dy^2.

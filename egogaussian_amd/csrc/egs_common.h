@@ -99,3 +99,4 @@ hipError_t egs_launch_zero_u32(uint32_t* p, size_t n, hipStream_t s);
 void egs_prof_start(int stage, hipStream_t s);
 void egs_prof_stop(int stage, hipStream_t s);
 extern int egs_force_ballot_rank;
+extern int egs_tile_culling;

@@ -28,16 +28,29 @@
 
 namespace {
 
+#ifdef EGS_FWD_WAVE_BLOCKS
+__global__ __launch_bounds__(64) void k_render_forward(
+#else
 __global__ __launch_bounds__(256) void k_render_forward(
+#endif
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ quad_work) {
+#ifdef EGS_FWD_WAVE_BLOCKS      // experiment: one wave per workgroup, occupancy capped by LDS padding -> the dispatcher balances
+    __shared__ float4 lds[1][64 * EGS_SPLAT_REC_F4];
+    const unsigned wi = blockIdx.x / EGS_XCDS;
+    const int tile = egs_tile_of_block((wi / 4) * EGS_XCDS + blockIdx.x % EGS_XCDS, n_tiles);
+    if (tile < 0) return;
+    const unsigned lane = threadIdx.x, q = wi % 4;
+    float4* my = lds[0];
+#else
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
     const int tile = egs_tile_of_block(blockIdx.x, n_tiles);
     if (tile < 0) return;
     const unsigned lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     float4* my = lds[q];
+#endif
     const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
     if (qx0 >= W || qy0 >= H) { if (lane == 0) quad_work[tile * 4 + q] = 0; return; }   // quadrant entirely outside the image
     const int px = qx0 + (int)(lane & 7), py = qy0 + (int)(lane >> 3);
@@ -53,6 +66,10 @@ __global__ __launch_bounds__(256) void k_render_forward(
     // Tf: the value final_T reports.  Invariant while live: Tl == Tf >= 1e-4.
     float Tl = inside ? 1.f : 0.f, Tf = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f, Aacc = 0.f;
     uint32_t last = 0;
+#ifdef EGS_MEASURE           // instrumentation builds only (tools/lane_use.py): 1 = (wave, splat) visits, 2 = kept lanes, 3 = timeline
+    uint32_t meas = 0;
+    const uint64_t t_start = wall_clock64();
+#endif
 
     // software pipeline: ids two batches ahead, records one batch ahead
     uint32_t id_next = lane < n ? list[lane] : 0u;
@@ -88,6 +105,9 @@ __global__ __launch_bounds__(256) void k_render_forward(
             Tl = cont ? test : 0.f;
             last = w > 0.f ? base + (uint32_t)j + 1u : last;
             alive = __ballot(cont) != 0ull;                       // whole quadrant saturated -> leave
+#ifdef EGS_MEASURE
+            meas += EGS_MEASURE != 2 ? 1u : (uint32_t)__popcll(__ballot(w > 0.f));
+#endif
         } while (mask != 0ull && alive);
         __builtin_amdgcn_wave_barrier();
     }
@@ -97,6 +117,9 @@ __global__ __launch_bounds__(256) void k_render_forward(
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
         if (lane == 0) quad_work[tile * 4 + q] = wmax;
+#ifdef EGS_MEASURE
+        if (lane == 0) quad_work[tile * 4 + q] = meas;
+#endif
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
@@ -104,6 +127,19 @@ __global__ __launch_bounds__(256) void k_render_forward(
         out_color[pix] = fmaf(T, bg[0], C0); out_color[HW + pix] = fmaf(T, bg[1], C1);
         out_color[2 * HW + pix] = fmaf(T, bg[2], C2);
         out_depth[pix] = Dacc; out_alpha[pix] = Aacc;
+#if defined(EGS_MEASURE) && EGS_MEASURE == 3
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (lane == 0) n_contrib[pix] = (uint32_t)t_start;
+        if (lane == 1) n_contrib[pix] = (uint32_t)wall_clock64();
+        if (lane == 2) n_contrib[pix] = ((xcc & 0xfu) << 16) | (hw & 0xffffu);
+        if (lane == 3) n_contrib[pix] = n;
+        if (lane == 4) n_contrib[pix] = meas;
+        uint32_t wm = last;
+        for (int d = 32; d >= 1; d >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, d, 64));
+        if (lane == 5) n_contrib[pix] = wm;
+#endif
     }
 }
 
@@ -115,6 +151,11 @@ hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs 
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
     if (n_tiles == 0) return hipSuccess;
+#ifdef EGS_FWD_WAVE_BLOCKS
+    hipLaunchKernelGGL(k_render_forward, dim3(egs_blocks_for_tiles(n_tiles) * 4), dim3(64), EGS_FWD_WAVE_BLOCKS, s, W, H, gx, n_tiles,
+                       im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, im.quad_work);
+    return hipGetLastError();
+#endif
     hipLaunchKernelGGL(k_render_forward, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                        im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, im.quad_work);
     return hipGetLastError();

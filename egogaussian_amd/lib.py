@@ -59,6 +59,7 @@ SIGNATURES = {
     "egs_adam_step_capturable": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
     "egs_knn3_mean_dist2": (C.c_int, [i32, vp, vp, vp]),
     "egs_debug_force_ballot_rank": (C.c_int, [i32]),
+    "egs_debug_set_tile_culling": (C.c_int, [i32]),
     "egs_profile_begin": (C.c_int, [i32]),
     "egs_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "egs_profile_stage_name": (C.c_char_p, [i32]),

@@ -227,6 +227,14 @@ int egs_knn3_mean_dist2(int N, const float* points /*[N,3]*/, float* mean_dist2 
  * process; on != 0 forces the ballot-based fallback so that tests can cover it.  Returns the previous setting. */
 int egs_debug_force_ballot_rank(int on);
 
+/* Tile culling (default on): an instance (splat, tile) of the reference's 3-sigma rectangle is dropped when no pixel of the
+ * tile can receive alpha >= 1/255 from the splat (exact, conservative ellipse-vs-tile test).  The reference skips such an
+ * instance at every pixel, so colour, depth, alpha, final transmittance and all gradients are bit-identical either way;
+ * only the internal lists (binning buffer, per-pixel contributor positions) get shorter.  `num_rendered` stays the
+ * reference's count.  on == 0 keeps every instance, which makes the internal lists comparable bit for bit with the
+ * reference algorithm's (used by the parity tests).  Returns the previous setting; applies to subsequent forwards. */
+int egs_debug_set_tile_culling(int on);
+
 /* ---- optional per-stage timing with HIP events on the caller's stream (bench / profiling aid) ------
  * The only process-wide state in the library; off by default.  egs_profile_begin allocates an event pool and
  * turns recording on; every stage launched afterwards is bracketed by two events on its stream;

