@@ -179,7 +179,10 @@ __device__ __forceinline__ void for_each_instance(unsigned bid, int P, const uin
         if (cnt) { rc = rect[i]; if (need_depth) dbits = __float_as_uint(rec[(size_t)i * EGS_SPLAT_REC_F4 + 2].y); }
         if (cull) {
             __builtin_amdgcn_wave_barrier();                            // earlier readers of the slice are done
-            if (cnt) { stage[2 * lane] = rec[(size_t)i * EGS_SPLAT_REC_F4]; stage[2 * lane + 1] = rec[(size_t)i * EGS_SPLAT_REC_F4 + 1]; }
+            if (cnt) {
+                const float4 r0 = rec[(size_t)i * EGS_SPLAT_REC_F4], r1 = rec[(size_t)i * EGS_SPLAT_REC_F4 + 1];
+                stage[2 * lane] = r0; stage[2 * lane + 1] = egs_ellipse_prep(r0.z, r0.w, r1.x, r1.y);
+            }
             __builtin_amdgcn_wave_barrier();
         }
         for (uint32_t s0 = 0; s0 < total; s0 += 64) {
@@ -198,12 +201,16 @@ __device__ __forceinline__ void for_each_instance(unsigned bid, int P, const uin
                 const uint32_t k = s - ost;
                 const uint32_t x0 = orc.x & 0xffffu, x1 = orc.x >> 16, y0 = orc.y & 0xffffu;
                 const uint32_t wd = x1 - x0;
-                const uint32_t ty = y0 + k / wd, tx = x0 + k % wd;
+                uint32_t row = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)wd));      // k < 2^24: off by at most one
+                uint32_t col = k - row * wd;
+                if ((int)col < 0) { row--; col += wd; }
+                if (col >= wd) { row++; col -= wd; }
+                const uint32_t ty = y0 + row, tx = x0 + col;
                 bool keep = true;
                 if (cull) {
-                    const float4 e0 = stage[2 * lo], e1 = stage[2 * lo + 1];             // (x, y, qa, qb), (qc, opacity, ..)
-                    keep = egs_ellipse_hits(e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, tx * EGS_TILE, min(tx * EGS_TILE + EGS_TILE - 1, (uint32_t)W - 1),
-                                            ty * EGS_TILE, min(ty * EGS_TILE + EGS_TILE - 1, (uint32_t)H - 1));
+                    const float4 e0 = stage[2 * lo], e1 = stage[2 * lo + 1];             // (x, y, qa, qb), (qc, need, sy, sx)
+                    keep = egs_ellipse_hits_prepped(e0, e1, tx * EGS_TILE, min(tx * EGS_TILE + EGS_TILE - 1, (uint32_t)W - 1),
+                                                    ty * EGS_TILE, min(ty * EGS_TILE + EGS_TILE - 1, (uint32_t)H - 1));
                 }
                 if (keep) body(ty * (uint32_t)gx + tx, (uint32_t)(g0 + lo), odb);
             }

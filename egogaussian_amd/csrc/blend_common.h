@@ -46,6 +46,26 @@ __device__ __forceinline__ bool egs_ellipse_hits(float cx, float cy, float qa, f
     return !(fmaxf(q1, q2) < need);                                                      // NaN anywhere -> keep
 }
 
+// The same test with the per-splat quantities hoisted (tile bucketing: computed once per splat, used for every tile of
+// its rectangle):  need = log2(1/(255 o)) - margin,  sy = -qb/(2 qc),  sx = -qb/(2 qa).
+__device__ __forceinline__ float4 egs_ellipse_prep(float qa, float qb, float qc, float opacity) {
+    return make_float4(qc, -__builtin_amdgcn_logf(255.f * opacity) - 0.03f, -0.5f * qb * __builtin_amdgcn_rcpf(qc),
+                       -0.5f * qb * __builtin_amdgcn_rcpf(qa));
+}
+__device__ __forceinline__ bool egs_ellipse_hits_prepped(const float4& e0 /*x, y, qa, qb*/, const float4& e1 /*qc, need, sy, sx*/,
+                                                         uint32_t qx0, uint32_t qx1, uint32_t qy0, uint32_t qy1) {
+    const float qa = e0.z, qb = e0.w, qc = e1.x;
+    const float lx = (float)qx0 - e0.x, hx = (float)qx1 - e0.x, ly = (float)qy0 - e0.y, hy = (float)qy1 - e0.y;
+    const float dxe = fminf(fmaxf(0.f, lx), hx), dye = fminf(fmaxf(0.f, ly), hy);
+    if (dxe == 0.f && dye == 0.f) return true;
+    if (!(qa < 0.f && qc < 0.f)) return true;
+    const float dys = fminf(fmaxf(e1.z * dxe, ly), hy);
+    const float dxs = fminf(fmaxf(e1.w * dye, lx), hx);
+    const float q1 = qa * dxe * dxe + qb * dxe * dys + qc * dys * dys;
+    const float q2 = qa * dxs * dxs + qb * dxs * dye + qc * dye * dye;
+    return !(fmaxf(q1, q2) < e1.y);
+}
+
 __device__ __forceinline__ bool egs_block_hits(const float4& c0, const float4& c1, const float4& c2, uint32_t qx0,
                                                uint32_t qx1, uint32_t qy0, uint32_t qy1) {
     const uint32_t bx = __float_as_uint(c2.z), by = __float_as_uint(c2.w);

@@ -205,6 +205,28 @@ def test_tile_culling_changes_no_output_bit(N, H, W, seed, mode, smul):
     assert np.array_equal(key_a[np.isin(key_a, key_b)], key_b)      # an ordered sub-list of the full list
 
 
+def test_4k_image_32400_tiles():
+    """3840x2160 = 32400 tiles: the per-tile counters of the bucketing kernels take 127 KiB of the 160 KiB LDS (one
+    workgroup per CU).  Lists and image vs the oracle, with the reference's rectangles and with tile culling."""
+    from egogaussian_amd import _C
+    dev = _dev()
+    N, H, W = 3000, 2160, 3840
+    d = make_inputs(N, H, W, 11, 0, "sh_cov", scale_mul=6.0)
+    o, st = oracle_forward(d)
+    for cull in (False, True):
+        with tile_culling(cull):
+            g, out = hip_forward(d, dev)
+        bv = _C.binning_views(out[6], N, out[0], W, H, _C.stats["capacity"]); iv = _C.image_views(out[7], W, H)
+        assert out[0] == st["R"] and st["R"] > N
+        pl, rng = bv["point_list"].cpu().numpy().view(np.uint32), iv["ranges"].cpu().numpy().view(np.uint32)
+        if cull:
+            kept, dropped = check_culled_lists(st, rng, pl, H, W)
+            assert dropped > 0
+        else:
+            assert np.array_equal(pl, st["point_list"]) and np.array_equal(rng, st["ranges"])
+        assert outlier_fraction(out[1].cpu().numpy(), st["color"], TOL) <= 1e-4
+
+
 def test_empty_and_culled_inputs():
     from egogaussian_amd import _C
     dev = _dev()
