@@ -4,137 +4,243 @@
 //     l1_loss, ssim           /root/reference/utils/loss_utils.py:57-107  (11x11 Gaussian window, sigma 1.5, zero padding,
 //                                                                          C1 = 0.01^2, C2 = 0.03^2)
 //     loss assembly, hand-mask gradient gate   /root/reference/trainers/train_static.py:91-95
-// Forward: one pass per (channel, 16x16 tile): x and y tiles with a 5-pixel halo are staged in LDS once, the five
-// windowed moments (E[x], E[y], E[x^2], E[y^2], E[xy]) are produced by a separable 11-tap blur inside LDS, the SSIM map
-// value is reduced per block, and the three partial derivatives of the map (w.r.t. E[x], E[x^2], E[xy]) are stored.
-// Backward: the same tiling blurs those three maps (the window is symmetric, so the adjoint of the blur is the blur)
-// and adds the L1 term and the optional per-pixel gradient gate.  HBM-bound: 8 B in + 12 B out per pixel-channel
-// forward, 20 B in + 4 B out backward.
+// Forward: the five windowed moments (E[x], E[y], E[x^2], E[y^2], E[xy]) come from a separable 11-tap blur, the SSIM
+// map value is summed per wave, and the three partial derivatives of the map (w.r.t. E[x], E[x^2], E[xy]) are stored.
+// Backward: the same machinery blurs those three maps (the window is symmetric, so the adjoint of the blur is the blur)
+// and adds the L1 term and the optional per-pixel gradient gate.  8 B in + 12 B out per pixel-channel forward,
+// 20 B in + 4 B out backward (+ 10/SR halo rows and 10/54 halo columns re-read).
 #include "egs_common.h"
 
-#define LT 16                 // output tile edge
+// Mapping (wave64 streaming, no workgroup barriers): a wave owns a strip of SW = 54 output columns x SR output rows of
+// one channel.  Lane L is image column  strip_x0 - 5 + L  (5 halo columns each side) and walks DOWN the rows:
+//   * vertical 11-tap blur in registers: the last 11 rows of the per-pixel products (x, y, x^2, y^2, xy -- or the three
+//     derivative maps in the backward) live in a register window that is rotated by full unrolling, never moved;
+//   * horizontal 11-tap blur across lanes through a wave-private LDS row (one write, 11 broadcast-free reads per map);
+//   * rows are read from HBM exactly once per strip (+10 halo rows per SR) with fully coalesced 256-byte accesses.
+// The old tiling (16x16 outputs per 256-thread workgroup, 26x26 inputs staged in LDS, three __syncthreads) spent its time
+// waiting: 3 rounds of latency-bound workgroups, 30 us + 25 us at 3x540x960; this one is bound by VALU/LDS issue.
 #define HALO 5
-#define LW (LT + 2 * HALO)    // 26
+#define SW 54                 // useful columns per wave (64 lanes - 2 * HALO)
+#define SR 15                 // output rows per wave (3 x 540 x 960: 1944 waves, just under 2 per SIMD)
+#define WPB 2                 // waves per workgroup (independent)
 
 namespace {
 
 // gaussian(11, 1.5) normalised, as float32 (utils/loss_utils.py:66-68)
-__device__ __constant__ float kWin[11] = { 1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f,
-                                           2.130055279e-01f, 2.660117149e-01f, 2.130055279e-01f, 1.093606874e-01f,
-                                           3.600077331e-02f, 7.598758209e-03f, 1.028380124e-03f };
-
-__device__ __forceinline__ float block_sum_256(float v, float* lds4) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+#define KW0 1.028380124e-03f
+#define KW1 7.598758209e-03f
+#define KW2 3.600077331e-02f
+#define KW3 1.093606874e-01f
+#define KW4 2.130055279e-01f
+#define KW5 2.660117149e-01f
+__device__ __forceinline__ constexpr float kwin(int k) {
+    return k == 0 || k == 10 ? KW0 : k == 1 || k == 9 ? KW1 : k == 2 || k == 8 ? KW2 : k == 3 || k == 7 ? KW3 : k == 4 || k == 6 ? KW4 : KW5;
 }
 
-// grid: (tiles_x, tiles_y, C); block 256 = 16x16 outputs
-__global__ __launch_bounds__(256) void k_l1_ssim_forward(int H, int W, const float* __restrict__ img,
-                                                          const float* __restrict__ gt, float* __restrict__ partial,
-                                                          float* __restrict__ dm_dmu1, float* __restrict__ dm_dexx,
-                                                          float* __restrict__ dm_dexy) {
-    __shared__ float sx[LW][LW + 1], sy[LW][LW + 1];
-    __shared__ float hb[5][LW][LT + 1];          // horizontally blurred x, y, xx, yy, xy for 26 rows x 16 columns
-    __shared__ float red[8];
-    const int c = blockIdx.z, x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
-    const size_t plane = (size_t)c * H * W;
-    for (int t = threadIdx.x; t < LW * LW; t += 256) {
-        const int ly = t / LW, lx = t % LW, gy = y0 + ly - HALO, gx = x0 + lx - HALO;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        sx[ly][lx] = in ? img[plane + (size_t)gy * W + gx] : 0.f;
-        sy[ly][lx] = in ? gt[plane + (size_t)gy * W + gx] : 0.f;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < LW * LT; t += 256) {
-        const int ly = t / LT, lx = t % LT;
-        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+// Horizontal blur of NV values per lane (= per column) through the wave's LDS rows: out[m] = sum_k w[k] v[m][lane - 5 + k].
+// All NV rows are written, then all reads are issued together: one LDS round trip per image row, not one per map.
+// Lanes 0..4 and 59..63 read the rows' zero padding and return values nobody uses.
+template <int NV>
+__device__ __forceinline__ void hblur(const float (&v)[NV], float (&out)[NV], float* rows /* [NV][80], lane L at [8 + L] */, unsigned lane) {
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = kWin[k], u = sx[ly][lx + k], v = sy[ly][lx + k];
-            a = fmaf(w, u, a); b = fmaf(w, v, b); aa = fmaf(w, u * u, aa); bb = fmaf(w, v * v, bb); ab = fmaf(w, u * v, ab);
-        }
-        hb[0][ly][lx] = a; hb[1][ly][lx] = b; hb[2][ly][lx] = aa; hb[3][ly][lx] = bb; hb[4][ly][lx] = ab;
-    }
-    __syncthreads();
-    const int lx = threadIdx.x % LT, ly = threadIdx.x / LT, gx = x0 + lx, gy = y0 + ly;
-    float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+    for (int m = 0; m < NV; m++) rows[m * 80 + 8 + lane] = v[m];
+    __builtin_amdgcn_wave_barrier();
+    float r[NV][11];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = kWin[k];
-        mu1 = fmaf(w, hb[0][ly + k][lx], mu1); mu2 = fmaf(w, hb[1][ly + k][lx], mu2);
-        exx = fmaf(w, hb[2][ly + k][lx], exx); eyy = fmaf(w, hb[3][ly + k][lx], eyy); exy = fmaf(w, hb[4][ly + k][lx], exy);
+    for (int m = 0; m < NV; m++)
+#pragma unroll
+        for (int k = 0; k < 11; k++) r[m][k] = rows[m * 80 + 3 + lane + k];          // r[m][k] = v[m][lane - 5 + k]
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < NV; m++) {
+        float acc = kwin(0) * (r[m][0] + r[m][10]);             // the window is symmetric: 6 multiplies instead of 11
+        acc = fmaf(kwin(1), r[m][1] + r[m][9], acc); acc = fmaf(kwin(2), r[m][2] + r[m][8], acc);
+        acc = fmaf(kwin(3), r[m][3] + r[m][7], acc); acc = fmaf(kwin(4), r[m][4] + r[m][6], acc);
+        out[m] = fmaf(kwin(5), r[m][5], acc);
     }
-    const bool in = gx < W && gy < H;
-    float l1 = 0.f, sm = 0.f;
-    if (in) {
+}
+
+template <int NV>
+struct Window {                                          // the last 11 rows of NV per-pixel values, slot = row % 11
+    float v[NV][11];
+};
+
+// Vertical blur over the window when the newest row sits in slot `newest` (compile-time): out = sum_k w[k] row[newest+1+k].
+template <int NV, int NEWEST>
+__device__ __forceinline__ void vblur(const Window<NV>& w, float (&out)[NV]) {
+#pragma unroll
+    for (int m = 0; m < NV; m++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) acc = fmaf(kwin(k), w.v[m][(NEWEST + 1 + k) % 11], acc);
+        out[m] = acc;
+    }
+}
+
+struct FwdCtx {
+    int H, W, gx, y_first, y_end; size_t plane; bool col_ok, col_out; unsigned lane;
+    const float* img; const float* gt; float* dm_dmu1; float* dm_dexx; float* dm_dexy; float* rows;   // rows: [5][80] floats
+    float l1, sm;
+};
+
+// One input row enters (slot NEWEST); if 11 rows are in, the output row 5 above it leaves.
+template <int NEWEST>
+__device__ __forceinline__ void fwd_step(FwdCtx& c, Window<5>& w, int y_in, float u, float v) {
+    w.v[0][NEWEST] = u; w.v[1][NEWEST] = v; w.v[2][NEWEST] = u * u; w.v[3][NEWEST] = v * v; w.v[4][NEWEST] = u * v;
+    const int y_out = y_in - HALO;
+    if (y_out < c.y_first || y_out >= c.y_end) return;                  // wave-uniform
+    float vb[5];
+    vblur<5, NEWEST>(w, vb);
+    float hbv[5];
+    hblur<5>(vb, hbv, c.rows, c.lane);
+    const float mu1 = hbv[0], mu2 = hbv[1], exx = hbv[2], eyy = hbv[3], exy = hbv[4];
+    if (c.col_out) {
         const float C1 = 0.0001f, C2 = 0.0009f;
         const float s1 = exx - mu1 * mu1, s2 = eyy - mu2 * mu2, s12 = exy - mu1 * mu2;
         const float A = 2.f * mu1 * mu2 + C1, B = 2.f * s12 + C2, D = mu1 * mu1 + mu2 * mu2 + C1, E = s1 + s2 + C2;
         const float invDE = 1.f / (D * E);
-        sm = A * B * invDE;
+        const float sm = A * B * invDE;
         // partial derivatives of the map holding the other windowed moments fixed
-        const float dmu1 = (2.f * mu2 * (B - A)) * invDE - sm * (2.f * mu1 * (E - D)) * invDE;
-        const float dexx = -sm / E;
-        const float dexy = 2.f * A * invDE;
-        const size_t p = plane + (size_t)gy * W + gx;
-        dm_dmu1[p] = dmu1; dm_dexx[p] = dexx; dm_dexy[p] = dexy;
-        l1 = fabsf(sx[ly + HALO][lx + HALO] - sy[ly + HALO][lx + HALO]);
-    }
-    const float tl1 = block_sum_256(l1, red);
-    __syncthreads();
-    const float tsm = block_sum_256(sm, red + 4);
-    if (threadIdx.x == 0) {
-        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        partial[2 * b] = tl1; partial[2 * b + 1] = tsm;
+        const size_t p = c.plane + (size_t)y_out * c.W + c.gx;
+        c.dm_dmu1[p] = (2.f * mu2 * (B - A)) * invDE - sm * (2.f * mu1 * (E - D)) * invDE;
+        c.dm_dexx[p] = -sm / E;
+        c.dm_dexy[p] = 2.f * A * invDE;
+        constexpr int CENTRE = (NEWEST + 11 - HALO) % 11;               // the row that is leaving sits 5 slots behind the newest
+        c.l1 += fabsf(w.v[0][CENTRE] - w.v[1][CENTRE]);
+        c.sm += sm;
     }
 }
 
-__global__ __launch_bounds__(256) void k_l1_ssim_backward(int H, int W, const float* __restrict__ img,
-                                                           const float* __restrict__ gt, float w_l1, float w_ssim,
-                                                           const float* __restrict__ upstream, const float* __restrict__ gate,
-                                                           const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dexx,
-                                                           const float* __restrict__ dm_dexy, float* __restrict__ dimg) {
-    __shared__ float s[3][LW][LW + 1];
-    __shared__ float hb[3][LW][LT + 1];
-    const int c = blockIdx.z, x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
-    const size_t plane = (size_t)c * H * W;
-    for (int t = threadIdx.x; t < LW * LW; t += 256) {
-        const int ly = t / LW, lx = t % LW, gy = y0 + ly - HALO, gx = x0 + lx - HALO;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t p = plane + (size_t)gy * W + gx;
-        s[0][ly][lx] = in ? dm_dmu1[p] : 0.f; s[1][ly][lx] = in ? dm_dexx[p] : 0.f; s[2][ly][lx] = in ? dm_dexy[p] : 0.f;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < LW * LT; t += 256) {
-        const int ly = t / LT, lx = t % LT;
-        float a = 0.f, b = 0.f, d = 0.f;
+// grid: (ceil(strips_x * strips_y / WPB), 1, C); a wave = one strip
+__global__ __launch_bounds__(64 * WPB) void k_l1_ssim_forward(int H, int W, int strips_x, int strips_y, const float* __restrict__ img,
+                                                               const float* __restrict__ gt, float* __restrict__ partial,
+                                                               float* __restrict__ dm_dmu1, float* __restrict__ dm_dexx,
+                                                               float* __restrict__ dm_dexy) {
+    __shared__ float lds[WPB][5 * 80];
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int strip = blockIdx.x * WPB + (int)wv;
+    if (strip >= strips_x * strips_y) return;
+    for (int k = lane; k < 5 * 80; k += 64) lds[wv][k] = 0.f;           // the padding words stay zero
+    __builtin_amdgcn_wave_barrier();
+    FwdCtx c;
+    c.H = H; c.W = W; c.lane = lane; c.img = img; c.gt = gt; c.dm_dmu1 = dm_dmu1; c.dm_dexx = dm_dexx; c.dm_dexy = dm_dexy;
+    c.rows = lds[wv]; c.plane = (size_t)blockIdx.z * H * W; c.l1 = 0.f; c.sm = 0.f;
+    const int sx = strip % strips_x, sy = strip / strips_x;
+    c.gx = sx * SW - HALO + (int)lane;
+    c.col_ok = c.gx >= 0 && c.gx < W;
+    c.col_out = c.col_ok && lane >= HALO && lane < HALO + SW;
+    c.y_first = sy * SR; c.y_end = min(c.y_first + SR, H);
+    Window<5> w;
+#pragma unroll
+    for (int m = 0; m < 5; m++)
+#pragma unroll
+        for (int k = 0; k < 11; k++) w.v[m][k] = 0.f;
+    // input rows y_first - 5 .. y_end + 4, eleven per trip so that every window slot index is a compile-time constant;
+    // the next trip's 22 loads are in flight while this trip computes (a row-by-row load would expose a full memory
+    // latency per row: 28 rows x ~1 us)
+    auto load_rows = [&](int y0, float (&u)[11], float (&v)[11]) {
 #pragma unroll
         for (int k = 0; k < 11; k++) {
-            const float w = kWin[k];
-            a = fmaf(w, s[0][ly][lx + k], a); b = fmaf(w, s[1][ly][lx + k], b); d = fmaf(w, s[2][ly][lx + k], d);
+            const int y = y0 + k;
+            const bool ok = c.col_ok && y >= 0 && y < H && y < c.y_end + HALO;
+            const size_t p = c.plane + (size_t)(ok ? y : 0) * W + (ok ? c.gx : 0);
+            u[k] = ok ? img[p] : 0.f; v[k] = ok ? gt[p] : 0.f;
         }
-        hb[0][ly][lx] = a; hb[1][ly][lx] = b; hb[2][ly][lx] = d;
-    }
-    __syncthreads();
-    const int lx = threadIdx.x % LT, ly = threadIdx.x / LT, gx = x0 + lx, gy = y0 + ly;
-    if (gx >= W || gy >= H) return;
-    float a = 0.f, b = 0.f, d = 0.f;
+    };
+    float cu[11], cv[11], nu[11], nv[11];
+    load_rows(c.y_first - HALO, cu, cv);
+    for (int y0 = c.y_first - HALO; y0 < c.y_end + HALO; y0 += 11) {
+        load_rows(y0 + 11, nu, nv);
+        fwd_step<0>(c, w, y0, cu[0], cv[0]);         fwd_step<1>(c, w, y0 + 1, cu[1], cv[1]); fwd_step<2>(c, w, y0 + 2, cu[2], cv[2]);
+        fwd_step<3>(c, w, y0 + 3, cu[3], cv[3]);     fwd_step<4>(c, w, y0 + 4, cu[4], cv[4]); fwd_step<5>(c, w, y0 + 5, cu[5], cv[5]);
+        fwd_step<6>(c, w, y0 + 6, cu[6], cv[6]);     fwd_step<7>(c, w, y0 + 7, cu[7], cv[7]); fwd_step<8>(c, w, y0 + 8, cu[8], cv[8]);
+        fwd_step<9>(c, w, y0 + 9, cu[9], cv[9]);     fwd_step<10>(c, w, y0 + 10, cu[10], cv[10]);
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = kWin[k];
-        a = fmaf(w, hb[0][ly + k][lx], a); b = fmaf(w, hb[1][ly + k][lx], b); d = fmaf(w, hb[2][ly + k][lx], d);
+        for (int k = 0; k < 11; k++) { cu[k] = nu[k]; cv[k] = nv[k]; }
     }
-    const size_t p = plane + (size_t)gy * W + gx;
-    const float x = img[p], y = gt[p];
-    const float diff = x - y;
-    const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-    float g = w_l1 * sgn - w_ssim * (a + 2.f * x * b + y * d);     // d loss / d x ; loss uses (1 - mean SSIM)
-    g *= upstream[0];
-    if (gate) g *= gate[(size_t)gy * W + gx];
-    dimg[p] = g;
+    float l1 = c.l1, sm = c.sm;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { l1 += __shfl_xor(l1, d, 64); sm += __shfl_xor(sm, d, 64); }
+    if (lane == 0) {
+        const size_t b = (size_t)blockIdx.z * strips_x * strips_y + strip;
+        partial[2 * b] = l1; partial[2 * b + 1] = sm;
+    }
+}
+
+struct BwdCtx {
+    int H, W, gx, y_first, y_end; size_t plane; bool col_ok, col_out; unsigned lane;
+    const float* img; const float* gt; const float* m0; const float* m1; const float* m2; const float* gate; float* dimg; float* rows;
+    float w_l1, w_ssim, up;
+};
+
+template <int NEWEST>
+__device__ __forceinline__ void bwd_step(BwdCtx& c, Window<3>& w, int y_in, float a, float b, float d, float x, float y) {
+    w.v[0][NEWEST] = a; w.v[1][NEWEST] = b; w.v[2][NEWEST] = d;
+    const int y_out = y_in - HALO;
+    if (y_out < c.y_first || y_out >= c.y_end) return;                  // wave-uniform
+    float vb[3];
+    vblur<3, NEWEST>(w, vb);
+    float hbv[3];
+    hblur<3>(vb, hbv, c.rows, c.lane);
+    const float ba = hbv[0], bb = hbv[1], bd = hbv[2];
+    if (c.col_out) {
+        const size_t p = c.plane + (size_t)y_out * c.W + c.gx;
+        const float diff = x - y;
+        const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        float g = c.w_l1 * sgn - c.w_ssim * (ba + 2.f * x * bb + y * bd);     // d loss / d x ; loss uses (1 - mean SSIM)
+        g *= c.up;
+        if (c.gate) g *= c.gate[(size_t)y_out * c.W + c.gx];
+        c.dimg[p] = g;
+    }
+}
+
+__global__ __launch_bounds__(64 * WPB) void k_l1_ssim_backward(int H, int W, int strips_x, int strips_y, const float* __restrict__ img,
+                                                                const float* __restrict__ gt, float w_l1, float w_ssim,
+                                                                const float* __restrict__ upstream, const float* __restrict__ gate,
+                                                                const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dexx,
+                                                                const float* __restrict__ dm_dexy, float* __restrict__ dimg) {
+    __shared__ float lds[WPB][3 * 80];
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int strip = blockIdx.x * WPB + (int)wv;
+    if (strip >= strips_x * strips_y) return;
+    for (int k = lane; k < 3 * 80; k += 64) lds[wv][k] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    BwdCtx c;
+    c.H = H; c.W = W; c.lane = lane; c.img = img; c.gt = gt; c.m0 = dm_dmu1; c.m1 = dm_dexx; c.m2 = dm_dexy; c.gate = gate; c.dimg = dimg;
+    c.rows = lds[wv]; c.plane = (size_t)blockIdx.z * H * W; c.w_l1 = w_l1; c.w_ssim = w_ssim; c.up = upstream[0];
+    const int sx = strip % strips_x, sy = strip / strips_x;
+    c.gx = sx * SW - HALO + (int)lane;
+    c.col_ok = c.gx >= 0 && c.gx < W;
+    c.col_out = c.col_ok && lane >= HALO && lane < HALO + SW;
+    c.y_first = sy * SR; c.y_end = min(c.y_first + SR, H);
+    Window<3> w;
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int k = 0; k < 11; k++) w.v[m][k] = 0.f;
+    // per trip: the 3 maps of 11 input rows and (x, y) of the 11 rows that leave (5 above), prefetched one trip ahead
+    struct Rows { float a[11], b[11], d[11], x[11], y[11]; };
+    auto load_rows = [&](int y0, Rows& r) {
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const int yi = y0 + k, yo = yi - HALO;
+            const bool ok = c.col_ok && yi >= 0 && yi < H && yi < c.y_end + HALO;
+            const size_t p = c.plane + (size_t)(ok ? yi : 0) * W + (ok ? c.gx : 0);
+            r.a[k] = ok ? dm_dmu1[p] : 0.f; r.b[k] = ok ? dm_dexx[p] : 0.f; r.d[k] = ok ? dm_dexy[p] : 0.f;
+            const bool oo = c.col_out && yo >= c.y_first && yo < c.y_end;
+            const size_t q = c.plane + (size_t)(oo ? yo : 0) * W + (oo ? c.gx : 0);
+            r.x[k] = oo ? img[q] : 0.f; r.y[k] = oo ? gt[q] : 0.f;
+        }
+    };
+    Rows cur, nxt;
+    load_rows(c.y_first - HALO, cur);
+    for (int y0 = c.y_first - HALO; y0 < c.y_end + HALO; y0 += 11) {
+        load_rows(y0 + 11, nxt);
+#define BSTEP(K) bwd_step<K>(c, w, y0 + K, cur.a[K], cur.b[K], cur.d[K], cur.x[K], cur.y[K])
+        BSTEP(0); BSTEP(1); BSTEP(2); BSTEP(3); BSTEP(4); BSTEP(5); BSTEP(6); BSTEP(7); BSTEP(8); BSTEP(9); BSTEP(10);
+#undef BSTEP
+        cur = nxt;
+    }
 }
 
 // Adds up the per-block partial sums and assembles the scalar loss (one workgroup; deterministic order).
@@ -159,18 +265,19 @@ __global__ __launch_bounds__(1024) void k_l1_ssim_finish(size_t nblocks, const f
 extern "C" {
 
 size_t egs_l1_ssim_partial_count(int channels, int height, int width) {
-    return (size_t)channels * ((height + LT - 1) / LT) * ((width + LT - 1) / LT) * 2;
+    return (size_t)channels * ((height + SR - 1) / SR) * ((width + SW - 1) / SW) * 2;
 }
 
 int egs_l1_ssim_forward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
                         float* partial_sums, float* dm_dmu1, float* dm_dexx, float* dm_dexy, float* loss, void* stream) {
     if (channels <= 0 || height <= 0 || width <= 0 || !img || !gt || !partial_sums || !dm_dmu1 || !dm_dexx || !dm_dexy || !loss)
         return EGS_ERR_ARG;
-    dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, channels);
-    hipLaunchKernelGGL(k_l1_ssim_forward, grid, dim3(256), 0, (hipStream_t)stream, height, width, img, gt, partial_sums,
-                       dm_dmu1, dm_dexx, dm_dexy);
+    const int strips_x = (width + SW - 1) / SW, strips_y = (height + SR - 1) / SR;
+    dim3 grid((strips_x * strips_y + WPB - 1) / WPB, 1, channels);
+    hipLaunchKernelGGL(k_l1_ssim_forward, grid, dim3(64 * WPB), 0, (hipStream_t)stream, height, width, strips_x, strips_y, img, gt,
+                       partial_sums, dm_dmu1, dm_dexx, dm_dexy);
     const float n = (float)channels * (float)height * (float)width;
-    hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, (size_t)grid.x * grid.y * grid.z, partial_sums,
+    hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, (size_t)strips_x * strips_y * channels, partial_sums,
                        (1.f - lambda_dssim) / n, lambda_dssim / n, lambda_dssim, loss);
     return (int)hipGetLastError();
 }
@@ -181,8 +288,9 @@ int egs_l1_ssim_backward(int channels, int height, int width, const float* img, 
     if (channels <= 0 || height <= 0 || width <= 0 || !img || !gt || !upstream_grad || !dm_dmu1 || !dm_dexx || !dm_dexy || !dL_dimg)
         return EGS_ERR_ARG;
     const float n = (float)channels * (float)height * (float)width;
-    dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, channels);
-    hipLaunchKernelGGL(k_l1_ssim_backward, grid, dim3(256), 0, (hipStream_t)stream, height, width, img, gt,
+    const int strips_x = (width + SW - 1) / SW, strips_y = (height + SR - 1) / SR;
+    dim3 grid((strips_x * strips_y + WPB - 1) / WPB, 1, channels);
+    hipLaunchKernelGGL(k_l1_ssim_backward, grid, dim3(64 * WPB), 0, (hipStream_t)stream, height, width, strips_x, strips_y, img, gt,
                        (1.f - lambda_dssim) / n, lambda_dssim / n, upstream_grad, gate, dm_dmu1, dm_dexx, dm_dexy, dL_dimg);
     return (int)hipGetLastError();
 }
