@@ -56,6 +56,11 @@ __device__ __forceinline__ float row_sum(float v) {
 // only -- any placement gives the same results).  One workgroup per XCD band ranks the band's tiles by the replay depth
 // the forward recorded and deals them to the 32 CUs in snake order (rank r -> round r/32, CU r%32 or 31 - r%32).
 // The same launch clears the gradient accumulator (workgroups 8..): two short kernels cost more than one.
+// Tried and rejected (round 1, config C, per-wave timelines from tools/lane_use.py): (a) persistent waves pulling
+// (tile, quadrant) tasks, sorted by cost, from one queue per XCD: perfectly balanced and 2.2x slower -- the four waves
+// of a workgroup then work on unrelated tiles and stop sharing list and record lines in the CU's L1; (b) dealing each
+// tile's quadrants to the CU's SIMDs by cost (a wave reads its SIMD from HW_ID): per-SIMD spread +-16% -> +-10%, but the
+// CU-level spread (-12%/+8% of blended splats) then bounds the launch and the longer prologue cancels the 2 us gained.
 #define ORDER_MAX_BAND 2048
 __global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const uint32_t* __restrict__ quad_work,
                                                              uint32_t* __restrict__ tile_order, float4* __restrict__ acc4, size_t n4) {
@@ -98,7 +103,8 @@ __global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const u
     }
 }
 
-__global__ __launch_bounds__(256) void k_render_backward(
+// 8 waves per SIMD (64 VGPRs, one spilled): every wave of a 960x540 frame is resident from the start (-2% vs 70 VGPRs / 7 waves)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_render_backward(
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
@@ -110,6 +116,10 @@ __global__ __launch_bounds__(256) void k_render_backward(
     const unsigned lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     float4* my = lds[q];
     float* myred = red[q];
+#if defined(EGS_MEASURE) && EGS_MEASURE == 4      // instrumentation build (tools/lane_use.py): per-wave timeline of the backward
+    const uint64_t t_start = wall_clock64();
+    uint32_t meas = 0;
+#endif
     const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
     if (qx0 >= W || qy0 >= H) return;
     const int px = qx0 + (int)(lane & 7), py = qy0 + (int)(lane >> 3);
@@ -182,6 +192,9 @@ __global__ __launch_bounds__(256) void k_render_backward(
             a = (base + (uint32_t)j + 1u <= last) ? a : 0.f;            // 0 = this pixel does not use the splat
             const bool contrib = a > 0.f;
             if (__ballot(contrib) == 0ull) continue;
+#if defined(EGS_MEASURE) && EGS_MEASURE == 4
+            meas++;
+#endif
             const float rcp = __builtin_amdgcn_rcpf(1.f - a);
             const float Tn = T * rcp;                                   // transmittance in front of this splat
             const float w = a * Tn;
@@ -215,6 +228,20 @@ __global__ __launch_bounds__(256) void k_render_backward(
         }
         __builtin_amdgcn_wave_barrier();
     }
+#if defined(EGS_MEASURE) && EGS_MEASURE == 4
+    if (inside) {                                                    // n_contrib was consumed above: reuse it as the log
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        uint32_t* log = const_cast<uint32_t*>(n_contrib) + (size_t)py * W + px;
+        if (lane == 0) *log = (uint32_t)t_start;
+        if (lane == 1) *log = (uint32_t)wall_clock64();
+        if (lane == 2) *log = ((xcc & 0xfu) << 16) | (hw & 0xffffu);
+        if (lane == 3) *log = range.y - range.x;
+        if (lane == 4) *log = meas;
+        if (lane == 5) *log = wmax;
+    }
+#endif
 }
 
 }  // namespace

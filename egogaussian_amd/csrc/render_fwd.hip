@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
     // Tf: the value final_T reports.  Invariant while live: Tl == Tf >= 1e-4.
     float Tl = inside ? 1.f : 0.f, Tf = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f, Aacc = 0.f;
     uint32_t last = 0;
+    uint32_t visits = 0;                                            // wave-uniform: splats blended by this quadrant
 #ifdef EGS_MEASURE           // instrumentation builds only (tools/lane_use.py): 1 = (wave, splat) visits, 2 = kept lanes, 3 = timeline
     uint32_t meas = 0;
     const uint64_t t_start = wall_clock64();
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
         do {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1ull;
+            visits++;
             const float4 s0 = my[j * 3 + 0], s1 = my[j * 3 + 1];
             const float2 s2 = *reinterpret_cast<const float2*>(&my[j * 3 + 2]);
             float G;
@@ -112,11 +114,13 @@ __global__ __launch_bounds__(256) void k_render_forward(
         __builtin_amdgcn_wave_barrier();
     }
     const float T = Tf;
-    {   // replay depth of this quadrant = work of its wave in the backward (used to balance that launch)
+    {   // cost of this quadrant's wave in the backward, which replays the same splats up to the deepest pixel's last
+        // contributor: ~10 time units per blended splat + ~18 per batch of 64 list entries scanned (measured per-SIMD
+        // regression, tools/lane_use.py).  Used only to balance that launch.
         uint32_t wmax = last;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
-        if (lane == 0) quad_work[tile * 4 + q] = wmax;
+        if (lane == 0) quad_work[tile * 4 + q] = 10u * visits + 18u * ((wmax + 63u) / 64u);
 #ifdef EGS_MEASURE
         if (lane == 0) quad_work[tile * 4 + q] = meas;
 #endif

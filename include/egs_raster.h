@@ -92,7 +92,7 @@ typedef struct egs_image_layout {
     size_t ranges;         /* uint32[tiles][2] */
     size_t final_T;        /* float[H*W] */
     size_t n_contrib;      /* uint32[H*W] */
-    size_t quad_work;      /* uint32[tiles][4] replay depth of every 8x8 quadrant (max n_contrib), written by the forward */
+    size_t quad_work;      /* uint32[tiles][4] estimated backward cost of every 8x8 quadrant (blended splats and list batches), written by the forward */
     size_t tile_order;     /* uint32[8*ceil(tiles/8)] tile handled by each workgroup of the backward blend */
 } egs_image_layout;
 int egs_get_geom_layout(int P, egs_geom_layout* out);

@@ -25,6 +25,13 @@ with torch.no_grad():
 torch.cuda.synchronize()
 v = _C.image_views(r[7], W, H)
 print("R", r[0], "sum(quad_work)", int(v["quad_work"].long().sum()), "sum(n_contrib)", int(v["n_contrib"].long().sum()))
+if os.environ.get("BACKWARD"):                          # EGS_MEASURE=4 build: the backward logs its timeline into n_contrib
+    gen = torch.Generator().manual_seed(1)
+    gc = torch.rand((3, H, W), generator=gen).to(dev)
+    v["n_contrib"][:, :6][::8] = v["n_contrib"][:, :6][::8]          # (no-op; keeps the view alive)
+    _C.rasterize_gaussians_backward(bg, pc.get_xyz, r[4], e, e, e, 1.0, pc.get_covariance(1.0), rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                                    rs.tanfovy, gc, e, e, pc.get_features, 0, rs.campos, r[5], r[0], r[6], r[7], r[3], False)
+    torch.cuda.synchronize()
 if os.environ.get("TIMELINE"):
     import numpy as np
     nc = v["n_contrib"].cpu().numpy().astype(np.int64)
