@@ -17,6 +17,17 @@ from . import lib as _lib
 stats = {"num_rendered": 0, "capacity": 0, "retries": 0}       # of the most recent forward (read by bench.py / tests)
 _capacity_hint = {}                # device index -> instance capacity the next forward is enqueued against
 _pinned_counts = {}                # device index -> page-locked host buffer for the per-workgroup instance counts
+_running_max = {}                  # device index -> int64[1] device tensor raised to the instance count of every captured forward
+
+
+def set_running_max(device, tensor):
+    """While a training step is being captured (egogaussian_amd/graph.py): the device word that every replayed forward raises
+    to its instance count when that is larger.  None switches the tracking off."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if tensor is None:
+        _running_max.pop(key, None)
+    else:
+        _running_max[key] = tensor
 
 
 def binning_passes(P, W, H):
@@ -117,8 +128,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), _ptr(background), W, H,
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
-                _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), _stream()))
-            R = C.c_int64(cap)                      # layout size; the true count is last_instance_count() after a sync
+                _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), None, _ptr(_running_max.get(key)), _stream()))
+            R = C.c_int64(cap)                      # layout size; the true count is stats["total_view"] after a sync
             rc = 0
         else:
             rc = L.egs_forward(P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
@@ -142,6 +153,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         lay = _lib.BinningLayout()
         L.egs_get_binning_layout(P, cap, W, H, C.byref(lay))
         stats["total_view"] = binning[lay.total:lay.total + 8].view(torch.int64)
+    if P:                                           # radii > 0 as a torch.bool view of bytes the preprocess kernel wrote (no compare kernel)
+        glay = _lib.GeomLayout()
+        L.egs_get_geom_layout(P, C.byref(glay))
+        stats["visible_view"] = geom[glay.visible:glay.visible + P].view(torch.bool)
+    else:
+        stats["visible_view"] = torch.zeros(0, dtype=torch.bool, device=dev)
     return int(R.value), out_color, out_depth, out_alpha, radii, geom, binning, img
 
 
@@ -208,7 +225,8 @@ def geom_views(geom, P):
     _lib.check(_lib.load().egs_get_geom_layout(P, C.byref(lay)))
     v = lambda off, n, dt: geom[off:off + n].view(dt)
     return dict(rec=v(lay.rec, P * 48, torch.float32).view(P, 12), rect=v(lay.rect, P * 8, torch.int32).view(P, 2),
-                offsets=v(lay.offsets, P * 4, torch.int32), clamped=geom[lay.clamped:lay.clamped + P])
+                offsets=v(lay.offsets, P * 4, torch.int32), clamped=geom[lay.clamped:lay.clamped + P],
+                visible=geom[lay.visible:lay.visible + P].view(torch.bool))
 
 
 def binning_views(binning, P, R, W, H, capacity=None):

@@ -18,6 +18,7 @@ GeomLayout geom_layout(int P) {
     L.o.rect = off;         off = egs_align(off + n * sizeof(uint2));
     L.o.offsets = off;      off = egs_align(off + n * sizeof(uint32_t));
     L.o.clamped = off;      off = egs_align(off + n);
+    L.o.visible = off;      off = egs_align(off + n);
     L.o.scan_scratch = off; off = egs_align(off + ((n + 255) / 256 + 64) * sizeof(uint32_t));     // per-block instance counts
     L.o.total = off;        off = egs_align(off + sizeof(uint64_t));
     L.bytes = off; return L;
@@ -51,7 +52,7 @@ ImgLayout img_layout(int W, int H) {
 EgsGeomPtrs geom_ptrs(void* buf, int P) {
     const GeomLayout L = geom_layout(P); char* b = (char*)buf; EgsGeomPtrs g;
     g.rec = (float4*)(b + L.o.rec); g.rect = (uint2*)(b + L.o.rect); g.offsets = (uint32_t*)(b + L.o.offsets);
-    g.clamped = (uint8_t*)(b + L.o.clamped); g.scan_scratch = (uint32_t*)(b + L.o.scan_scratch);
+    g.clamped = (uint8_t*)(b + L.o.clamped); g.visible = (uint8_t*)(b + L.o.visible); g.scan_scratch = (uint32_t*)(b + L.o.scan_scratch);
     g.total = (uint64_t*)(b + L.o.total); return g;
 }
 EgsBinPtrs bin_ptrs(void* buf, int P, int64_t R, int W, int H) {
@@ -225,8 +226,8 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
                 const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                 int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
-                float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, int64_t* num_rendered,
-                void* stream, int debug) {
+                float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
+                int64_t* num_rendered, void* stream, int debug) {
     (void)prefiltered;
     int rc = check_dims(P, width, height); if (rc) return rc;
     if (!num_rendered || capacity < 0 || capacity >= (1ll << 31)) return EGS_ERR_ARG;
@@ -235,8 +236,8 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) return egs_forward_render(0, 0, background, width, height, geom_buffer, binning_buffer, image_buffer, out_color,
                                           out_depth, out_alpha, stream, debug);
-    if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !pinned_host_counts)
-        return EGS_ERR_ARG;
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer) return EGS_ERR_ARG;
+    if (wait_for_count && !pinned_host_counts) return EGS_ERR_ARG;
     if (capacity > 0 && !binning_buffer) return EGS_ERR_ARG;
     if (!wait_for_count && capacity <= 0) return EGS_ERR_ARG;
     rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp); if (rc) return rc;
@@ -250,12 +251,12 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
                                   rotations, cov3D_precomp, cam, radii, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     const size_t nb = ((size_t)P + 255) / 256;
-    EGS_TRY(hipMemcpyAsync(pinned_host_counts, g.scan_scratch, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (pinned_host_counts) EGS_TRY(hipMemcpyAsync(pinned_host_counts, g.scan_scratch, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (wait_for_count) EGS_TRY(hipEventRecord(ev, s));
     if (capacity > 0) {                                              // speculative: sized by the caller's guess
         EgsBinPtrs b = bin_ptrs(binning_buffer, P, capacity, width, height);
         EgsImgPtrs im = img_ptrs(image_buffer, width, height);
-        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, s, 0));
+        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, s, 0));
         egs_prof_start(EGS_K_RENDER_FWD, s);
         EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, s));
         egs_prof_stop(EGS_K_RENDER_FWD, s);
@@ -281,23 +282,25 @@ int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const
     return forward_impl(1, P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
-                        pinned_host_counts, num_rendered, stream, debug);
+                        pinned_host_counts, nullptr, num_rendered, stream, debug);
 }
 
-// Same chain with NO host wait: everything (including the copy of the instance counts into pinned_host_counts) is only
-// enqueued, so the call can be captured into a hipGraph.  The caller sums pinned_host_counts after it has synchronised
-// (egs_sum_counts) and must discard the frame if the sum exceeds `capacity`.
+// Same chain with NO host wait: everything is only enqueued, so the call can be captured into a hipGraph.  Overflow of
+// `capacity` is detected afterwards, either from pinned_host_counts (optional copy of the per-workgroup rectangle counts;
+// egs_sum_counts after synchronising) or from `running_max` (optional device uint64 that the chain raises to the number
+// of instances it bucketed whenever that is larger -- one word a caller can read after any number of replays).
 int egs_forward_enqueue(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* colors_precomp,
                         const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
                         const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                         int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
-                        float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, void* stream) {
+                        float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
+                        void* stream) {
     int64_t unused = 0;
     return forward_impl(0, P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
-                        pinned_host_counts, &unused, stream, 0);
+                        pinned_host_counts, running_max, &unused, stream, 0);
 }
 
 int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts) {
@@ -319,7 +322,7 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
     EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
     EgsBinPtrs b = bin_ptrs(binning_buffer, P, R, width, height);
     EgsImgPtrs im = img_ptrs(image_buffer, width, height);
-    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, s, debug));
+    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, nullptr, s, debug));
     const uint32_t* point_list = b.point_list;
     egs_prof_start(EGS_K_RENDER_FWD, s);
     EGS_TRY(egs_launch_render_forward(width, height, background, g, point_list, im, out_color, out_depth, out_alpha, s));

@@ -391,7 +391,8 @@ __device__ __forceinline__ void block_min_max(uint32_t& mn, uint32_t& mx, uint32
 
 template <bool RANK_ATOMIC>
 __global__ __launch_bounds__(TS_THREADS) void k_tile_sort(int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
-                                                    const uint64_t* __restrict__ total, uint32_t R /* capacity */,
+                                                    const uint64_t* __restrict__ total, uint64_t* __restrict__ running_max,
+                                                    uint32_t R /* capacity */,
                                                     int index_passes, uint64_t* __restrict__ pairs,
                                                     uint64_t* __restrict__ scratch, uint32_t* __restrict__ point_list,
                                                     uint2* __restrict__ ranges) {
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_tile_sort(int n_tiles, uint32_t 
     __shared__ uint32_t cnt[TS_WAVES][256];
     __shared__ uint32_t lds8[2 * TS_WAVES];
     const int tile = blockIdx.x;
+    if (running_max && tile == 0 && threadIdx.x == 0 && *total > *running_max) *running_max = *total;   // for hipGraph replays (api.hip)
     const uint32_t beg = table_scanned[(size_t)tile * nblocks];
     const uint32_t end = tile + 1 < n_tiles ? table_scanned[(size_t)(tile + 1) * nblocks] : (uint32_t)*total;
     const uint32_t n = end > R ? 0u : end - beg;                     // end > capacity: speculative launch that overflowed
@@ -551,7 +553,7 @@ hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int 
 uint32_t egs_bin_blocks(int P) { return (uint32_t)((P + EGS_BIN_GPB - 1) / EGS_BIN_GPB); }
 
 hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
-                              hipStream_t s, int debug) {
+                              uint64_t* running_max, hipStream_t s, int debug) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
     if (R64 == 0 || P == 0) return egs_launch_zero_u32((uint32_t*)im.ranges, 2 * (size_t)n_tiles, s);
@@ -596,10 +598,10 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     if (egs_force_ballot_rank) fast = 0;
     egs_prof_start(EGS_K_SORT, s);
     if (fast)
-        hipLaunchKernelGGL(k_tile_sort<true>, dim3(n_tiles), dim3(TS_THREADS), 0, s, n_tiles, nblocks, b.table, b.total, R,
+        hipLaunchKernelGGL(k_tile_sort<true>, dim3(n_tiles), dim3(TS_THREADS), 0, s, n_tiles, nblocks, b.table, b.total, running_max, R,
                            (index_bits + TS_DBITS - 1) / TS_DBITS, b.pairs, b.scratch, b.point_list, im.ranges);
     else
-        hipLaunchKernelGGL(k_tile_sort<false>, dim3(n_tiles), dim3(TS_THREADS), 0, s, n_tiles, nblocks, b.table, b.total, R,
+        hipLaunchKernelGGL(k_tile_sort<false>, dim3(n_tiles), dim3(TS_THREADS), 0, s, n_tiles, nblocks, b.table, b.total, running_max, R,
                            (index_bits + TS_DBITS - 1) / TS_DBITS, b.pairs, b.scratch, b.point_list, im.ranges);
     egs_prof_stop(EGS_K_SORT, s);
     EGS_DBG(s);

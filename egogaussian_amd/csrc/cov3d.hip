@@ -25,7 +25,10 @@ __device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* 
         for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
 
-__global__ __launch_bounds__(256) void k_cov3d_forward(int N, const float* __restrict__ scaling, float mod,
+// `log_scaling`: the scaling tensor holds the RAW parameters (log of the scales, /root/reference/scene/gaussian_model.py:36
+// scaling_activation = torch.exp); the exponential and its derivative are then applied here instead of by two more
+// elementwise kernels over [N,3] per step.
+__global__ __launch_bounds__(256) void k_cov3d_forward(int N, const float* __restrict__ scaling, int log_scaling, float mod,
                                                         const float* __restrict__ rotation, const float* __restrict__ M,
                                                         const uint8_t* __restrict__ sel, float* __restrict__ cov) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -34,7 +37,9 @@ __global__ __launch_bounds__(256) void k_cov3d_forward(int N, const float* __res
     const float inv = 1.f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
     float R[9]; rot_from_unit_quat(q, R);
-    const float sc[3] = { mod * scaling[3 * i], mod * scaling[3 * i + 1], mod * scaling[3 * i + 2] };
+    float s3[3] = { scaling[3 * i], scaling[3 * i + 1], scaling[3 * i + 2] };
+    if (log_scaling) { s3[0] = expf(s3[0]); s3[1] = expf(s3[1]); s3[2] = expf(s3[2]); }
+    const float sc[3] = { mod * s3[0], mod * s3[1], mod * s3[2] };
     float L[9];
 #pragma unroll
     for (int a = 0; a < 3; a++)
@@ -63,7 +68,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_cov3d_backward(int N, const float* __restrict__ scaling, float mod,
+__global__ __launch_bounds__(256) void k_cov3d_backward(int N, const float* __restrict__ scaling, int log_scaling, float mod,
                                                          const float* __restrict__ rotation, const float* __restrict__ M,
                                                          const uint8_t* __restrict__ sel, float row0_mult,
                                                          const float* __restrict__ dcov, float* __restrict__ dscaling,
@@ -75,7 +80,9 @@ __global__ __launch_bounds__(256) void k_cov3d_backward(int N, const float* __re
         const float inv = 1.f / sqrtf(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
         const float q[4] = { q0[0] * inv, q0[1] * inv, q0[2] * inv, q0[3] * inv };
         float R[9]; rot_from_unit_quat(q, R);
-        const float sc[3] = { mod * scaling[3 * i], mod * scaling[3 * i + 1], mod * scaling[3 * i + 2] };
+        float s3[3] = { scaling[3 * i], scaling[3 * i + 1], scaling[3 * i + 2] };
+        if (log_scaling) { s3[0] = expf(s3[0]); s3[1] = expf(s3[1]); s3[2] = expf(s3[2]); }
+        const float sc[3] = { mod * s3[0], mod * s3[1], mod * s3[2] };
         float L0[9], L[9];
 #pragma unroll
         for (int a = 0; a < 3; a++)
@@ -114,7 +121,8 @@ __global__ __launch_bounds__(256) void k_cov3d_backward(int N, const float* __re
         float gR[9];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            dscaling[3 * i + k] = mod * (gL0[k] * R[k] + gL0[3 + k] * R[3 + k] + gL0[6 + k] * R[6 + k]);
+            const float ds = mod * (gL0[k] * R[k] + gL0[3 + k] * R[3 + k] + gL0[6 + k] * R[6 + k]);
+            dscaling[3 * i + k] = log_scaling ? ds * s3[k] : ds;           // d/d raw = d/d scale * exp(raw)
 #pragma unroll
             for (int a = 0; a < 3; a++) gR[3 * a + k] = gL0[3 * a + k] * sc[k];
         }
@@ -141,24 +149,24 @@ __global__ __launch_bounds__(256) void k_cov3d_backward(int N, const float* __re
 
 extern "C" {
 
-int egs_cov3d_forward(int N, const float* scaling, float scale_modifier, const float* rotation, const float* M9,
+int egs_cov3d_forward(int N, const float* scaling, int scaling_is_log, float scale_modifier, const float* rotation, const float* M9,
                       const uint8_t* selected, float* cov6, void* stream) {
     if (N < 0) return EGS_ERR_ARG;
     if (N == 0) return 0;
     if (!scaling || !rotation || !cov6) return EGS_ERR_ARG;
-    hipLaunchKernelGGL(k_cov3d_forward, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling, scale_modifier,
+    hipLaunchKernelGGL(k_cov3d_forward, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling, scaling_is_log, scale_modifier,
                        rotation, M9, selected, cov6);
     return (int)hipGetLastError();
 }
 
-int egs_cov3d_backward(int N, const float* scaling, float scale_modifier, const float* rotation, const float* M9,
+int egs_cov3d_backward(int N, const float* scaling, int scaling_is_log, float scale_modifier, const float* rotation, const float* M9,
                        const uint8_t* selected, float row0_grad_mult, const float* dL_dcov6, float* dL_dscaling,
                        float* dL_drotation, float* dL_dM9, void* stream) {
     if (N < 0) return EGS_ERR_ARG;
     if (dL_dM9) { hipError_t e = egs_launch_zero_u32((uint32_t*)dL_dM9, 9, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     if (N == 0) return 0;
     if (!scaling || !rotation || !dL_dcov6 || !dL_dscaling || !dL_drotation) return EGS_ERR_ARG;
-    hipLaunchKernelGGL(k_cov3d_backward, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling, scale_modifier,
+    hipLaunchKernelGGL(k_cov3d_backward, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling, scaling_is_log, scale_modifier,
                        rotation, M9, selected, row0_grad_mult, dL_dcov6, dL_dscaling, dL_drotation, M9 ? dL_dM9 : nullptr);
     return (int)hipGetLastError();
 }

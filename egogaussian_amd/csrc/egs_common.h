@@ -27,7 +27,7 @@
 #define EGS_GRAD_STRIDE 12
 
 struct EgsGeomPtrs {
-    float4* rec; uint2* rect; uint32_t* offsets; uint8_t* clamped; uint32_t* scan_scratch; uint64_t* total;
+    float4* rec; uint2* rect; uint32_t* offsets; uint8_t* clamped; uint8_t* visible; uint32_t* scan_scratch; uint64_t* total;
 };
 struct EgsBinPtrs {
     uint64_t* pairs;        // [R] (depth<<32 | index), bucketed by tile
@@ -82,7 +82,7 @@ hipError_t egs_launch_mark_visible(int P, const float* means3D, const float* vie
 hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int inclusive, uint32_t* scratch,
                                uint64_t* total, hipStream_t s);
 hipError_t egs_launch_binning(int P, int64_t R, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
-                              hipStream_t s, int debug);
+                              uint64_t* running_max, hipStream_t s, int debug);
 hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                      EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha,
                                      hipStream_t s);

@@ -119,9 +119,9 @@ __device__ __forceinline__ uint32_t preprocess_one(
     const float* __restrict__ rots, const float* __restrict__ cov3D_in, const float* __restrict__ V,
     const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
-    uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out) {
+    uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
-    radii[i] = 0; tiles_touched[i] = 0;
+    radii[i] = 0; tiles_touched[i] = 0; visible[i] = 0;
 
     const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
     float c6[6];
@@ -197,7 +197,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
         }
     }
 
-    radii[i] = rad;
+    radii[i] = rad; visible[i] = 1;                                  // radii > 0 as one byte (a torch.bool view for the caller)
     tiles_touched[i] = (uint32_t)((rx1 - rx0) * (ry1 - ry0));
     rect_out[i] = make_uint2((uint32_t)rx0 | ((uint32_t)rx1 << 16), (uint32_t)ry0 | ((uint32_t)ry1 << 16));
     clamped_out[i] = (uint8_t)cl;
@@ -214,12 +214,13 @@ __global__ __launch_bounds__(256) void k_preprocess(
     const float* __restrict__ rots, const float* __restrict__ cov3D_in, const float* __restrict__ V,
     const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
-    uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint32_t* __restrict__ block_sums) {
+    uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible,
+    uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t wsum[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t my_tiles = 0;
     if (i < P) my_tiles = preprocess_one(i, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D_in, V, PM, campos, W, H,
-                                         tanfovx, tanfovy, radii, rec, rect_out, tiles_touched, clamped_out);
+                                         tanfovx, tanfovy, radii, rec, rect_out, tiles_touched, clamped_out, visible);
     // per-block instance count; the host adds the block sums to get R (no contended atomic, deterministic)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) my_tiles += (uint32_t)__shfl_xor((int)my_tiles, d, 64);
@@ -460,7 +461,7 @@ hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, cons
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(k_preprocess, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, colors, opac, scales,
                        mod, rots, cov3D, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.tanfovx, cam.tanfovy, radii,
-                       g.rec, g.rect, g.offsets, g.clamped, g.scan_scratch);
+                       g.rec, g.rect, g.offsets, g.clamped, g.visible, g.scan_scratch);
     return hipGetLastError();
 }
 

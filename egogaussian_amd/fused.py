@@ -33,7 +33,7 @@ def _need_hip(t, name):
 
 class _Cov3D(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scaling, rotation, M, selected, modifier, row0_mult):
+    def forward(ctx, scaling, rotation, M, selected, modifier, row0_mult, log_scaling=False):
         L = _lib.load()
         scaling, rotation = _need_hip(scaling, "scaling"), _need_hip(rotation, "rotation")
         N = scaling.shape[0]
@@ -41,9 +41,11 @@ class _Cov3D(torch.autograd.Function):
         sel = None if selected is None else selected.to(torch.uint8).contiguous()
         cov = torch.empty((N, 6), device=scaling.device, dtype=torch.float32)
         with torch.cuda.device(scaling.device):
-            _lib.check(L.egs_cov3d_forward(N, _p(scaling), float(modifier), _p(rotation), _p(Mc), _p(sel), _p(cov), _stream()))
+            _lib.check(L.egs_cov3d_forward(N, _p(scaling), int(bool(log_scaling)), float(modifier), _p(rotation), _p(Mc), _p(sel), _p(cov),
+                                           _stream()))
         ctx.save_for_backward(scaling, rotation, Mc if Mc is not None else torch.empty(0), sel if sel is not None else torch.empty(0))
         ctx.modifier, ctx.row0_mult, ctx.has_M, ctx.has_sel = float(modifier), float(row0_mult), M is not None, selected is not None
+        ctx.log_scaling = int(bool(log_scaling))
         return cov
 
     @staticmethod
@@ -57,17 +59,24 @@ class _Cov3D(torch.autograd.Function):
         ds, dr = torch.empty_like(scaling), torch.empty_like(rotation)
         dM = torch.empty(9, device=scaling.device) if (ctx.has_M and ctx.needs_input_grad[2]) else None
         with torch.cuda.device(scaling.device):
-            _lib.check(L.egs_cov3d_backward(N, _p(scaling), ctx.modifier, _p(rotation), _p(Mc), _p(sel), ctx.row0_mult, _p(dcov),
-                                            _p(ds), _p(dr), _p(dM), _stream()))
-        return ds, dr, (None if dM is None else dM.view(3, 3)), None, None, None
+            _lib.check(L.egs_cov3d_backward(N, _p(scaling), ctx.log_scaling, ctx.modifier, _p(rotation), _p(Mc), _p(sel), ctx.row0_mult,
+                                            _p(dcov), _p(ds), _p(dr), _p(dM), _stream()))
+        return ds, dr, (None if dM is None else dM.view(3, 3)), None, None, None, None
 
 
 def covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
     return _Cov3D.apply(scaling, rotation, None, None, scaling_modifier, 1.0)
 
 
+def covariance_from_log_scaling(log_scaling, scaling_modifier, rotation):
+    """Same, fed with the RAW scaling parameters (GaussianModel._scaling): exp() and its derivative run inside the kernels,
+    which saves the two elementwise launches of `get_scaling` per step.  For a reference GaussianModel:
+        gaussians.get_covariance = lambda m=1: fused.covariance_from_log_scaling(gaussians._scaling, m, gaussians._rotation)"""
+    return _Cov3D.apply(log_scaling, rotation, None, None, scaling_modifier, 1.0, True)
+
+
 def rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation, accum_R, is_object=None, which_object=None,
-                                             rot_matrix=None):
+                                             rot_matrix=None, scaling_is_log=False):
     """`rot_matrix` (3x3, may require grad) is the trainable object rotation applied on top of accum_R during training
     (trainable_object_move.rot_L in the reference).  Keeps the reference's [N,1]-index quirk, see covariance.py."""
     dev = scaling.device
@@ -87,7 +96,7 @@ def rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation
                 sel = sel.clone(); sel[0] = True
     elif is_object is not None and is_object.dim() == 2 and n > 0:
         mult = float(n + 1)
-    return _Cov3D.apply(scaling, rotation, M, sel, scaling_modifier, mult)
+    return _Cov3D.apply(scaling, rotation, M, sel, scaling_modifier, mult, scaling_is_log)
 
 
 class _L1SSIM(torch.autograd.Function):

@@ -53,8 +53,6 @@ class GraphedTrainStep:
 
     def _body(self):
         out = render(self.cam, self.pc, self.pipe, self.bg, **self.render_kwargs)
-        if self._max_r is not None:                                  # running maximum of R over all replays, on the device
-            torch.maximum(self._max_r, _C.stats["total_view"], out=self._max_r)
         loss = l1_ssim_loss(out["render"], self.gt, self.lam)
         loss.backward()
         self.opt.step()
@@ -77,14 +75,19 @@ class GraphedTrainStep:
         self.capacity = max(int(_C.stats["num_rendered"] * capacity_margin), _C.stats["capacity"])
         _C.set_capacity_hint(self.capacity, dev)
         self.P = P
-        self._max_r = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._max_r = torch.zeros(1, dtype=torch.int64, device=dev)      # raised by every replayed forward (library side)
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss, out = self._body()
-            self.image = out["render"].detach()
-            self.radii = out["radii"]
-            self.viewspace_grad = out["viewspace_points"].grad
+        _C.set_running_max(dev, self._max_r)
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss, out = self._body()
+                self.image = out["render"].detach()
+                self.radii = out["radii"]
+                self.viewspace_grad = out["viewspace_points"].grad
+                self._total = _C.stats["total_view"]
+        finally:
+            _C.set_running_max(dev, None)
         torch.cuda.synchronize(dev)
         return self
 
@@ -96,8 +99,9 @@ class GraphedTrainStep:
         return self.loss
 
     def last_instance_count(self):
-        """R of the most recent replay; call after synchronising.  R > capacity means that frame was clipped."""
-        return _C.last_instance_count(self.gt.device, self.P)
+        """Instances the most recent replay bucketed; call after synchronising.  More than `capacity` means that frame was
+        clipped."""
+        return int(self._total.item())
 
     def max_instances(self):
         """Largest R over every replay so far (reads a device scalar: synchronises)."""

@@ -15,7 +15,7 @@ vp, f32, i32, i64 = C.c_void_p, C.c_float, C.c_int, C.c_int64
 
 
 class GeomLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("rec", "rect", "offsets", "clamped", "scan_scratch", "total")]
+    _fields_ = [(n, C.c_size_t) for n in ("rec", "rect", "offsets", "clamped", "visible", "scan_scratch", "total")]
 
 
 class BinningLayout(C.Structure):
@@ -44,14 +44,14 @@ SIGNATURES = {
     "egs_forward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, i64,
                                vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp, i32]),
     "egs_forward_enqueue": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp,
-                                       i64, vp, vp, vp, vp, vp, vp, vp]),
+                                       i64, vp, vp, vp, vp, vp, vp, vp, vp]),
     "egs_sum_counts": (C.c_int64, [i32, vp]),
     "egs_forward_render": (C.c_int, [i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, f32, f32,
                                vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
-    "egs_cov3d_forward": (C.c_int, [i32, vp, f32, vp, vp, vp, vp, vp]),
-    "egs_cov3d_backward": (C.c_int, [i32, vp, f32, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
+    "egs_cov3d_forward": (C.c_int, [i32, vp, i32, f32, vp, vp, vp, vp, vp]),
+    "egs_cov3d_backward": (C.c_int, [i32, vp, i32, f32, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
     "egs_l1_ssim_partial_count": (C.c_size_t, [i32, i32, i32]),
     "egs_l1_ssim_forward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
     "egs_l1_ssim_backward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),

@@ -67,7 +67,11 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     image, radii, depth, alpha = rasterizer(means3D=xyz, means2D=screenspace_points, shs=shs,
                                             colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales,
                                             rotations=rotations, cov3D_precomp=cov3D_precomp)
-    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+    from . import _C
+    visible = _C.stats.get("visible_view")                 # radii > 0, written by the preprocess kernel of the call above
+    if visible is None or visible.shape != radii.shape or visible.device != radii.device:
+        visible = radii > 0
+    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": visible, "radii": radii,
             "depth": depth, "alpha": alpha}
 
 

@@ -158,7 +158,7 @@ class SynthGaussians:
     def get_covariance(self, scaling_modifier=1):
         if self.fused and self._xyz.is_cuda:
             from . import fused
-            return fused.covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
+            return fused.covariance_from_log_scaling(self._scaling, scaling_modifier, self._rotation)
         return self._cov.covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
 
     def get_rotated_covariance(self, accum_R, which_object, during_training, scaling_modifier=1):

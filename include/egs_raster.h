@@ -73,6 +73,7 @@ typedef struct egs_geom_layout {
     size_t rect;           /* uint32[P][2]  tile rect: (x0 | x1<<16, y0 | y1<<16) */
     size_t offsets;        /* uint32[P]     tiles touched by each Gaussian (0 = culled) */
     size_t clamped;        /* uint8[P]      bit c set <=> colour channel c was clamped at 0 */
+    size_t visible;        /* uint8[P]      1 <=> radii > 0 (the renderer's visibility_filter without a compare kernel) */
     size_t scan_scratch;   /* uint32[ceil(P/256)] per-workgroup instance counts (their sum is R) */
     size_t total;          /* reserved */
 } egs_geom_layout;
@@ -137,10 +138,12 @@ int egs_forward(
     float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts /*HOST, page-locked*/,
     int64_t* num_rendered /*HOST out*/, void* stream, int debug);
 
-/* ---- the same chain with NO host wait, for hipGraph capture of a whole training step: everything, including the copy
- *      of the per-workgroup instance counts into `pinned_host_counts`, is only enqueued (capacity must be > 0).  After
- *      the caller has synchronised it reads R = egs_sum_counts(P, pinned_host_counts); a frame with R > capacity is
- *      invalid (its kernels were clipped to the capacity) and must be redone with a larger buffer. */
+/* ---- the same chain with NO host wait, for hipGraph capture of a whole training step: everything is only enqueued
+ *      (capacity must be > 0).  A frame that needs more than `capacity` instances is invalid (its kernels were clipped to
+ *      the capacity) and must be redone with a larger buffer; the caller finds out after synchronising, from either of
+ *        pinned_host_counts   optional (NULL: no copy): the per-workgroup rectangle counts, R = egs_sum_counts(P, ..)
+ *        running_max          optional device uint64: raised by the chain to the number of instances it bucketed whenever
+ *                             that is larger, so one word tells whether ANY replay so far overflowed. */
 int egs_forward_enqueue(
     int P, int sh_degree, int sh_coeffs,
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
@@ -148,7 +151,7 @@ int egs_forward_enqueue(
     const float* viewmatrix, const float* projmatrix, const float* campos, const float* background,
     int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
     int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
-    float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, void* stream);
+    float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max, void* stream);
 int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts /*HOST*/);
 
 /* ---- backward  (upstream: render backward + computeCov2D backward + preprocess backward) ------- */
@@ -177,13 +180,15 @@ int egs_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  *      (/root/reference/utils/general_utils.py:110-156) and the covariance activations
  *      (/root/reference/scene/gaussian_model.py:29-33,46-63):
  *      q <- q/|q|; L = R(q) diag(scale_modifier * scaling); rows with selected[i] != 0 (all rows if selected == NULL)
- *      get L <- M L when M9 != NULL; cov6 = unique entries of L L^T in the order (00,01,02,11,12,22). */
-int egs_cov3d_forward(int N, const float* scaling /*[N,3]*/, float scale_modifier, const float* rotation /*[N,4] raw*/,
+ *      get L <- M L when M9 != NULL; cov6 = unique entries of L L^T in the order (00,01,02,11,12,22).
+ *      scaling_is_log != 0: `scaling` holds the raw parameters and the scaling activation exp() (gaussian_model.py:36) is
+ *      applied by the kernel; the backward then returns the gradient w.r.t. the raw parameters. */
+int egs_cov3d_forward(int N, const float* scaling /*[N,3]*/, int scaling_is_log, float scale_modifier, const float* rotation /*[N,4] raw*/,
                       const float* M9 /*[9] device, row-major, or NULL*/, const uint8_t* selected /*[N] or NULL*/,
                       float* cov6 /*[N,6] out*/, void* stream);
 /* row0_grad_mult reproduces the reference's duplicated-index gradient on Gaussian 0 (egogaussian_amd/covariance.py);
  * pass 1.0 otherwise.  dL_dM9 (device [9], may be NULL) is zeroed and accumulated by the callee. */
-int egs_cov3d_backward(int N, const float* scaling, float scale_modifier, const float* rotation, const float* M9,
+int egs_cov3d_backward(int N, const float* scaling, int scaling_is_log, float scale_modifier, const float* rotation, const float* M9,
                        const uint8_t* selected, float row0_grad_mult, const float* dL_dcov6 /*[N,6]*/,
                        float* dL_dscaling /*[N,3] out*/, float* dL_drotation /*[N,4] out*/, float* dL_dM9, void* stream);
 

@@ -43,6 +43,28 @@ def test_fused_covariance_matches_torch_and_reference_fixture():
             assert _close(ls.grad, g["rg_scaling"], 1e-4) and _close(q.grad, g["rg_rotation"], 1e-4)
 
 
+def test_fused_covariance_from_raw_scaling():
+    """exp() folded into the kernels: same covariance and same gradient w.r.t. the RAW scaling as torch.exp + the op."""
+    from egogaussian_amd import fused, covariance as ref
+    gen = torch.Generator().manual_seed(5)
+    N = 7000
+    raw = (torch.randn(N, 3, generator=gen) * 0.7 - 3.0).to(DEV).requires_grad_(True)
+    raw2 = raw.detach().clone().requires_grad_(True)
+    q = torch.randn(N, 4, generator=gen).to(DEV).requires_grad_(True)
+    q2 = q.detach().clone().requires_grad_(True)
+    w = torch.randn(N, 6, generator=gen).to(DEV)
+    a = fused.covariance_from_log_scaling(raw, 1.3, q)
+    b = ref.covariance_from_scaling_rotation(torch.exp(raw2), 1.3, q2)
+    assert _close(a, b)
+    (a * w).sum().backward(); (b * w).sum().backward()
+    assert _close(raw.grad, raw2.grad, 1e-4) and _close(q.grad, q2.grad, 1e-4)
+    io = (torch.rand(N, 1, generator=gen) < 0.4).float().to(DEV)
+    A = torch.linalg.qr(torch.randn(3, 3, generator=gen))[0].to(DEV)
+    c = fused.rotated_covariance_from_scaling_rotation(raw.detach(), 1.0, q.detach(), A, io, 1, scaling_is_log=True)
+    d = ref.rotated_covariance_from_scaling_rotation(torch.exp(raw.detach()), 1.0, q.detach(), A, io, 1)
+    assert _close(c, d)
+
+
 def test_fused_covariance_trainable_rotation_gradient():
     from egogaussian_amd import fused, covariance as ref
     gen = torch.Generator().manual_seed(3)

@@ -328,6 +328,7 @@ def test_autograd_surface_reaches_all_parameters():
     out = render(cam, pc, Pipe, bg)
     assert out["render"].shape == (3, H, W) and out["depth"].shape == (1, H, W) and out["alpha"].shape == (1, H, W)
     assert out["radii"].dtype == torch.int32 and out["visibility_filter"].dtype == torch.bool
+    assert torch.equal(out["visibility_filter"], out["radii"] > 0) and 0 < int(out["visibility_filter"].sum()) < 1000
     (out["render"].sum() + out["alpha"].sum()).backward()
     for p in (pc._xyz, pc._features_dc, pc._scaling, pc._rotation, pc._opacity):
         assert p.grad is not None and float(p.grad.abs().sum()) > 0
