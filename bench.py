@@ -36,11 +36,12 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s 
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
-def algorithmic_bytes(stage, N, R, npix, passes):
-    """Bytes one launch of `stage` must move at minimum: per-unit figures x units."""
+def algorithmic_bytes(stage, N, R, npix):
+    """Bytes one launch of `stage` must move at minimum: per-unit figures x units.  R = instances the
+    launch actually processes (after tile culling)."""
     return {
         "preprocess": 52 * N + 48 * N,                 # xyz 12 + cov 24 + opacity 4 + sh 12 in; record 48 out
-        "tile_bucket": 2 * 16 * N + 8 * R,             # two walks over (tiles_touched, rect, depth) per Gaussian; one pair out per instance
+        "tile_bucket": 2 * (16 + 32) * N + 8 * R,      # two walks over (tiles_touched, rect, depth | ellipse) per Gaussian; one pair out per instance
         "tile_sort": 8 * R + 4 * R,                    # pair in, index out; the radix passes stay in registers/LDS
         "render_forward": 4 * R + 48 * R + 28 * npix,  # id + record per instance; 7 floats per pixel out
         "render_backward": 4 * R + 48 * R + 40 * R + 32 * npix,   # + one 40-byte accumulate per instance; 8 floats/pixel in
@@ -184,12 +185,19 @@ def main():
 
     npix = H * W
     passes = _C.binning_passes(N, W, H)
+    # instances that survive tile culling (what the sort and the blend kernels process): sampled on four frames
+    kept, rect = 0, 0
+    with torch.no_grad():
+        for i in range(min(4, n_used)):
+            render(cams[i], pc, Pipe, bg)
+            kept += int(_C.stats["total_view"].item()); rect += _C.stats["num_rendered"]
+    R_kept = R_mean * kept / max(rect, 1)
     stage_rows, dominant = {}, None
     for name, (ms, n) in stages.items():
         if n == 0:
             continue
         per = ms / n
-        ab = algorithmic_bytes(name, N, R_mean, npix, passes)
+        ab = algorithmic_bytes(name, N, R_kept, npix)
         stage_rows[name] = {"ms_per_launch": round(per, 4), "launches": n, "alg_MB": round(ab / 1e6, 2),
                             "alg_GBps": round(ab / (per * 1e-3) / 1e9, 1), "frac_hbm": round(ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if dominant is None or per * n > stages[dominant][0]:
@@ -207,7 +215,7 @@ def main():
                 "frac": round(d["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "ms_per_launch": d["ms_per_launch"], "alg_bytes_per_launch": int(d["alg_MB"] * 1e6), "timing": stage_timing,
                 "note": "blend stages are VALU/LDS-bound (per pixel-splat pair work), not HBM-bound; see `stages` for the streaming kernels"}
-    op_ms = sum(ms for ms, n in stages.values()) / max(args.steps, 1)
+    op_ms = sum(ms / n for ms, n in stages.values() if n)
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -237,7 +245,8 @@ def main():
                                + ("rasterizer fwd+bwd only (seeded upstream grads on colour/depth/alpha)" if args.op_only else
                                   ("cov3D(torch) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) (torch) + bwd + Adam" if args.torch_host_ops else
                                    "cov3D (HIP) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) (HIP) + bwd (HIP+autograd) + Adam (HIP)")),
-                   "gaussians": N, "image": [H, W], "sh_degree": 0, "instances_R": int(R_mean), "sort_passes": passes,
+                   "gaussians": N, "image": [H, W], "sh_degree": 0, "instances_R": int(R_mean), "instances_after_tile_culling": int(R_kept),
+                   "sort_passes_max": passes,
                    "parallelism": f"frames sharded over {world} GPU(s), scalar all-reduce only",
                    "launch": "one hipGraph replay per step" if use_graph else "eager (one launch per kernel)"},
         "psnr_db": round(psnr_e, 3), "psnr_db_before": round(psnr_s, 3), "mean_loss": round(mean_loss, 6),

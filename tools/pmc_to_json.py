@@ -8,8 +8,8 @@ import json, os, sys
 import pandas as pd
 
 STAGES = {"preprocess": ["k_preprocess("], "tile_bucket": ["k_bin_count", "k_scan_", "k_bin_scatter"], "tile_sort": ["k_tile_sort"],
-          "render_forward": ["k_render_forward"], "render_backward": ["k_render_backward"],
-          "preprocess_backward": ["k_preprocess_backward"], "cov3d": ["k_cov3d_"], "loss": ["k_l1_ssim_"]}
+          "render_forward": ["k_render_forward"], "render_backward": ["k_render_backward", "k_backward_prologue"],
+          "preprocess_backward": ["k_preprocess_backward"], "cov3d": ["k_cov3d_"], "loss": ["k_l1_ssim_"], "adam": ["k_adam"]}
 
 
 def per_kernel(csv, counter):
