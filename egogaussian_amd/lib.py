@@ -57,6 +57,14 @@ SIGNATURES = {
     "egs_l1_ssim_backward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_adam_step": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
     "egs_adam_step_capturable": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
+    "egs_densify_stats": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp]),
+    "egs_densify_plan_scratch_bytes": (C.c_size_t, [i32]),
+    "egs_densify_plan": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp,
+                                    vp, vp, vp]),
+    "egs_prune_plan": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp]),
+    "egs_gather_rows_f32": (C.c_int, [i64, i32, vp, vp, i32, vp, vp, vp]),
+    "egs_gather_i32": (C.c_int, [i64, vp, vp, i32, i32, vp, vp, vp]),
+    "egs_split_children": (C.c_int, [i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_knn3_mean_dist2": (C.c_int, [i32, vp, vp, vp]),
     "egs_debug_force_ballot_rank": (C.c_int, [i32]),
     "egs_debug_set_tile_culling": (C.c_int, [i32]),

@@ -133,12 +133,32 @@ class SynthGaussians:
         n = scene["xyz"].shape[0]
         self._label = torch.zeros((n, 1), device=device).requires_grad_(requires_grad)
         self._is_object = torch.zeros((n, 1), device=device)
+        self._generation = torch.zeros((n, 1), dtype=torch.int, device=device)
+        self.max_radii2D = torch.zeros((n,), device=device)
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=device)
+        self.denom = torch.zeros((n, 1), device=device)
+        self.percent_dense = 0.01
+        self.optimizer = None
         self.active_sh_degree = sh_degree
         self.max_sh_degree = sh_degree
         self.trainable_object_move = None
 
     def parameters(self):
         return [self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity]
+
+    def training_setup(self, optimizer_cls=None, percent_dense=0.01, **kw):
+        """One named group per parameter with the reference's default learning rates
+        (/root/reference/scene/gaussian_model.py:180-198, arguments/__init__.py OptimizationParams)."""
+        self.percent_dense = percent_dense
+        self._label = self._label.detach().requires_grad_(True)
+        groups = [{"params": [self._xyz], "lr": 1.6e-4, "name": "xyz"}, {"params": [self._features_dc], "lr": 2.5e-3, "name": "f_dc"},
+                  {"params": [self._features_rest], "lr": 2.5e-3 / 20.0, "name": "f_rest"},
+                  {"params": [self._opacity], "lr": 0.05, "name": "opacity"}, {"params": [self._scaling], "lr": 5e-3, "name": "scaling"},
+                  {"params": [self._rotation], "lr": 1e-3, "name": "rotation"}, {"params": [self._label], "lr": 0.0, "name": "label"}]
+        if optimizer_cls is None:
+            from .optim import FusedAdam as optimizer_cls
+        self.optimizer = optimizer_cls(groups, lr=0.0, eps=1e-15, **kw)
+        return self.optimizer
 
     @property
     def get_xyz(self): return self._xyz

@@ -223,6 +223,44 @@ int egs_adam_step_capturable(int n_tensors, float* const* params, const float* c
                              const float* const* lr_dev /*HOST array of device ptrs*/, uint32_t* ticket, float beta1, float beta2,
                              float eps, void* stream);
 
+/* ---- f-4 (densify / prune part): the bookkeeping of /root/reference/scene/gaussian_model.py:506-709,735-740 on the device.
+ *      egs_densify_stats         per-iteration statistics in one pass: for every visible Gaussian (visible[i] != 0, or
+ *                                radii[i] > 0 when `visible` is NULL)  grad_accum += |viewspace_grad.xy|, denom += 1 and, when
+ *                                radii and max_radii2D are given, max_radii2D = max(max_radii2D, radii)
+ *                                (add_densification_stats :735-740 + trainers/train_static.py:125).
+ *      egs_densify_plan          evaluates densify_and_clone / densify_and_split / the final prune of densify_and_prune
+ *                                (:588-709) for every Gaussian and compacts the results: src_index[k], kind[k] (0 kept original,
+ *                                1 clone, 2 / 3 first / second split child) for the k-th Gaussian of the new model, in the
+ *                                reference's order; split_rank[i] = rank of source i among the split ones (-1: not split);
+ *                                totals (device uint64[4]) = kept originals, kept clones, kept children PER COPY, split sources.
+ *                                New size = totals[0] + totals[1] + 2 totals[2].  Everything is enqueued; read totals after
+ *                                synchronising.  EGS_ERR_MODE for prune_prev_gen == 0 without a curr_gen (the reference raises).
+ *      egs_prune_plan            the same plan for prune_points(mask) (:536-563): kept = !mask.
+ *      egs_gather_rows_f32       out[k][:] = in[src_index[k]][:]; zero_new_rows != 0 writes zeros for kind != 0 (Adam moments).
+ *      egs_gather_i32            same for the int32 side arrays; clone_value_on: clones take clone_value (curr_gen).
+ *      egs_split_children        rows of kind 2 / 3: xyz = parent + R(q) (exp(scaling) * z), scaling = log(exp(scaling) / 1.6);
+ *                                z = the 2 * n_split standard-normal draws, first children first (torch.normal at :621). */
+int egs_densify_stats(int P, const float* viewspace_grad /*[P,3]*/, const uint8_t* visible /*[P] or NULL*/,
+                      const int32_t* radii /*[P] or NULL*/, float* grad_accum /*[P]*/, float* denom /*[P]*/,
+                      float* max_radii2D /*[P] or NULL*/, void* stream);
+size_t egs_densify_plan_scratch_bytes(int P);
+int egs_densify_plan(int P, const float* grad_accum, const float* denom, const float* scaling_raw /*[P,3]*/,
+                     const float* opacity_raw /*[P]*/, const float* max_radii2D /*[P]*/, const int32_t* generation /*[P]*/,
+                     const int32_t* is_object /*[P]*/, float max_grad, float min_opacity, float percent_dense, float extent,
+                     float max_screen_size /* <= 0: criterion off */, int clone, int split, int has_curr_gen, int curr_gen,
+                     int prune_prev_gen, int has_which_object, int which_object, void* scratch,
+                     int32_t* src_index /*[3P] out*/, uint8_t* kind /*[3P] out*/, int32_t* split_rank /*[P] out*/,
+                     uint64_t* totals /*device [4] out*/, void* stream);
+int egs_prune_plan(int P, const uint8_t* prune_mask /*[P]*/, void* scratch, int32_t* src_index, uint8_t* kind, int32_t* split_rank,
+                   uint64_t* totals, void* stream);
+int egs_gather_rows_f32(int64_t rows, int row_floats, const int32_t* src_index, const uint8_t* kind, int zero_new_rows,
+                        const float* in, float* out, void* stream);
+int egs_gather_i32(int64_t rows, const int32_t* src_index, const uint8_t* kind, int clone_value_on, int clone_value,
+                   const int32_t* in, int32_t* out, void* stream);
+int egs_split_children(int64_t rows, const int32_t* src_index, const uint8_t* kind, const int32_t* split_rank, int n_split,
+                       const float* z /*[2 n_split, 3]*/, const float* xyz_old, const float* scaling_old, const float* rotation_old,
+                       float* xyz_new, float* scaling_new, void* stream);
+
 /* ---- f-2: mean squared distance of every point to its 3 nearest neighbours (self excluded by index).
  *      Replaces simple_knn._C.distCUDA2 (un-vendored submodule, /root/reference/.gitmodules:4-6), imported at
  *      /root/reference/scene/gaussian_model.py:21 and called at :301.  Exact (all pairs). */

@@ -65,3 +65,55 @@ def test_reset_opacity_matches_reference():
     st = D.reset_opacity(state_from(g, "in_"))
     assert np.allclose(st["opacity"].numpy(), g["reset_opacity"], rtol=1e-6, atol=1e-7)
     assert float(g["reset_exp_avg_abs_sum"]) == 0.0
+
+
+# ---- PLY hand-off (numpy only) ---------------------------------------------------------------------------------------
+class _Model:
+    max_sh_degree = 1
+
+
+def _model_from(g, prefix="in_"):
+    m = _Model()
+    st = state_from(g, prefix)
+    m._xyz, m._features_dc, m._features_rest = st["xyz"], st["f_dc"], st["f_rest"]
+    m._opacity, m._scaling, m._rotation, m._label = st["opacity"], st["scaling"], st["rotation"], st["label"]
+    m._generation, m._is_object = st["generation"], st["is_object"]
+    return m
+
+
+def test_ply_vertex_table_matches_what_the_reference_hands_to_plyfile():
+    from egogaussian_amd import ply
+    g = load()
+    m = _model_from(g)
+    m._opacity = torch.tensor(g["reset_opacity"])          # the capture saved the model right after reset_opacity()
+    names, table = ply.vertex_table(m)
+    assert list(names) == [str(n) for n in g["ply_names"]] and str(g["ply_element_name"]) == "vertex"
+    assert all(str(f) == "<f4" for f in g["ply_formats"])
+    assert np.array_equal(table, g["ply_table"])
+
+
+def test_ply_round_trip_and_upstream_files(tmp_path):
+    from egogaussian_amd import ply
+    g = load()
+    m = _model_from(g)
+    path = str(tmp_path / "iteration_7" / "point_cloud.ply")
+    ply.save_ply(m, path)
+    raw = open(path, "rb").read()
+    head = raw[:raw.index(b"end_header\n") + len(b"end_header\n")].decode()
+    assert head.startswith("ply\nformat binary_little_endian 1.0\nelement vertex 400\nproperty float x\n") and "property float is_object\n" in head
+    assert len(raw) == len(head) + 400 * 4 * len(g["ply_names"])
+    back = ply.load_ply(_Model(), path, train_params=True, device="cpu")
+    for a in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_label"):
+        assert isinstance(getattr(back, a), torch.nn.Parameter) and torch.equal(getattr(back, a).detach(), getattr(m, a)), a
+    assert back._generation.dtype == torch.int32 and torch.equal(back._generation, m._generation) and torch.equal(back._is_object, m._is_object)
+    assert back.max_radii2D.shape == (400,) and back.active_sh_degree == 1
+    # a file without the three extra columns (upstream 3DGS): the reference's defaults
+    names, table = ply.vertex_table(m)
+    ply.write_table(str(tmp_path / "og.ply"), names[:-3], table[:, :-3])
+    og = ply.load_ply(_Model(), str(tmp_path / "og.ply"), train_params=False, is_object=True, device="cpu")
+    assert not isinstance(og._xyz, torch.nn.Parameter) and torch.all(og._label == 0.01) and torch.all(og._generation == 0)
+    assert torch.all(og._is_object == 1)
+    assert torch.all(ply.load_ply(_Model(), str(tmp_path / "og.ply"), is_object=True, force_bg=True, device="cpu")._is_object == 0)
+    with pytest.raises(ValueError):
+        bad = _Model(); bad.max_sh_degree = 2
+        ply.load_ply(bad, path, device="cpu")

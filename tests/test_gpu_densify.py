@@ -1,0 +1,151 @@
+"""GPU: the device-side densification bookkeeping (egogaussian_amd/densify.py, csrc/densify.hip) against the fixture captured
+from the reference's GaussianModel and, at larger sizes, against the torch restatement that the fixture pins."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_densify_cpu import load, state_from, case_kwargs, assert_state_equal
+from oracle import densify_torch as D
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
+        "rotation": "_rotation", "label": "_label"}
+
+
+class Model:
+    """Duck-typed GaussianModel with a torch Adam laid out like the reference's (one named group per parameter)."""
+
+    def __init__(self, st, percent_dense=0.01, optimizer="torch"):
+        from egogaussian_amd.optim import FusedAdam
+        for k, a in ATTR.items():
+            setattr(self, a, torch.nn.Parameter(st[k].to(DEV)))
+        self._generation, self._is_object = st["generation"].to(DEV), st["is_object"].to(DEV)
+        self.xyz_gradient_accum, self.denom, self.max_radii2D = st["xyz_gradient_accum"].to(DEV), st["denom"].to(DEV), st["max_radii2D"].to(DEV)
+        self.percent_dense = percent_dense
+        groups = [{"params": [getattr(self, a)], "lr": 1e-3, "name": k} for k, a in ATTR.items()]
+        self.optimizer = (FusedAdam if optimizer == "fused" else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
+        for k, a in ATTR.items():
+            p = getattr(self, a)
+            self.optimizer.state[p] = {"step": torch.tensor(2.0), "exp_avg": st[k + "_exp_avg"].to(DEV), "exp_avg_sq": st[k + "_exp_avg_sq"].to(DEV)}
+
+    def state(self):
+        st = {}
+        for group in self.optimizer.param_groups:
+            p = group["params"][0]
+            assert p is getattr(self, ATTR[group["name"]]) and isinstance(p, torch.nn.Parameter) and p.requires_grad
+            st[group["name"]] = p.detach().cpu()
+            st[group["name"] + "_exp_avg"] = self.optimizer.state[p]["exp_avg"].cpu()
+            st[group["name"] + "_exp_avg_sq"] = self.optimizer.state[p]["exp_avg_sq"].cpu()
+            assert float(self.optimizer.state[p]["step"]) == 2.0
+        for k in ("_generation", "_is_object"):
+            st[k[1:]] = getattr(self, k).cpu()
+        for k in ("xyz_gradient_accum", "denom", "max_radii2D"):
+            st[k] = getattr(self, k).cpu()
+        return st
+
+
+def test_stats_kernel_matches_reference_fixture():
+    from egogaussian_amd import densify
+    g = load()
+    m = Model(state_from(g, "in_"))
+    vs = torch.zeros(400, 3, device=DEV, requires_grad=True)
+    for i, (grads, radii) in enumerate(zip(g["stats_grads"], g["stats_radii"])):
+        vs.grad = torch.tensor(grads, device=DEV)
+        r = torch.tensor(radii, device=DEV)
+        densify.add_densification_stats(m, vs, (r > 0) if i % 2 == 0 else None, radii=r)     # explicit filter / radii > 0
+    assert np.allclose(m.xyz_gradient_accum.cpu().numpy(), g["stats_xyz_gradient_accum"], rtol=1e-6, atol=0)
+    assert np.array_equal(m.denom.cpu().numpy(), g["stats_denom"]) and np.array_equal(m.max_radii2D.cpu().numpy(), g["stats_max_radii2D"])
+    before = m.max_radii2D.clone()
+    densify.add_densification_stats(m, vs, r > 0)                                           # without radii: max_radii2D untouched
+    assert torch.equal(m.max_radii2D, before)
+
+
+@pytest.mark.parametrize("k", range(8))
+@pytest.mark.parametrize("optimizer", ["torch", "fused"])
+def test_densify_and_prune_matches_reference_fixture(k, optimizer):
+    from egogaussian_amd import densify
+    g = load()
+    m = Model(state_from(g, f"case{k}_in_"), float(g["percent_dense"]), optimizer)
+    kw = case_kwargs(g[f"case{k}_args"])
+    n0, n1 = densify.densify_and_prune(m, z=torch.tensor(g[f"case{k}_z"], device=DEV), **kw)
+    assert n0 == 400 and n1 == g[f"case{k}_out_xyz"].shape[0]
+    assert_state_equal(m.state(), g, f"case{k}_out_")
+    # the model trains on: one more optimizer step over the new parameter objects
+    for a in ATTR.values():
+        getattr(m, a).grad = torch.ones_like(getattr(m, a))
+    m.optimizer.step()
+
+
+def test_prune_points_and_reset_opacity_match_reference():
+    from egogaussian_amd import densify
+    g = load()
+    m = Model(state_from(g, "in_"))
+    densify.reset_opacity(m)
+    assert np.allclose(m._opacity.detach().cpu().numpy(), g["reset_opacity"], rtol=1e-6, atol=1e-7)
+    assert float(m.optimizer.state[m._opacity]["exp_avg"].abs().sum()) == 0.0 and m.optimizer.param_groups[3]["params"][0] is m._opacity
+    st0 = m.state()
+    mask = torch.rand(400, generator=torch.Generator().manual_seed(3)) < 0.37
+    densify.prune_points(m, mask.to(DEV))
+    st1 = m.state()
+    for k, v in st0.items():
+        assert torch.equal(st1[k], v[~mask]), k
+
+
+def test_densify_at_scale_against_the_torch_restatement():
+    """200k Gaussians, SH degree 3, every rule active; element for element against oracle/densify_torch.py."""
+    from egogaussian_amd import densify
+    gen = torch.Generator().manual_seed(11)
+    N = 200_000
+    r = lambda *s: torch.randn(*s, generator=gen)
+    st = {"xyz": r(N, 3), "f_dc": r(N, 1, 3), "f_rest": r(N, 15, 3) * 0.1, "opacity": r(N, 1) * 2.5,
+          "scaling": torch.log(torch.rand(N, 3, generator=gen) * 0.078 + 0.002), "rotation": r(N, 4), "label": r(N, 1)}
+    for k in list(st):
+        st[k + "_exp_avg"] = r(*st[k].shape) * 1e-3; st[k + "_exp_avg_sq"] = torch.rand(*st[k].shape, generator=gen) * 1e-6
+    st["generation"] = torch.randint(0, 3, (N, 1), generator=gen, dtype=torch.int32)
+    st["is_object"] = (torch.rand(N, 1, generator=gen) < 0.3).to(torch.int32)
+    st["xyz_gradient_accum"] = torch.rand(N, 1, generator=gen) * 1.5e-3 * torch.randint(0, 4, (N, 1), generator=gen)
+    st["denom"] = torch.randint(0, 4, (N, 1), generator=gen).float()
+    st["max_radii2D"] = torch.rand(N, generator=gen) * 30
+    kw = dict(max_grad=3e-4, min_opacity=0.05, extent=4.0, max_screen_size=20, curr_gen=5, prune_prev_gen=True)
+    m = Model(st)
+    # number of split sources decides the size of z: get it from the oracle's rule, then draw z once for both sides
+    grads = st["xyz_gradient_accum"] / st["denom"]; grads[grads.isnan()] = 0
+    n_split = int(((grads.squeeze(1) >= kw["max_grad"]) & (torch.exp(st["scaling"]).max(1).values > 0.01 * kw["extent"])).sum())
+    z = r(2 * n_split, 3)
+    want = D.densify_and_prune(st, z=z, **kw)
+    n0, n1 = densify.densify_and_prune(m, z=z.to(DEV), **kw)
+    got = m.state()
+    assert n1 == want["xyz"].shape[0] and n_split > 1000 and n1 != N
+    for k, v in want.items():
+        if k in ("xyz", "scaling"):
+            assert torch.allclose(got[k], v, rtol=2e-6, atol=2e-7), k
+        else:
+            assert torch.equal(got[k], v.to(got[k].dtype)), k
+
+
+def test_densified_model_renders_and_trains():
+    """End to end on the synthetic scene: statistics from a real backward, densify, render again, step the optimizer."""
+    import math
+    from egogaussian_amd import densify
+    from egogaussian_amd.scene_synth import make_scene, make_camera, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    H, W = 96, 160
+    sc = make_scene(5000, H, W, 0); sc["log_scale"] += math.log(2.0)
+    pc = SynthGaussians(sc, device=DEV)
+    pc.training_setup()
+    cam, bg = make_camera(0, H, W, device=DEV), torch.zeros(3, device=DEV)
+    for it in range(3):
+        out = render(cam, pc, Pipe, bg)
+        out["render"].sum().backward()
+        densify.add_densification_stats(pc, out["viewspace_points"], out["visibility_filter"], radii=out["radii"])
+        pc.optimizer.step(); pc.optimizer.zero_grad(set_to_none=True)
+    assert float(pc.denom.max()) == 3.0 and float(pc.max_radii2D.max()) > 0
+    n0, n1 = densify.densify_and_prune(pc, 1e-7, 0.005, 10.0, 20)
+    assert n1 > n0 and pc._xyz.shape[0] == n1 == pc.max_radii2D.shape[0] and float(pc.denom.abs().sum()) == 0.0
+    out = render(cam, pc, Pipe, bg)
+    out["render"].sum().backward()
+    pc.optimizer.step()
+    assert all(torch.isfinite(p).all() for p in (pc._xyz, pc._scaling, pc._opacity))
