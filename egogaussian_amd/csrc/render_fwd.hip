@@ -21,6 +21,8 @@
 // (v_readlane id -> s_load_dwordx8 + x2 into SGPRs, VALU reads SGPR operands, no LDS in the loop).  Compiler-scheduled:
 // 100 us; hand-placed s_waitcnt with the next splat's s_load in flight during the blend: 86 us; LDS staging: 70 us.
 // One s_load per (wave, splat) pays an L2 round trip each, while the LDS design gathers 64 records at once a batch ahead.
+// Also rejected: one-wave workgroups with the occupancy capped through LDS padding, so that the dispatcher hands out the
+// last quadrants dynamically (8 / 6 / 5 / 4 waves per SIMD: 70 / 76 / 79 / 81 us) -- latency hiding beats balance here.
 // Arithmetic: alpha evaluation is shared with the backward (blend_common.h) so both make identical
 // keep/skip decisions.
 #include "egs_common.h"
@@ -28,29 +30,16 @@
 
 namespace {
 
-#ifdef EGS_FWD_WAVE_BLOCKS
-__global__ __launch_bounds__(64) void k_render_forward(
-#else
 __global__ __launch_bounds__(256) void k_render_forward(
-#endif
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ quad_work) {
-#ifdef EGS_FWD_WAVE_BLOCKS      // experiment: one wave per workgroup, occupancy capped by LDS padding -> the dispatcher balances
-    __shared__ float4 lds[1][64 * EGS_SPLAT_REC_F4];
-    const unsigned wi = blockIdx.x / EGS_XCDS;
-    const int tile = egs_tile_of_block((wi / 4) * EGS_XCDS + blockIdx.x % EGS_XCDS, n_tiles);
-    if (tile < 0) return;
-    const unsigned lane = threadIdx.x, q = wi % 4;
-    float4* my = lds[0];
-#else
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
     const int tile = egs_tile_of_block(blockIdx.x, n_tiles);
     if (tile < 0) return;
     const unsigned lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     float4* my = lds[q];
-#endif
     const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
     if (qx0 >= W || qy0 >= H) { if (lane == 0) quad_work[tile * 4 + q] = 0; return; }   // quadrant entirely outside the image
     const int px = qx0 + (int)(lane & 7), py = qy0 + (int)(lane >> 3);
@@ -155,11 +144,6 @@ hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs 
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
     if (n_tiles == 0) return hipSuccess;
-#ifdef EGS_FWD_WAVE_BLOCKS
-    hipLaunchKernelGGL(k_render_forward, dim3(egs_blocks_for_tiles(n_tiles) * 4), dim3(64), EGS_FWD_WAVE_BLOCKS, s, W, H, gx, n_tiles,
-                       im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, im.quad_work);
-    return hipGetLastError();
-#endif
     hipLaunchKernelGGL(k_render_forward, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                        im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, im.quad_work);
     return hipGetLastError();
