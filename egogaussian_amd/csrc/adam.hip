@@ -17,8 +17,8 @@ struct AdamArgs {
     float* p[ADAM_MAX_TENSORS]; const float* g[ADAM_MAX_TENSORS]; float* m[ADAM_MAX_TENSORS]; float* v[ADAM_MAX_TENSORS];
     long long numel[ADAM_MAX_TENSORS]; unsigned block_start[ADAM_MAX_TENSORS + 1];
     float step_size[ADAM_MAX_TENSORS], inv_bc2_sqrt[ADAM_MAX_TENSORS];
-    float* step_dev[ADAM_MAX_TENSORS]; const float* lr_dev[ADAM_MAX_TENSORS];         // capturable variant: read on the device
-    unsigned* ticket;                                                                  // capturable variant: workgroups-finished counter
+    float* step_dev[ADAM_MAX_TENSORS]; const float* lr_dev[ADAM_MAX_TENSORS];         // capturable variant: step out / lr in, on the device
+    unsigned* counter[ADAM_MAX_TENSORS];                                               // capturable variant: launches x workgroups so far
     int n; float b1, b2, eps;
 };
 
@@ -36,13 +36,25 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     const long long n = a.numel[t];
     float* __restrict__ p = a.p[t]; const float* __restrict__ g = a.g[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
     float ss = a.step_size[t], ib = a.inv_bc2_sqrt[t];
-    if (a.step_dev[t]) {                                             // wave-uniform: hipGraph replays see the current step / lr
-        // same double-precision expressions as the host computes for the non-capturable launch, so both variants take
-        // bit-identical steps (the float powf route differs by ~1e-5 relative, which Adam's eps = 1e-15 turns into visibly
-        // different trajectories for parameters whose gradients are at rounding level)
-        const double st = (double)a.step_dev[t][0] + 1.0;            // steps taken so far + this one
-        ss = (float)((double)a.lr_dev[t][0] / (1.0 - pow((double)a.b1, st)));
-        ib = (float)(1.0 / sqrt(1.0 - pow((double)a.b2, st)));
+    if (a.counter[t]) {                                              // workgroup-uniform: hipGraph replays see the current step / lr
+        // The step number is kept without any cross-workgroup traffic: every workgroup of tensor t owns one word of
+        // counter[t] holding the steps it has taken, reads it and writes it back plus one.  (Anything shared costs: ~1.7k
+        // device-scope atomics per launch on a handful of words -- a last-workgroup ticket, or a fire-and-forget
+        // launches-x-workgroups counter -- serialise at ~20 ns each and added 7 us to this 33 us kernel.)
+        // The bias corrections use the same double-precision expressions as the host computes for the non-capturable
+        // launch, so both variants take bit-identical steps; one thread per workgroup does the two pow() calls.
+        __shared__ float s_ss, s_ib;
+        if (threadIdx.x == 0) {
+            unsigned* mine = a.counter[t] + (blockIdx.x - a.block_start[t]);
+            const unsigned taken = *mine;
+            *mine = taken + 1u;
+            const double st = (double)(taken + 1u);
+            s_ss = (float)((double)a.lr_dev[t][0] / (1.0 - pow((double)a.b1, st)));
+            s_ib = (float)(1.0 / sqrt(1.0 - pow((double)a.b2, st)));
+            if (blockIdx.x == a.block_start[t]) a.step_dev[t][0] = (float)st;        // torch's state["step"], for the host to read
+        }
+        __syncthreads();
+        ss = s_ss; ib = s_ib;
     }
     const bool vec = (((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0;
 #pragma unroll
@@ -63,41 +75,27 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
             }
         }
     }
-    if (a.ticket) {
-        // The workgroup that finishes last advances every step counter: all the others have read theirs by then, so
-        // no separate "step += 1" launch per parameter is needed (five tiny kernels per iteration in the reference's
-        // optimizer layout).  The ticket returns to zero for the next launch.  No fence: nothing this workgroup WROTE is
-        // read by the last one (an agent-scope release here would write back the XCD's whole L2 per workgroup, 3x the
-        // kernel's time); its read of the counter has been consumed by the stores above before the barrier.
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (atomicAdd(a.ticket, 1u) == gridDim.x - 1) {
-                for (int k = 0; k < a.n; k++) a.step_dev[k][0] += 1.f;
-                *a.ticket = 0u;
-            }
-        }
-    }
 }
 
 }  // namespace
 
 static int adam_impl(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
-                     float* const* step_dev, const float* const* lr_dev, unsigned* ticket, float beta1, float beta2, float eps,
+                     float* const* step_dev, const float* const* lr_dev, unsigned* const* counters, float beta1, float beta2, float eps,
                      void* stream) {
     if (n_tensors < 0) return EGS_ERR_ARG;
     const bool dev = step_dev != nullptr;
     if (n_tensors && (!params || !grads || !exp_avg || !exp_avg_sq || !numels)) return EGS_ERR_ARG;
-    if (n_tensors && (dev ? (!lr_dev || !ticket) : (!lrs || !steps))) return EGS_ERR_ARG;
+    if (n_tensors && (dev ? (!lr_dev || !counters) : (!lrs || !steps))) return EGS_ERR_ARG;
     for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MAX_TENSORS) {
-        AdamArgs a; a.n = 0; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.ticket = dev ? ticket : nullptr;
+        AdamArgs a; a.n = 0; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
         unsigned blocks = 0;
         for (int t = t0; t < n_tensors && a.n < ADAM_MAX_TENSORS; t++) {
             if (numels[t] <= 0) continue;
             if (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t]) return EGS_ERR_ARG;
-            if (dev ? (!step_dev[t] || !lr_dev[t]) : steps[t] < 1) return EGS_ERR_ARG;
+            if (dev ? (!step_dev[t] || !lr_dev[t] || !counters[t]) : steps[t] < 1) return EGS_ERR_ARG;
             const int k = a.n++;
-            a.step_dev[k] = dev ? step_dev[t] : nullptr; a.lr_dev[k] = dev ? lr_dev[t] : nullptr;
+            a.step_dev[k] = dev ? step_dev[t] : nullptr; a.lr_dev[k] = dev ? lr_dev[t] : nullptr; a.counter[k] = dev ? counters[t] : nullptr;
             a.p[k] = params[t]; a.g[k] = grads[t]; a.m[k] = exp_avg[t]; a.v[k] = exp_avg_sq[t]; a.numel[k] = numels[t];
             a.block_start[k] = blocks;
             blocks += (unsigned)((numels[t] + ADAM_EPB - 1) / ADAM_EPB);
@@ -122,14 +120,17 @@ extern "C" int egs_adam_step(int n_tensors, float* const* params, const float* c
     return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, lrs, steps, nullptr, nullptr, nullptr, beta1, beta2, eps, stream);
 }
 
-// hipGraph-capturable variant: the number of steps already taken and the learning rate of every tensor are read from
-// device scalars (float[1], one per tensor, not shared between tensors) at run time; the launch itself adds one to every
-// step scalar when its last workgroup retires (`ticket`: a device uint32 that is zero between launches).  A captured
-// step therefore keeps counting across replays with no other kernel, and the host may edit the learning rates between them.
+// hipGraph-capturable variant: the learning rate of every tensor is read from a device scalar, and the step number from
+// per-workgroup device counters the launch itself advances (see k_adam): counters[t] is uint32[egs_adam_workgroups(numel_t)],
+// every word = the number of steps tensor t has taken, on entry and again on exit.  step_dev[t] (float[1]) is
+// WRITTEN with the step just taken.  A captured step therefore keeps counting across replays with no other kernel and no
+// workgroup waiting on another, and the host may edit the learning rates between replays.
+extern "C" int64_t egs_adam_workgroups(int64_t numel) { return numel <= 0 ? 0 : (numel + ADAM_EPB - 1) / ADAM_EPB; }
+
 extern "C" int egs_adam_step_capturable(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                                         float* const* exp_avg_sq, const int64_t* numels, float* const* step_dev,
-                                        const float* const* lr_dev, uint32_t* ticket, float beta1, float beta2, float eps,
+                                        const float* const* lr_dev, uint32_t* const* counters, float beta1, float beta2, float eps,
                                         void* stream) {
     if (n_tensors && !step_dev) return EGS_ERR_ARG;
-    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, nullptr, nullptr, step_dev, lr_dev, ticket, beta1, beta2, eps, stream);
+    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, nullptr, nullptr, step_dev, lr_dev, counters, beta1, beta2, eps, stream);
 }

@@ -13,7 +13,8 @@ from . import lib as _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
-    """capturable=True keeps the step count and every group's learning rate in device scalars that the kernel reads, so
+    """capturable=True keeps the step count and every group's learning rate in device scalars that the kernel reads (and, for
+    the count, advances), so
     `step()` can be captured into a hipGraph and replayed while `param_groups[i]["lr"]` keeps being edited on the host
     (call `sync_lr()` before a replay to push the edits)."""
 
@@ -21,7 +22,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.capturable = capturable
         self._lr_dev = {}
-        self._ticket = {}                 # device -> uint32 scalar the capturable kernel counts finished workgroups in
+        self._counter = {}                # (group index, index in group) -> (int32[workgroups] device counters, workgroups, numel); see k_adam
 
     def sync_lr(self):
         for gi, group in enumerate(self.param_groups):
@@ -54,17 +55,23 @@ class FusedAdam(torch.optim.Optimizer):
                     lr_t = self._lr_dev[(gi, id(p))] = torch.full((1,), float(group["lr"]), device=p.device)
                     lr_t._host_value = float(group["lr"])
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                by_cfg.setdefault((p.device, group["betas"], group["eps"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"], st["step"], lr_t))
+                # the kernel keeps the step number in one word per workgroup of this tensor and advances them itself;
+                # (re)seeded here from state["step"] when the tensor is new or its size changed (densification)
+                key, G = (gi, group["params"].index(p) if len(group["params"]) > 1 else 0), int(L.egs_adam_workgroups(p.numel()))
+                ent = self._counter.get(key)
+                if ent is None or ent[1] != G or ent[2] != p.numel() or ent[0].device != p.device:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("FusedAdam(capturable=True): take one eager step() before capturing (device counters are created then)")
+                    ent = (torch.full((max(G, 1),), int(round(float(st["step"]))), dtype=torch.int32, device=p.device), G, p.numel())
+                    self._counter[key] = ent
+                by_cfg.setdefault((p.device, group["betas"], group["eps"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"], st["step"], lr_t, ent[0]))
         for (dev, betas, eps), items in by_cfg.items():
             n = len(items)
             arr = lambda k: (C.c_void_p * n)(*[t[k].data_ptr() for t in items])
             NN = (C.c_int64 * n)(*[t[0].numel() for t in items])
-            if dev not in self._ticket:
-                self._ticket[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
-            with torch.cuda.device(dev):                             # the kernel itself advances every st["step"] by one
-                _lib.check(L.egs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), NN, arr(4), arr(5),
-                                                      C.c_void_p(self._ticket[dev].data_ptr()), float(betas[0]), float(betas[1]),
-                                                      float(eps), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            with torch.cuda.device(dev):                             # the kernel itself advances the counters and writes st["step"]
+                _lib.check(L.egs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), NN, arr(4), arr(5), arr(6), float(betas[0]),
+                                                      float(betas[1]), float(eps), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -214,14 +214,16 @@ int egs_l1_ssim_backward(int channels, int height, int width, const float* img, 
 int egs_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                   float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
                   float beta1, float beta2, float eps, void* stream);
-/* hipGraph-capturable variant: `step_dev[t]` (device float[1], one per tensor, never shared) holds the number of steps
- * tensor t has ALREADY taken and `lr_dev[t]` (device float[1]) its learning rate; both are read by the kernel.  The launch
- * adds one to every step scalar as its last workgroup retires, using `ticket` (device uint32, zero between launches), so
- * a captured iteration needs no other kernel to keep count. */
+/* hipGraph-capturable variant: `lr_dev[t]` (device float[1]) is tensor t's learning rate, read by the kernel; the step number
+ * comes from `counters[t]` (device uint32[egs_adam_workgroups(numels[t])], one array per tensor, never shared), every word of
+ * which must hold the number of steps tensor t has taken; the launch adds one to each, so a captured iteration needs no
+ * other kernel to keep count.  `step_dev[t]` (device float[1]) is WRITTEN with the number of the step
+ * just taken (torch's state["step"]). */
+int64_t egs_adam_workgroups(int64_t numel);
 int egs_adam_step_capturable(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                              float* const* exp_avg_sq, const int64_t* numels, float* const* step_dev /*HOST array of device ptrs*/,
-                             const float* const* lr_dev /*HOST array of device ptrs*/, uint32_t* ticket, float beta1, float beta2,
-                             float eps, void* stream);
+                             const float* const* lr_dev /*HOST array of device ptrs*/, uint32_t* const* counters /*HOST array of device ptrs*/,
+                             float beta1, float beta2, float eps, void* stream);
 
 /* ---- f-4 (densify / prune part): the bookkeeping of /root/reference/scene/gaussian_model.py:506-709,735-740 on the device.
  *      egs_densify_stats         per-iteration statistics in one pass: for every visible Gaussian (visible[i] != 0, or
