@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void k_cov3d_backward(int N, const float* __re
                                                          const float* __restrict__ rotation, const float* __restrict__ M,
                                                          const uint8_t* __restrict__ sel, float row0_mult,
                                                          const float* __restrict__ dcov, float* __restrict__ dscaling,
-                                                         float* __restrict__ drotation, float* __restrict__ dM) {
+                                                         float* __restrict__ drotation, float* __restrict__ dM_partial) {
+    __shared__ float wsum[4][9];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float gM[9] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     if (i < N) {
@@ -136,12 +137,30 @@ __global__ __launch_bounds__(256) void k_cov3d_backward(int N, const float* __re
 #pragma unroll
         for (int k = 0; k < 4; k++) drotation[4 * i + k] = (gq[k] - q[k] * dot) * inv;
     }
-    if (dM) {                                                              // wave-uniform branch
+    // d/dM is a sum over every Gaussian.  One float atomic per wave and component (70k device-scope atomics on nine words
+    // of one cache line at 500k Gaussians) serialises at the memory side: 896 us for this kernel instead of 9.  Workgroup
+    // partial sums are written out plainly and added up by k_cov3d_dm_finish.
+    if (dM_partial) {                                                      // workgroup-uniform branch
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             const float s = wave_sum(gM[k]);
-            if ((threadIdx.x & 63) == 0 && s != 0.f) unsafeAtomicAdd(dM + k, s);
+            if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][k] = s;
         }
+        __syncthreads();
+        if (threadIdx.x < 9) dM_partial[(size_t)blockIdx.x * 9 + threadIdx.x] = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_cov3d_dm_finish(int nblocks, const float* __restrict__ partial, float* __restrict__ dM) {
+    __shared__ float red[16];
+    for (int k = 0; k < 9; k++) {
+        float v = 0.f;
+        for (int b = threadIdx.x; b < nblocks; b += 1024) v += partial[(size_t)b * 9 + k];
+        v = wave_sum(v);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < 16; w++) t += red[w]; dM[k] = t; }
+        __syncthreads();
     }
 }
 
@@ -159,15 +178,22 @@ int egs_cov3d_forward(int N, const float* scaling, int scaling_is_log, float sca
     return (int)hipGetLastError();
 }
 
+size_t egs_cov3d_dm_scratch_floats(int N) { return N > 0 ? (size_t)((N + 255) / 256) * 9 : 0; }
+
 int egs_cov3d_backward(int N, const float* scaling, int scaling_is_log, float scale_modifier, const float* rotation, const float* M9,
                        const uint8_t* selected, float row0_grad_mult, const float* dL_dcov6, float* dL_dscaling,
-                       float* dL_drotation, float* dL_dM9, void* stream) {
+                       float* dL_drotation, float* dL_dM9, float* dM_scratch, void* stream) {
     if (N < 0) return EGS_ERR_ARG;
-    if (dL_dM9) { hipError_t e = egs_launch_zero_u32((uint32_t*)dL_dM9, 9, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
+    if (dL_dM9 && N == 0) { hipError_t e = egs_launch_zero_u32((uint32_t*)dL_dM9, 9, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     if (N == 0) return 0;
     if (!scaling || !rotation || !dL_dcov6 || !dL_dscaling || !dL_drotation) return EGS_ERR_ARG;
+    if (M9 && dL_dM9 && !dM_scratch) return EGS_ERR_ARG;
     hipLaunchKernelGGL(k_cov3d_backward, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling, scaling_is_log, scale_modifier,
-                       rotation, M9, selected, row0_grad_mult, dL_dcov6, dL_dscaling, dL_drotation, M9 ? dL_dM9 : nullptr);
+                       rotation, M9, selected, row0_grad_mult, dL_dcov6, dL_dscaling, dL_drotation, (M9 && dL_dM9) ? dM_scratch : nullptr);
+    if (dL_dM9) {
+        if (M9) hipLaunchKernelGGL(k_cov3d_dm_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, (N + 255) / 256, dM_scratch, dL_dM9);
+        else { hipError_t e = egs_launch_zero_u32((uint32_t*)dL_dM9, 9, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
+    }
     return (int)hipGetLastError();
 }
 

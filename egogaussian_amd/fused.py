@@ -58,9 +58,10 @@ class _Cov3D(torch.autograd.Function):
         dcov = dcov.float().contiguous()
         ds, dr = torch.empty_like(scaling), torch.empty_like(rotation)
         dM = torch.empty(9, device=scaling.device) if (ctx.has_M and ctx.needs_input_grad[2]) else None
+        dM_scratch = torch.empty(L.egs_cov3d_dm_scratch_floats(N), device=scaling.device) if dM is not None else None
         with torch.cuda.device(scaling.device):
             _lib.check(L.egs_cov3d_backward(N, _p(scaling), ctx.log_scaling, ctx.modifier, _p(rotation), _p(Mc), _p(sel), ctx.row0_mult,
-                                            _p(dcov), _p(ds), _p(dr), _p(dM), _stream()))
+                                            _p(dcov), _p(ds), _p(dr), _p(dM), _p(dM_scratch), _stream()))
         return ds, dr, (None if dM is None else dM.view(3, 3)), None, None, None, None
 
 

@@ -187,10 +187,13 @@ int egs_cov3d_forward(int N, const float* scaling /*[N,3]*/, int scaling_is_log,
                       const float* M9 /*[9] device, row-major, or NULL*/, const uint8_t* selected /*[N] or NULL*/,
                       float* cov6 /*[N,6] out*/, void* stream);
 /* row0_grad_mult reproduces the reference's duplicated-index gradient on Gaussian 0 (egogaussian_amd/covariance.py);
- * pass 1.0 otherwise.  dL_dM9 (device [9], may be NULL) is zeroed and accumulated by the callee. */
+ * pass 1.0 otherwise.  dL_dM9 (device [9], may be NULL) is written by the callee; when it is requested, dM_scratch must
+ * provide egs_cov3d_dm_scratch_floats(N) floats (per-workgroup partial sums, no atomics). */
+size_t egs_cov3d_dm_scratch_floats(int N);
 int egs_cov3d_backward(int N, const float* scaling, int scaling_is_log, float scale_modifier, const float* rotation, const float* M9,
                        const uint8_t* selected, float row0_grad_mult, const float* dL_dcov6 /*[N,6]*/,
-                       float* dL_dscaling /*[N,3] out*/, float* dL_drotation /*[N,4] out*/, float* dL_dM9, void* stream);
+                       float* dL_dscaling /*[N,3] out*/, float* dL_drotation /*[N,4] out*/, float* dL_dM9, float* dM_scratch,
+                       void* stream);
 
 /* ---- f-3: fused image loss (1 - lambda) * L1 + lambda * (1 - SSIM), 11x11 Gaussian window sigma 1.5, zero padding.
  *      Replaces l1_loss + ssim (/root/reference/utils/loss_utils.py:57-107) as combined at
