@@ -30,9 +30,11 @@ __device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* 
 // elementwise kernels over [N,3] per step.
 __global__ __launch_bounds__(256) void k_cov3d_forward(int N, const float* __restrict__ scaling, int log_scaling, float mod,
                                                         const float* __restrict__ rotation, const float* __restrict__ M,
-                                                        const uint8_t* __restrict__ sel, float* __restrict__ cov) {
+                                                        const uint8_t* __restrict__ sel, float* __restrict__ cov,
+                                                        const float* __restrict__ opacity_raw, float* __restrict__ opacity) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    if (opacity_raw) opacity[i] = 1.f / (1.f + expf(-opacity_raw[i]));           // opacity_activation = torch.sigmoid (gaussian_model.py:40)
     float q[4] = { rotation[4 * i], rotation[4 * i + 1], rotation[4 * i + 2], rotation[4 * i + 3] };
     const float inv = 1.f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
@@ -72,8 +74,15 @@ __global__ __launch_bounds__(256) void k_cov3d_backward(int N, const float* __re
                                                          const float* __restrict__ rotation, const float* __restrict__ M,
                                                          const uint8_t* __restrict__ sel, float row0_mult,
                                                          const float* __restrict__ dcov, float* __restrict__ dscaling,
-                                                         float* __restrict__ drotation, float* __restrict__ dM_partial) {
+                                                         float* __restrict__ drotation, float* __restrict__ dM_partial,
+                                                         const float* __restrict__ opacity, const float* __restrict__ dopacity,
+                                                         float* __restrict__ dopacity_raw) {
     __shared__ float wsum[4][9];
+    if (opacity && blockIdx.x * blockDim.x + threadIdx.x < (unsigned)N) {
+        const int j = blockIdx.x * blockDim.x + threadIdx.x;
+        const float o = opacity[j];
+        dopacity_raw[j] = dopacity[j] * ((1.f - o) * o);                        // sigmoid backward: grad * (1 - y) * y
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float gM[9] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     if (i < N) {
@@ -169,12 +178,12 @@ __global__ __launch_bounds__(1024) void k_cov3d_dm_finish(int nblocks, const flo
 extern "C" {
 
 int egs_cov3d_forward(int N, const float* scaling, int scaling_is_log, float scale_modifier, const float* rotation, const float* M9,
-                      const uint8_t* selected, float* cov6, void* stream) {
+                      const uint8_t* selected, float* cov6, const float* opacity_raw, float* opacity, void* stream) {
     if (N < 0) return EGS_ERR_ARG;
     if (N == 0) return 0;
-    if (!scaling || !rotation || !cov6) return EGS_ERR_ARG;
+    if (!scaling || !rotation || !cov6 || (opacity_raw && !opacity)) return EGS_ERR_ARG;
     hipLaunchKernelGGL(k_cov3d_forward, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling, scaling_is_log, scale_modifier,
-                       rotation, M9, selected, cov6);
+                       rotation, M9, selected, cov6, opacity_raw, opacity);
     return (int)hipGetLastError();
 }
 
@@ -182,14 +191,17 @@ size_t egs_cov3d_dm_scratch_floats(int N) { return N > 0 ? (size_t)((N + 255) / 
 
 int egs_cov3d_backward(int N, const float* scaling, int scaling_is_log, float scale_modifier, const float* rotation, const float* M9,
                        const uint8_t* selected, float row0_grad_mult, const float* dL_dcov6, float* dL_dscaling,
-                       float* dL_drotation, float* dL_dM9, float* dM_scratch, void* stream) {
+                       float* dL_drotation, float* dL_dM9, float* dM_scratch, const float* opacity, const float* dL_dopacity,
+                       float* dL_dopacity_raw, void* stream) {
     if (N < 0) return EGS_ERR_ARG;
     if (dL_dM9 && N == 0) { hipError_t e = egs_launch_zero_u32((uint32_t*)dL_dM9, 9, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     if (N == 0) return 0;
     if (!scaling || !rotation || !dL_dcov6 || !dL_dscaling || !dL_drotation) return EGS_ERR_ARG;
     if (M9 && dL_dM9 && !dM_scratch) return EGS_ERR_ARG;
+    if (opacity && (!dL_dopacity || !dL_dopacity_raw)) return EGS_ERR_ARG;
     hipLaunchKernelGGL(k_cov3d_backward, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling, scaling_is_log, scale_modifier,
-                       rotation, M9, selected, row0_grad_mult, dL_dcov6, dL_dscaling, dL_drotation, (M9 && dL_dM9) ? dM_scratch : nullptr);
+                       rotation, M9, selected, row0_grad_mult, dL_dcov6, dL_dscaling, dL_drotation, (M9 && dL_dM9) ? dM_scratch : nullptr,
+                       opacity, dL_dopacity, dL_dopacity_raw);
     if (dL_dM9) {
         if (M9) hipLaunchKernelGGL(k_cov3d_dm_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, (N + 255) / 256, dM_scratch, dL_dM9);
         else { hipError_t e = egs_launch_zero_u32((uint32_t*)dL_dM9, 9, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }

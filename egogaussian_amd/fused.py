@@ -33,36 +33,45 @@ def _need_hip(t, name):
 
 class _Cov3D(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scaling, rotation, M, selected, modifier, row0_mult, log_scaling=False):
+    def forward(ctx, scaling, rotation, M, selected, modifier, row0_mult, log_scaling=False, opacity_raw=None):
         L = _lib.load()
         scaling, rotation = _need_hip(scaling, "scaling"), _need_hip(rotation, "rotation")
         N = scaling.shape[0]
         Mc = None if M is None else _need_hip(M, "M").reshape(9)
         sel = None if selected is None else selected.to(torch.uint8).contiguous()
         cov = torch.empty((N, 6), device=scaling.device, dtype=torch.float32)
+        o_raw = None if opacity_raw is None else _need_hip(opacity_raw, "opacity_raw")
+        opacity = None if o_raw is None else torch.empty_like(o_raw)
         with torch.cuda.device(scaling.device):
             _lib.check(L.egs_cov3d_forward(N, _p(scaling), int(bool(log_scaling)), float(modifier), _p(rotation), _p(Mc), _p(sel), _p(cov),
-                                           _stream()))
-        ctx.save_for_backward(scaling, rotation, Mc if Mc is not None else torch.empty(0), sel if sel is not None else torch.empty(0))
+                                           _p(o_raw), _p(opacity), _stream()))
+        empty = torch.empty(0, device=scaling.device)
+        ctx.save_for_backward(scaling, rotation, Mc if Mc is not None else empty, sel if sel is not None else empty,
+                              opacity if opacity is not None else empty)
         ctx.modifier, ctx.row0_mult, ctx.has_M, ctx.has_sel = float(modifier), float(row0_mult), M is not None, selected is not None
-        ctx.log_scaling = int(bool(log_scaling))
-        return cov
+        ctx.log_scaling, ctx.has_opacity = int(bool(log_scaling)), opacity is not None
+        return cov if opacity is None else (cov, opacity)
 
     @staticmethod
-    def backward(ctx, dcov):
+    def backward(ctx, dcov, dopacity=None):
         L = _lib.load()
-        scaling, rotation, Mc, sel = ctx.saved_tensors
+        scaling, rotation, Mc, sel, opacity = ctx.saved_tensors
         Mc = Mc if ctx.has_M else None
         sel = sel if ctx.has_sel else None
         N = scaling.shape[0]
-        dcov = dcov.float().contiguous()
+        dcov = torch.zeros((N, 6), device=scaling.device) if dcov is None else dcov.float().contiguous()
         ds, dr = torch.empty_like(scaling), torch.empty_like(rotation)
         dM = torch.empty(9, device=scaling.device) if (ctx.has_M and ctx.needs_input_grad[2]) else None
         dM_scratch = torch.empty(L.egs_cov3d_dm_scratch_floats(N), device=scaling.device) if dM is not None else None
+        o = do = do_raw = None
+        if ctx.has_opacity:
+            o = opacity
+            do = torch.zeros_like(o) if dopacity is None else dopacity.float().contiguous()
+            do_raw = torch.empty_like(o)
         with torch.cuda.device(scaling.device):
             _lib.check(L.egs_cov3d_backward(N, _p(scaling), ctx.log_scaling, ctx.modifier, _p(rotation), _p(Mc), _p(sel), ctx.row0_mult,
-                                            _p(dcov), _p(ds), _p(dr), _p(dM), _p(dM_scratch), _stream()))
-        return ds, dr, (None if dM is None else dM.view(3, 3)), None, None, None, None
+                                            _p(dcov), _p(ds), _p(dr), _p(dM), _p(dM_scratch), _p(o), _p(do), _p(do_raw), _stream()))
+        return ds, dr, (None if dM is None else dM.view(3, 3)), None, None, None, None, do_raw
 
 
 def covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
@@ -74,6 +83,14 @@ def covariance_from_log_scaling(log_scaling, scaling_modifier, rotation):
     which saves the two elementwise launches of `get_scaling` per step.  For a reference GaussianModel:
         gaussians.get_covariance = lambda m=1: fused.covariance_from_log_scaling(gaussians._scaling, m, gaussians._rotation)"""
     return _Cov3D.apply(log_scaling, rotation, None, None, scaling_modifier, 1.0, True)
+
+
+def covariance_and_opacity(log_scaling, scaling_modifier, rotation, opacity_raw):
+    """(cov3D [N,6], opacity [N,1]) from the raw parameters in ONE launch each way: covariance_from_log_scaling plus the opacity
+    activation sigmoid (gaussian_model.py:40) and its derivative.  render() uses it when the model offers
+    `get_covariance_and_opacity(scaling_modifier)`:
+        gaussians.get_covariance_and_opacity = lambda m=1: fused.covariance_and_opacity(gaussians._scaling, m, gaussians._rotation, gaussians._opacity)"""
+    return _Cov3D.apply(log_scaling, rotation, None, None, scaling_modifier, 1.0, True, opacity_raw)
 
 
 def rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation, accum_R, is_object=None, which_object=None,

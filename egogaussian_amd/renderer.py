@@ -42,10 +42,13 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     screenspace_points = _screenspace_leaf(xyz)
     rasterizer = GaussianRasterizer(raster_settings=get_raster_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
 
-    scales = rotations = cov3D_precomp = None
+    scales = rotations = cov3D_precomp = opacity = None
     if pipe.compute_cov3D_python:
         if rot_cov:
             cov3D_precomp = pc.get_rotated_covariance(accum_R, which_object, during_training, scaling_modifier)
+        elif getattr(pc, "get_covariance_and_opacity", None) is not None:
+            # optional fused producer (fused.covariance_and_opacity): covariance and activated opacity from one launch
+            cov3D_precomp, opacity = pc.get_covariance_and_opacity(scaling_modifier)
         else:
             cov3D_precomp = pc.get_covariance(scaling_modifier)
     else:
@@ -65,7 +68,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         shs = pc.get_features
 
     image, radii, depth, alpha = rasterizer(means3D=xyz, means2D=screenspace_points, shs=shs,
-                                            colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales,
+                                            colors_precomp=colors_precomp, opacities=pc.get_opacity if opacity is None else opacity, scales=scales,
                                             rotations=rotations, cov3D_precomp=cov3D_precomp)
     from . import _C
     visible = _C.stats.get("visible_view")                 # radii > 0, written by the preprocess kernel of the call above

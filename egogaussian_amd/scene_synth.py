@@ -181,6 +181,13 @@ class SynthGaussians:
             return fused.covariance_from_log_scaling(self._scaling, scaling_modifier, self._rotation)
         return self._cov.covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
 
+    def get_covariance_and_opacity(self, scaling_modifier=1):
+        """Optional hook render() looks for: covariance and activated opacity from one fused launch (HIP devices only)."""
+        if self.fused and self._xyz.is_cuda:
+            from . import fused
+            return fused.covariance_and_opacity(self._scaling, scaling_modifier, self._rotation, self._opacity)
+        return self.get_covariance(scaling_modifier), self.get_opacity
+
     def get_rotated_covariance(self, accum_R, which_object, during_training, scaling_modifier=1):
         tom = self.trainable_object_move if during_training else None
         if self.fused and self._xyz.is_cuda:

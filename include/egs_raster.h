@@ -182,10 +182,13 @@ int egs_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  *      q <- q/|q|; L = R(q) diag(scale_modifier * scaling); rows with selected[i] != 0 (all rows if selected == NULL)
  *      get L <- M L when M9 != NULL; cov6 = unique entries of L L^T in the order (00,01,02,11,12,22).
  *      scaling_is_log != 0: `scaling` holds the raw parameters and the scaling activation exp() (gaussian_model.py:36) is
- *      applied by the kernel; the backward then returns the gradient w.r.t. the raw parameters. */
+ *      applied by the kernel; the backward then returns the gradient w.r.t. the raw parameters.
+ *      opacity_raw != NULL: the same launch also applies the opacity activation, opacity[i] = sigmoid(opacity_raw[i])
+ *      (gaussian_model.py:40), and the backward turns dL/dopacity into dL/dopacity_raw -- two elementwise launches less per step. */
 int egs_cov3d_forward(int N, const float* scaling /*[N,3]*/, int scaling_is_log, float scale_modifier, const float* rotation /*[N,4] raw*/,
                       const float* M9 /*[9] device, row-major, or NULL*/, const uint8_t* selected /*[N] or NULL*/,
-                      float* cov6 /*[N,6] out*/, void* stream);
+                      float* cov6 /*[N,6] out*/, const float* opacity_raw /*[N] or NULL*/, float* opacity /*[N] out or NULL*/,
+                      void* stream);
 /* row0_grad_mult reproduces the reference's duplicated-index gradient on Gaussian 0 (egogaussian_amd/covariance.py);
  * pass 1.0 otherwise.  dL_dM9 (device [9], may be NULL) is written by the callee; when it is requested, dM_scratch must
  * provide egs_cov3d_dm_scratch_floats(N) floats (per-workgroup partial sums, no atomics). */
@@ -193,7 +196,8 @@ size_t egs_cov3d_dm_scratch_floats(int N);
 int egs_cov3d_backward(int N, const float* scaling, int scaling_is_log, float scale_modifier, const float* rotation, const float* M9,
                        const uint8_t* selected, float row0_grad_mult, const float* dL_dcov6 /*[N,6]*/,
                        float* dL_dscaling /*[N,3] out*/, float* dL_drotation /*[N,4] out*/, float* dL_dM9, float* dM_scratch,
-                       void* stream);
+                       const float* opacity /*[N] forward output or NULL*/, const float* dL_dopacity /*[N]*/,
+                       float* dL_dopacity_raw /*[N] out*/, void* stream);
 
 /* ---- f-3: fused image loss (1 - lambda) * L1 + lambda * (1 - SSIM), 11x11 Gaussian window sigma 1.5, zero padding.
  *      Replaces l1_loss + ssim (/root/reference/utils/loss_utils.py:57-107) as combined at

@@ -65,6 +65,25 @@ def test_fused_covariance_from_raw_scaling():
     assert _close(c, d)
 
 
+def test_fused_covariance_and_opacity_in_one_launch():
+    from egogaussian_amd import fused, covariance as ref
+    gen = torch.Generator().manual_seed(9)
+    N = 6000
+    mk = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    raw, q, o = (mk(N, 3) * 0.7 - 3.0).requires_grad_(True), mk(N, 4).requires_grad_(True), (mk(N, 1) * 2).requires_grad_(True)
+    raw2, q2, o2 = [t.detach().clone().requires_grad_(True) for t in (raw, q, o)]
+    w, wo = mk(N, 6), mk(N, 1)
+    cov, op = fused.covariance_and_opacity(raw, 1.0, q, o)
+    cov2, op2 = ref.covariance_from_scaling_rotation(torch.exp(raw2), 1.0, q2), torch.sigmoid(o2)
+    assert _close(cov, cov2) and _close(op, op2, 1e-6) and op.shape == (N, 1)
+    ((cov * w).sum() + (op * wo).sum()).backward(); ((cov2 * w).sum() + (op2 * wo).sum()).backward()
+    assert _close(raw.grad, raw2.grad, 1e-4) and _close(q.grad, q2.grad, 1e-4) and _close(o.grad, o2.grad, 1e-5)
+    # only the opacity is used downstream
+    o.grad = None
+    fused.covariance_and_opacity(raw, 1.0, q, o)[1].sum().backward()
+    assert _close(o.grad, (op2 * (1 - op2)).detach(), 1e-5)
+
+
 def test_fused_covariance_trainable_rotation_gradient():
     from egogaussian_amd import fused, covariance as ref
     gen = torch.Generator().manual_seed(3)
