@@ -43,10 +43,13 @@ class _StaticCamera:
 
 
 class GraphedTrainStep:
-    def __init__(self, pc, optimizer, bg, lambda_dssim=0.2, pipe=Pipe, render_kwargs=None):
+    def __init__(self, pc, optimizer, bg, lambda_dssim=0.2, pipe=Pipe, render_kwargs=None, densify_stats=False):
+        """densify_stats: also run the per-iteration densification statistics (egogaussian_amd.densify.add_densification_stats,
+        i.e. trainers/train_static.py:125-127) inside the captured step."""
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True)")
         self.pc, self.opt, self.bg, self.lam, self.pipe = pc, optimizer, bg, lambda_dssim, pipe
+        self.densify_stats = densify_stats
         self.render_kwargs = render_kwargs or {}
         self.graph = None
         self._max_r = None
@@ -55,6 +58,9 @@ class GraphedTrainStep:
         out = render(self.cam, self.pc, self.pipe, self.bg, **self.render_kwargs)
         loss = l1_ssim_loss(out["render"], self.gt, self.lam)
         loss.backward()
+        if self.densify_stats:
+            from .densify import add_densification_stats
+            add_densification_stats(self.pc, out["viewspace_points"], out["visibility_filter"], radii=out["radii"])
         self.opt.step()
         return loss.detach(), out
 
@@ -90,6 +96,14 @@ class GraphedTrainStep:
             _C.set_running_max(dev, None)
         torch.cuda.synchronize(dev)
         return self
+
+    def recapture(self, cam=None, gt=None, warmup=1, capacity_margin=1.25):
+        """Capture again with the model as it is now -- after densification / pruning replaced the parameters, or after ok()
+        reported a frame that outgrew the capacity.  Like capture(), the `warmup` eager iterations are real training steps."""
+        cam = self.cam if cam is None else cam
+        gt = self.gt if gt is None else gt
+        self.graph = None                                            # drop the old graph and its private memory pool first
+        return self.capture(cam, gt, warmup=warmup, capacity_margin=capacity_margin)
 
     def __call__(self, cam, gt):
         """One training iteration: copy inputs in, replay.  Returns the (device, static) loss tensor."""

@@ -149,3 +149,47 @@ def test_densified_model_renders_and_trains():
     out["render"].sum().backward()
     pc.optimizer.step()
     assert all(torch.isfinite(p).all() for p in (pc._xyz, pc._scaling, pc._opacity))
+
+
+def test_graphed_training_with_statistics_then_densify_then_recapture():
+    """The whole loop a trainer runs: hipGraph-replayed iterations that also accumulate the densification statistics,
+    an eager densify_and_prune, a re-capture over the new parameters, more replayed iterations."""
+    import math
+    from egogaussian_amd import densify
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.losses import psnr
+    from egogaussian_amd.graph import GraphedTrainStep
+    H, W, N = 96, 160, 8000
+    teacher = make_scene(N, H, W, 0); teacher["log_scale"] += math.log(2.0)
+    cams = [make_camera(k, H, W, device=DEV) for k in (0, 40, 80, 120)]
+    bg = torch.zeros(3, device=DEV)
+    with torch.no_grad():
+        tpc = SynthGaussians(teacher, device=DEV, requires_grad=False)
+        gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
+    pc = SynthGaussians(perturb_student(teacher), device=DEV)
+    pc.training_setup(capturable=True)
+
+    def quality():
+        with torch.no_grad():
+            return float(sum(psnr(render(c, pc, Pipe, bg)["render"][None], g[None]) for c, g in zip(cams, gts)) / len(cams))
+    q0 = quality()
+    step = GraphedTrainStep(pc, pc.optimizer, bg, densify_stats=True).capture(cams[0], gts[0], warmup=2)
+    for k in range(30):
+        step(cams[k % 4], gts[k % 4])
+    torch.cuda.synchronize()
+    assert step.ok() and float(pc.denom.max()) == 32.0 and float(pc.xyz_gradient_accum.max()) > 0 and float(pc.max_radii2D.max()) > 0
+    q1 = quality()
+    n0, n1 = densify.densify_and_prune(pc, 1e-3, 0.005, 10.0, None)        # clones and splits; no screen-size pruning
+    assert n1 > n0 and pc._xyz.shape[0] == n1
+    qd = quality()                                                          # duplicated / resampled splats: the image changes
+    step.recapture(warmup=1)
+    qs = []
+    for k in range(60):
+        step(cams[k % 4], gts[k % 4])
+        if k in (19, 59):
+            torch.cuda.synchronize(); qs.append(quality())
+    print(f"\n  PSNR {q0:.2f} -> {q1:.2f} dB; densify {n0} -> {n1}: {qd:.2f} dB; then {qs[0]:.2f} -> {qs[1]:.2f} dB")
+    assert step.ok() and q1 > q0 + 3 and qs[1] > qs[0] > qd                # training proceeds on the new model
+    assert float(pc.optimizer.state[pc._xyz]["step"]) == 93.0 and float(pc.optimizer.state[pc._opacity]["step"]) == 93.0
+    assert float(pc.denom.max()) == 61.0                      # statistics restarted by the densification, then 1 + 60 iterations
