@@ -138,7 +138,7 @@ __global__ __launch_bounds__(EGS_SCAN_THREADS) void k_scan_apply_sum(const uint3
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tile bucketing.  A workgroup (16 waves) owns EGS_BIN_GPB consecutive Gaussians, 64 per wave.  For
+// Tile bucketing.  A workgroup (16 waves) owns `gpb` consecutive Gaussians (egs_bin_gpb), gpb / 16 per wave.  For
 // each group of 64 Gaussians the wave deals their instance slots to lanes: slot s of the group's contiguous span is
 // mapped back to its Gaussian by a 6-step search over the per-lane exclusive offsets, so lanes do equal work however
 // uneven the rectangles are.  `body(tile, gaussian_index, depth_bits)` runs once per instance.
@@ -160,13 +160,13 @@ __device__ __forceinline__ unsigned bin_logical_block(unsigned nblocks) {
 // ellipse-vs-block test the blend kernels apply per 8x8 quadrant (blend_common.h), on the whole 16x16 tile; the wave
 // parks its 64 splats' ellipse parameters in a private LDS slice and each slot-lane reads its own.
 template <typename Body>
-__device__ __forceinline__ void for_each_instance(unsigned bid, int P, const uint32_t* __restrict__ tiles_touched,
+__device__ __forceinline__ void for_each_instance(unsigned bid, int gpb, int P, const uint32_t* __restrict__ tiles_touched,
                                                   const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
                                                   bool need_depth, bool cull, int W, int H, float4* __restrict__ stage, Body body) {
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     stage += w * 128;                                                  // 64 x 2 float4 per wave
-    const int per_wave = EGS_BIN_GPB / (EGS_BIN_THREADS / 64);
-    const int first = (int)bid * EGS_BIN_GPB + (int)w * per_wave;
+    const int per_wave = gpb / (EGS_BIN_THREADS / 64);
+    const int first = (int)bid * gpb + (int)w * per_wave;
     for (int g0 = first; g0 < first + per_wave && g0 < P; g0 += 64) {
         const int i = g0 + (int)lane;
         const bool have = i < P;
@@ -220,7 +220,7 @@ __device__ __forceinline__ void for_each_instance(unsigned bid, int P, const uin
 
 extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
 
-__global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, const uint32_t* __restrict__ tiles_touched,
+__global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, int gpb, const uint32_t* __restrict__ tiles_touched,
                                                     const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
                                                     int n_tiles, uint32_t nblocks, int cull, int W, int H,
                                                     uint32_t* __restrict__ table) {
@@ -230,13 +230,13 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, const uint
     float4* stage = reinterpret_cast<float4*>(dyn_lds + ((n_tiles + 3) & ~3));
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) hist[t] = 0;
     __syncthreads();
-    for_each_instance(bid, P, tiles_touched, rect, rec, gx, false, cull != 0, W, H, stage,
+    for_each_instance(bid, gpb, P, tiles_touched, rect, rec, gx, false, cull != 0, W, H, stage,
                       [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); });
     __syncthreads();
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) table[(size_t)t * nblocks + bid] = hist[t];   // tile-major
 }
 
-__global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, const uint32_t* __restrict__ tiles_touched,
+__global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, int gpb, const uint32_t* __restrict__ tiles_touched,
                                                       const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
                                                       int n_tiles, uint32_t nblocks, int cull, int W, int H,
                                                       const uint32_t* __restrict__ table_scanned,
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, const ui
     float4* stage = reinterpret_cast<float4*>(dyn_lds + ((n_tiles + 3) & ~3));
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) cursor[t] = table_scanned[(size_t)t * nblocks + bid];
     __syncthreads();
-    for_each_instance(bid, P, tiles_touched, rect, rec, gx, true, cull != 0, W, H, stage, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
+    for_each_instance(bid, gpb, P, tiles_touched, rect, rec, gx, true, cull != 0, W, H, stage, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
         const uint32_t pos = atomicAdd(&cursor[tile], 1u);
         if (pos < cap) pairs[pos] = ((uint64_t)dbits << 32) | idx;      // cap < R only in a speculative launch that will be redone
     });
@@ -550,7 +550,11 @@ hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int 
     do { if (debug) { hipError_t e_ = hipStreamSynchronize(s); if (e_ != hipSuccess) return e_; \
                       e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } } while (0)
 
-uint32_t egs_bin_blocks(int P) { return (uint32_t)((P + EGS_BIN_GPB - 1) / EGS_BIN_GPB); }
+// The count table has one column per bucketing workgroup and one row per tile; its scan and the strided column accesses grow
+// with (tiles x workgroups), which at 2M Gaussians @ 3840x2160 (32 400 tiles) made the bucketing 2.3 ms with 1024 Gaussians per
+// workgroup.  The workgroup count is therefore capped near 512 (two per CU): gpb = 1024 x ceil(P / (1024 x 512)).
+int egs_bin_gpb(int P) { const int k = (P + EGS_BIN_GPB * 512 - 1) / (EGS_BIN_GPB * 512); return EGS_BIN_GPB * (k > 1 ? k : 1); }
+uint32_t egs_bin_blocks(int P) { const int g = egs_bin_gpb(P); return (uint32_t)((P + g - 1) / g); }
 
 hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
                               uint64_t* running_max, hipStream_t s, int debug) {
@@ -570,11 +574,11 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
         if (e != hipSuccess) return e;
     }
     egs_prof_start(EGS_K_DUPLICATE, s);
-    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, W, H, b.table);
+    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, egs_bin_gpb(P), g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, W, H, b.table);
     EGS_DBG(s);
     hipError_t e = egs_launch_scan_u32(b.table, b.table, (size_t)n_tiles * nblocks, 0, b.spine, b.total, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bin_scatter, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
+    hipLaunchKernelGGL(k_bin_scatter, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, egs_bin_gpb(P), g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
                        cull, W, H, b.table, R, b.pairs);
     egs_prof_stop(EGS_K_DUPLICATE, s);
     EGS_DBG(s);

@@ -45,7 +45,7 @@ static inline size_t egs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 #ifdef EGS_BIN_GPB_OVERRIDE
 #define EGS_BIN_GPB EGS_BIN_GPB_OVERRIDE
 #else
-#define EGS_BIN_GPB 1024                                       // Gaussians per bucketing workgroup
+#define EGS_BIN_GPB 1024                                       // Gaussians per bucketing workgroup (minimum; see egs_bin_gpb)
 #endif
 #ifdef EGS_BIN_THREADS_OVERRIDE
 #define EGS_BIN_THREADS EGS_BIN_THREADS_OVERRIDE
@@ -54,6 +54,7 @@ static inline size_t egs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 #endif
 #define EGS_MAX_TILES 36864                                    // one 4-byte LDS counter per tile must fit in 160 KiB
 uint32_t egs_bin_blocks(int P);
+int egs_bin_gpb(int P);                                          // Gaussians per bucketing workgroup for a model of P Gaussians
 #define EGS_SCAN_THREADS 256
 #define EGS_SCAN_ITEMS 8
 #define EGS_SCAN_EPB (EGS_SCAN_THREADS * EGS_SCAN_ITEMS)      // elements per block

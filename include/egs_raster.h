@@ -84,7 +84,7 @@ typedef struct egs_binning_layout {
     size_t table;          /* uint32[tiles][bin_blocks] per-(tile, block) counts, exclusive-scanned in place */
     size_t spine;          /* uint32[..] scan scratch */
     size_t total;          /* uint64[1]  instance count found by the bucketing scan (== R; may exceed a speculative capacity) */
-    int    bin_blocks;     /* workgroups of the bucketing kernels = ceil(P / 1024) */
+    int    bin_blocks;     /* workgroups of the bucketing kernels: ceil(P / gpb), gpb = 1024 * ceil(P / 524288) */
     int    key_bits;       /* significant bits of the canonical (tile<<32 | depth) key: 32 + bits(tile count) */
     int    index_passes;   /* 9-bit radix passes on the Gaussian index inside the per-tile sort, run only for tiles with depth ties
                              (+ up to 4 on depth: ceil(bits(zmax - zmin of the tile) / 9)) */
