@@ -193,3 +193,14 @@ def test_graphed_training_with_statistics_then_densify_then_recapture():
     assert step.ok() and q1 > q0 + 3 and qs[1] > qs[0] > qd                # training proceeds on the new model
     assert float(pc.optimizer.state[pc._xyz]["step"]) == 93.0 and float(pc.optimizer.state[pc._opacity]["step"]) == 93.0
     assert float(pc.denom.max()) == 61.0                      # statistics restarted by the densification, then 1 + 60 iterations
+
+
+def test_example_trainer_runs(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train_synth", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                 "examples", "train_synth.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    out = str(tmp_path / "pc.ply")
+    pc = mod.main(["--gaussians", "6000", "--height", "96", "--width", "160", "--iters", "130", "--densify-from", "40", "--densify-until", "120",
+                   "--densify-interval", "40", "--opacity-reset-interval", "80", "--frames", "8", "--out", out])
+    assert os.path.getsize(out) > 6000 * 4 * 20 and pc._xyz.shape[0] != 6000
