@@ -210,11 +210,19 @@ def main():
             traffic = ent["hbm_bytes_per_launch"] if ent else None
         except Exception:
             traffic = None
+    valu_busy = None                                             # SQ counters of the same workload (profiles/sq_counters.json)
+    sq_file = os.path.join(os.path.dirname(PMC_FILE), "sq_counters.json")
+    if os.path.exists(sq_file):
+        try:
+            valu_busy = json.load(open(sq_file)).get(f"{N}@{W}x{H}", {}).get(dominant, {}).get("valu_busy")
+        except Exception:
+            valu_busy = None
     d = stage_rows[dominant]
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": d["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(d["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(d["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": traffic, "valu_busy": valu_busy,
                 "ms_per_launch": d["ms_per_launch"], "alg_bytes_per_launch": int(d["alg_MB"] * 1e6), "timing": stage_timing,
-                "note": "blend stages are VALU/LDS-bound (per pixel-splat pair work), not HBM-bound; see `stages` for the streaming kernels"}
+                "note": "blend stages are VALU-issue-bound (per pixel-splat pair work; valu_busy = measured VALUBusy of this kernel), not HBM-bound; "
+                        "see `stages` for the streaming kernels"}
     op_ms = sum(ms / n for ms, n in stages.values() if n)
 
     cpu = None
