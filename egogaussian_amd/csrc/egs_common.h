@@ -19,11 +19,11 @@
 #define EGS_LOG2E 1.4426950408889634f
 #define EGS_LN2   0.6931471805599453f
 
-// Per-Gaussian accumulator written by the blend backward (one 48-B line per Gaussian).  With kG = dL/dG * G per
+// Per-Gaussian accumulator written by the blend backward (one 48-B line per Gaussian).  With gd = dL/dalpha * G per
 // (pixel, splat) pair and d = splat centre - pixel:
-//   [0]=sum kG dx  [1]=sum kG dy  [2]=sum kG dx^2  [3]=sum kG dx dy  [4]=sum kG dy^2  [5]=dL/dopacity
+//   [0]=sum gd dx  [1]=sum gd dy  [2]=sum gd dx^2  [3]=sum gd dx dy  [4]=sum gd dy^2  [5]=sum gd = dL/dopacity
 //   [6..8]=dL/dcolor rgb  [9]=dL/ddepth  [10..11]=pad
-// k_preprocess_backward converts the five moments into dL/dmean2D and dL/dconic with the Gaussian's own conic.
+// k_preprocess_backward converts the five moments into dL/dmean2D and dL/dconic with the Gaussian's own opacity and conic.
 #define EGS_GRAD_STRIDE 12
 
 struct EgsGeomPtrs {

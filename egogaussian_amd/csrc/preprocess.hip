@@ -249,16 +249,17 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
             acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
         }
     }
-    // acc[0..4] are moments of kG = dL/dG * G (egs_common.h); with the conic (A, B, C) of this Gaussian
-    //   dL/dmean2D = -(A Sx + B Sy, C Sy + B Sx)   and   dL/dconic = -0.5 (Sxx, Sxy, Syy)  (xy slot: half the derivative)
+    // acc[0..4] are moments of gd = dL/dalpha * G (egs_common.h); with the opacity o and the conic (A, B, C) of this Gaussian
+    //   dL/dmean2D = -o (A Sx + B Sy, C Sy + B Sx)   and   dL/dconic = -0.5 o (Sxx, Sxy, Syy)  (xy slot: half the derivative)
     // The published op reports dL/dmean2D in NDC units (x 0.5 W, 0.5 H).
     float gmx = 0.f, gmy = 0.f;
     if (vis) {
         const float4* r = rec + (size_t)i * EGS_SPLAT_REC_F4;
         const float4 r0 = r[0], r1 = r[1];
         const float cA = r0.z * (-2.f * EGS_LN2), cB = r0.w * (-EGS_LN2), cC = r1.x * (-2.f * EGS_LN2);
-        gmx = -(cA * acc[0] + cB * acc[1]); gmy = -(cC * acc[1] + cB * acc[0]);
-        acc[2] *= -0.5f; acc[3] *= -0.5f; acc[4] *= -0.5f;
+        const float o = r1.y;
+        gmx = -o * (cA * acc[0] + cB * acc[1]); gmy = -o * (cC * acc[1] + cB * acc[0]);
+        acc[2] *= -0.5f * o; acc[3] *= -0.5f * o; acc[4] *= -0.5f * o;
     }
     acc[0] = gmx * (0.5f * (float)W); acc[1] = gmy * (0.5f * (float)H);
     dmeans2D[3 * i] = acc[0]; dmeans2D[3 * i + 1] = acc[1]; dmeans2D[3 * i + 2] = 0.f;

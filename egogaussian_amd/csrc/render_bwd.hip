@@ -9,7 +9,7 @@
 //   * the colour / depth / alpha channels share ONE running accumulator: with u_j = c_j . dL/dC + d_j dL/dD
 //     + dL/dA the published per-channel recurrences collapse to U <- a_last u_last + (1 - a_last) U and
 //     dL/dalpha_j = T_j (u_j - U_j) - T_final/(1-a_j) bg . dL/dC   (algebraically identical);
-//   * the 10 per-splat partial sums (five moments of kG, opacity, rgb, depth) are reduced across the 64 lanes in three
+//   * the 10 per-splat partial sums (five moments of gd = dL/dalpha * G, opacity, rgb, depth) are reduced across the 64 lanes in three
 //     stages priced with tools/ubench/xlane_rate.hip (cycles per SIMD at 8 waves: plain VALU 2.4, DPP add 6.8,
 //     v_permlane{16,32}_swap 11.5, v_readlane 8, ds_bpermute 22):
 //       1. v_permlane32_swap "transpose-and-add" folds the ten registers into five (lanes 0-31: even value, 32-63: odd);
@@ -104,6 +104,9 @@ __global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const u
 }
 
 // 8 waves per SIMD (64 VGPRs, one spilled): every wave of a 960x540 frame is resident from the start (-2% vs 70 VGPRs / 7 waves)
+// HAS_DA: upstream gradients on the depth and / or alpha outputs exist (the training loss uses colour only: three FMAs and a
+// multiply less per (wave, splat) visit of a kernel that is 86 % VALU-busy).
+template <bool HAS_DA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_render_backward(
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         T_final = final_T[pix]; last = n_contrib[pix];
         g_r = dL_dcolor[pix]; g_g = dL_dcolor[HW + pix]; g_b = dL_dcolor[2 * HW + pix];
-        if (dL_ddepth) g_d = dL_ddepth[pix];
-        if (dL_dalpha) g_a = dL_dalpha[pix];
+        if (HAS_DA && dL_ddepth) g_d = dL_ddepth[pix];
+        if (HAS_DA && dL_dalpha) g_a = dL_dalpha[pix];
     }
     const float bg_term = -T_final * (bg[0] * g_r + bg[1] * g_g + bg[2] * g_b);
     uint32_t wmax = last;
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (mask == 0ull) continue;
         my[lane * 3 + 0] = c0; my[lane * 3 + 1] = c1; my[lane * 3 + 2] = c2;
         __builtin_amdgcn_wave_barrier();
+        const uint32_t lastb = last > base ? last - base : 0u;       // this pixel uses entries j < lastb of the batch
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << j);
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             float a = fminf(0.99f, __fmul_rn(s1.y, G));
             a = p > 0.f ? 0.f : a;
             a = a < (1.0f / 255.0f) ? 0.f : a;
-            a = (base + (uint32_t)j + 1u <= last) ? a : 0.f;            // 0 = this pixel does not use the splat
+            a = ((uint32_t)j < lastb) ? a : 0.f;                        // 0 = this pixel does not use the splat
             const bool contrib = a > 0.f;
             if (__ballot(contrib) == 0ull) continue;
 #if defined(EGS_MEASURE) && EGS_MEASURE == 4
@@ -198,22 +202,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const float rcp = __builtin_amdgcn_rcpf(1.f - a);
             const float Tn = T * rcp;                                   // transmittance in front of this splat
             const float w = a * Tn;
-            const float u = fmaf(s1.z, g_r, fmaf(s1.w, g_g, fmaf(s2.x, g_b, fmaf(s2.y, g_d, g_a))));
+            const float u = HAS_DA ? fmaf(s1.z, g_r, fmaf(s1.w, g_g, fmaf(s2.x, g_b, fmaf(s2.y, g_d, g_a))))
+                                   : fmaf(s1.z, g_r, fmaf(s1.w, g_g, s2.x * g_b));
             const float Un = fmaf(last_alpha, last_u - U, U);
             float dLda = fmaf(bg_term, rcp, (u - Un) * Tn);
             dLda = contrib ? dLda : 0.f;
             T = Tn; U = contrib ? Un : U; last_u = contrib ? u : last_u; last_alpha = contrib ? a : last_alpha;
 
-            // Per-splat sums published to the accumulator line are MOMENTS of kG = dL/dG * G over the pixels:
-            //   v0 = sum kG dx, v1 = sum kG dy, v2 = sum kG dx^2, v3 = sum kG dx dy, v4 = sum kG dy^2
-            // k_preprocess_backward turns them into d/d mean2D and d/d conic with the Gaussian's own conic
+            // Per-splat sums published to the accumulator line are MOMENTS of gd = dL/dalpha * G over the pixels:
+            //   v0 = sum gd dx, v1 = sum gd dy, v2 = sum gd dx^2, v3 = sum gd dx dy, v4 = sum gd dy^2,  v5 = sum gd
+            // k_preprocess_backward turns them into d/d mean2D and d/d conic with the Gaussian's own opacity and conic
             // (they are linear in these moments), which keeps that algebra out of the per-pixel loop.
             const float gd = G * dLda;                                  // d/d opacity
-            const float kG = s1.y * gd;
-            const float v0 = kG * dx, v1 = kG * dy;
+            const float v0 = gd * dx, v1 = gd * dy;
             const float v2 = v0 * dx, v3 = v0 * dy, v4 = v1 * dy;
             const float v5 = gd;
-            const float v6 = w * g_r, v7 = w * g_g, v8 = w * g_b, v9 = w * g_d;
+            const float v6 = w * g_r, v7 = w * g_g, v8 = w * g_b, v9 = HAS_DA ? w * g_d : 0.f;
             (void)t; (void)m; (void)nn;
 
             // 64-lane sums of v0..v9 (see the header): swap-fold, LDS regroup, quad DPP
@@ -256,8 +260,13 @@ hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs
     const unsigned zero_blocks = (unsigned)std::min<size_t>((n4 + 1023) / 1024, 1024);
     hipLaunchKernelGGL(k_backward_prologue, dim3(EGS_XCDS + zero_blocks), dim3(1024), 0, s, n_tiles, im.quad_work, im.tile_order,
                        (float4*)grad_acc, n4);
-    hipLaunchKernelGGL(k_render_backward, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
-                       im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
-                       im.tile_order, grad_acc);
+    if (dL_ddepth || dL_dalpha)
+        hipLaunchKernelGGL(k_render_backward<true>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
+                           im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
+                           im.tile_order, grad_acc);
+    else
+        hipLaunchKernelGGL(k_render_backward<false>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
+                           im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
+                           im.tile_order, grad_acc);
     return hipGetLastError();
 }
