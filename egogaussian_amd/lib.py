@@ -92,6 +92,11 @@ def profile_end():
 _lib = None
 
 
+def library_path():
+    """Path of the shared library this process loads (EGS_RASTER_LIB overrides the in-tree build)."""
+    return LIB_PATH
+
+
 def load():
     """Load (once) and return the ctypes handle.  Raises RuntimeError when the library is absent."""
     global _lib

@@ -448,3 +448,26 @@ def test_training_psnr_matches_oracle_training():
     print(f"\n  PSNR after {K} steps: gpu {results['gpu'][0]:.4f} dB, oracle chain {results['cpu'][0]:.4f} dB")
     assert rel_err(results["gpu"][1].numpy(), results["cpu"][1].numpy()) < 1e-4       # same ground truth on both sides
     assert abs(results["gpu"][0] - results["cpu"][0]) <= 0.05
+
+
+def test_integration_md_ctypes_stub_runs_as_written():
+    """The binding shown in INTEGRATION.md section 2 is executed verbatim (only the library path is substituted) and must give
+    the same forward result as the package's own _C module."""
+    import os, re
+    from egogaussian_amd import lib
+    dev = _dev()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def rasterize_forward" in b]
+    assert len(block) == 1
+    lib.load()
+    ns = {}
+    exec(block[0].replace('"libegs_raster.so"', repr(lib.library_path())), ns)
+    d = make_inputs(3000, 70, 100, 1, 0, "sh_cov", scale_mul=3.0)
+    with tile_culling(True):
+        g, out = hip_forward(d, dev)
+        R, color, depth, alpha, radii, geom, binning, img = ns["rasterize_forward"](
+            g["bg"], g["means3D"], g["opacities"], g["shs"], g["cov3D_precomp"], g["viewmatrix"], g["projmatrix"], g["campos"],
+            g["tanfovx"], g["tanfovy"], 70, 100, 0)
+    torch.cuda.synchronize()
+    assert R == out[0] and torch.equal(color, out[1]) and torch.equal(depth, out[2]) and torch.equal(alpha, out[3]) and torch.equal(radii, out[4])
