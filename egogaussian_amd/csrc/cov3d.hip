@@ -73,6 +73,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(256) void k_cov3d_backward(int N, const float* __restrict__ scaling, int log_scaling, float mod,
                                                          const float* __restrict__ rotation, const float* __restrict__ M,
                                                          const uint8_t* __restrict__ sel, float row0_mult,
+                                                         const float* __restrict__ row0_mult_dev,
                                                          const float* __restrict__ dcov, float* __restrict__ dscaling,
                                                          float* __restrict__ drotation, float* __restrict__ dM_partial,
                                                          const float* __restrict__ opacity, const float* __restrict__ dopacity,
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k_cov3d_backward(int N, const float* __re
         const float Gs[9] = { g6[0], 0.5f * g6[1], 0.5f * g6[2], 0.5f * g6[1], g6[3], 0.5f * g6[4], 0.5f * g6[2], 0.5f * g6[4], g6[5] };
         float gL[9];                                                   // dL/dL = 2 Gs L
         mat3_mul(Gs, L, gL);
-        const float mult = (moved && i == 0) ? row0_mult : 1.f;       // the reference's duplicated-index gradient (covariance.py)
+        const float mult = (moved && i == 0) ? (row0_mult_dev ? row0_mult_dev[0] : row0_mult) : 1.f;   // the reference's duplicated-index gradient (covariance.py)
 #pragma unroll
         for (int k = 0; k < 9; k++) gL[k] *= 2.f * mult;
         float gL0[9];
@@ -190,7 +191,7 @@ int egs_cov3d_forward(int N, const float* scaling, int scaling_is_log, float sca
 size_t egs_cov3d_dm_scratch_floats(int N) { return N > 0 ? (size_t)((N + 255) / 256) * 9 : 0; }
 
 int egs_cov3d_backward(int N, const float* scaling, int scaling_is_log, float scale_modifier, const float* rotation, const float* M9,
-                       const uint8_t* selected, float row0_grad_mult, const float* dL_dcov6, float* dL_dscaling,
+                       const uint8_t* selected, float row0_grad_mult, const float* row0_grad_mult_dev, const float* dL_dcov6, float* dL_dscaling,
                        float* dL_drotation, float* dL_dM9, float* dM_scratch, const float* opacity, const float* dL_dopacity,
                        float* dL_dopacity_raw, void* stream) {
     if (N < 0) return EGS_ERR_ARG;
@@ -200,7 +201,7 @@ int egs_cov3d_backward(int N, const float* scaling, int scaling_is_log, float sc
     if (M9 && dL_dM9 && !dM_scratch) return EGS_ERR_ARG;
     if (opacity && (!dL_dopacity || !dL_dopacity_raw)) return EGS_ERR_ARG;
     hipLaunchKernelGGL(k_cov3d_backward, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling, scaling_is_log, scale_modifier,
-                       rotation, M9, selected, row0_grad_mult, dL_dcov6, dL_dscaling, dL_drotation, (M9 && dL_dM9) ? dM_scratch : nullptr,
+                       rotation, M9, selected, row0_grad_mult, row0_grad_mult_dev, dL_dcov6, dL_dscaling, dL_drotation, (M9 && dL_dM9) ? dM_scratch : nullptr,
                        opacity, dL_dopacity, dL_dopacity_raw);
     if (dL_dM9) {
         if (M9) hipLaunchKernelGGL(k_cov3d_dm_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, (N + 255) / 256, dM_scratch, dL_dM9);

@@ -48,7 +48,9 @@ class _Cov3D(torch.autograd.Function):
         empty = torch.empty(0, device=scaling.device)
         ctx.save_for_backward(scaling, rotation, Mc if Mc is not None else empty, sel if sel is not None else empty,
                               opacity if opacity is not None else empty)
-        ctx.modifier, ctx.row0_mult, ctx.has_M, ctx.has_sel = float(modifier), float(row0_mult), M is not None, selected is not None
+        mult_dev = row0_mult if torch.is_tensor(row0_mult) else None          # device float[1]: no host read of the selection count
+        ctx.mult_dev = None if mult_dev is None else mult_dev.detach().float().reshape(1).contiguous()
+        ctx.modifier, ctx.row0_mult, ctx.has_M, ctx.has_sel = float(modifier), (1.0 if mult_dev is not None else float(row0_mult)), M is not None, selected is not None
         ctx.log_scaling, ctx.has_opacity = int(bool(log_scaling)), opacity is not None
         return cov if opacity is None else (cov, opacity)
 
@@ -70,7 +72,7 @@ class _Cov3D(torch.autograd.Function):
             do_raw = torch.empty_like(o)
         with torch.cuda.device(scaling.device):
             _lib.check(L.egs_cov3d_backward(N, _p(scaling), ctx.log_scaling, ctx.modifier, _p(rotation), _p(Mc), _p(sel), ctx.row0_mult,
-                                            _p(dcov), _p(ds), _p(dr), _p(dM), _p(dM_scratch), _p(o), _p(do), _p(do_raw), _stream()))
+                                            _p(ctx.mult_dev), _p(dcov), _p(ds), _p(dr), _p(dM), _p(dM_scratch), _p(o), _p(do), _p(do_raw), _stream()))
         return ds, dr, (None if dM is None else dM.view(3, 3)), None, None, None, None, do_raw
 
 
@@ -108,10 +110,12 @@ def rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation
     if which_object is not None and is_object is not None:
         sel = (is_object.reshape(-1) == which_object)
         if is_object.dim() == 2 and n > 0:
-            cnt = int(sel.sum().item())                      # host read: the count is a gradient multiplier for Gaussian 0
-            if cnt > 0:
-                mult = float(cnt + int(sel[0].item()))
-                sel = sel.clone(); sel[0] = True
+            # the reference's index quirk (covariance.py): Gaussian 0 is rotated too whenever any Gaussian is selected, and its
+            # gradient is multiplied by (count + [0 selected]).  Both are evaluated on the device -- no host read per step.
+            cnt = sel.sum()
+            mult = (cnt + sel[0]).to(torch.float32).reshape(1)
+            first = torch.logical_or(sel[0:1], (cnt > 0).reshape(1))
+            sel = sel.clone(); sel[0:1] = first
     elif is_object is not None and is_object.dim() == 2 and n > 0:
         mult = float(n + 1)
     return _Cov3D.apply(scaling, rotation, M, sel, scaling_modifier, mult, scaling_is_log)

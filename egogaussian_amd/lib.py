@@ -52,7 +52,7 @@ SIGNATURES = {
     "egs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "egs_cov3d_forward": (C.c_int, [i32, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_cov3d_dm_scratch_floats": (C.c_size_t, [i32]),
-    "egs_cov3d_backward": (C.c_int, [i32, vp, i32, f32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "egs_cov3d_backward": (C.c_int, [i32, vp, i32, f32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "egs_l1_ssim_partial_count": (C.c_size_t, [i32, i32, i32]),
     "egs_l1_ssim_forward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
     "egs_l1_ssim_backward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),

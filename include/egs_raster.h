@@ -190,11 +190,12 @@ int egs_cov3d_forward(int N, const float* scaling /*[N,3]*/, int scaling_is_log,
                       float* cov6 /*[N,6] out*/, const float* opacity_raw /*[N] or NULL*/, float* opacity /*[N] out or NULL*/,
                       void* stream);
 /* row0_grad_mult reproduces the reference's duplicated-index gradient on Gaussian 0 (egogaussian_amd/covariance.py);
- * pass 1.0 otherwise.  dL_dM9 (device [9], may be NULL) is written by the callee; when it is requested, dM_scratch must
+ * pass 1.0 otherwise; row0_grad_mult_dev (device float[1], may be NULL) overrides it with a value computed on the device, so
+ * that the caller needs no host read of the selection count.  dL_dM9 (device [9], may be NULL) is written by the callee; when it is requested, dM_scratch must
  * provide egs_cov3d_dm_scratch_floats(N) floats (per-workgroup partial sums, no atomics). */
 size_t egs_cov3d_dm_scratch_floats(int N);
 int egs_cov3d_backward(int N, const float* scaling, int scaling_is_log, float scale_modifier, const float* rotation, const float* M9,
-                       const uint8_t* selected, float row0_grad_mult, const float* dL_dcov6 /*[N,6]*/,
+                       const uint8_t* selected, float row0_grad_mult, const float* row0_grad_mult_dev, const float* dL_dcov6 /*[N,6]*/,
                        float* dL_dscaling /*[N,3] out*/, float* dL_drotation /*[N,4] out*/, float* dL_dM9, float* dM_scratch,
                        const float* opacity /*[N] forward output or NULL*/, const float* dL_dopacity /*[N]*/,
                        float* dL_dopacity_raw /*[N] out*/, void* stream);
