@@ -288,7 +288,8 @@ __device__ __forceinline__ uint32_t ts_digit(uint64_t kv, int pass, int index_pa
     return (word >> sh) & (TS_DIGITS - 1);
 }
 
-// Exclusive scan of one value per thread over the FIRST 256 threads of the workgroup (every thread must call).
+// Exclusive scan of one value per thread over the FIRST 256 threads of the workgroup (every thread must call).  The caller
+// must pass a workgroup barrier before the next call (lds4 is reused); both users end with one.
 __device__ __forceinline__ uint32_t scan_first_256(uint32_t v, uint32_t* lds4) {
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t incl = wave_incl_scan(v);
@@ -297,7 +298,6 @@ __device__ __forceinline__ uint32_t scan_first_256(uint32_t v, uint32_t* lds4) {
     uint32_t base = 0;
 #pragma unroll
     for (int k = 0; k < 3; k++) if (k < (int)w) base += lds4[k];
-    __syncthreads();
     return base + incl - v;
 }
 
@@ -428,10 +428,11 @@ __global__ __launch_bounds__(TS_THREADS) void k_tile_sort(int n_tiles, uint32_t 
         block_min_max(dmin, dmax, lds8);
         const int depth_passes = (32 - __clz((int)(dmax - dmin)) + TS_DBITS - 1) / TS_DBITS;     // 0 when every depth is equal
         const int npass = index_passes + depth_passes;
+        // Barriers per pass: 4.  Every wave clears ITS OWN counters (nobody else touches them between the barrier after the
+        // scatter and the one after the ranking), so clearing needs no workgroup barrier.
+        for (int k = lane; k < 256; k += 64) cnt[w][k] = 0;
         for (int phase = depth_passes ? 0 : 1; phase < 2; phase++) {
             for (int p = phase == 0 ? index_passes : 0; p < npass; p++) {
-                for (int k = threadIdx.x; k < TS_WAVES * 256; k += TS_THREADS) cnt[0][k] = 0;
-                __syncthreads();
                 uint32_t rank[TS_ITEMS];
 #pragma unroll
                 for (int r = 0; r < TS_ITEMS; r++) {
@@ -459,7 +460,8 @@ __global__ __launch_bounds__(TS_THREADS) void k_tile_sort(int n_tiles, uint32_t 
                     const uint32_t i = wbeg + r * 64 + lane;
                     if (r * 64u < chunk && i < n) key[r] = xbuf[i];
                 }
-                // xbuf stays intact until the next pass writes it (after two barriers), so it can be read below
+                for (int k = lane; k < 256; k += 64) cnt[w][k] = 0;     // own counters, for the next pass
+                // xbuf stays intact until the next pass writes it (after three barriers), so it can be read below
             }
             if (phase == 1) break;
             // sorted by depth: any equal-depth neighbours?
