@@ -471,3 +471,27 @@ def test_integration_md_ctypes_stub_runs_as_written():
             g["tanfovx"], g["tanfovy"], 70, 100, 0)
     torch.cuda.synchronize()
     assert R == out[0] and torch.equal(color, out[1]) and torch.equal(depth, out[2]) and torch.equal(alpha, out[3]) and torch.equal(radii, out[4])
+
+
+def test_degenerate_inputs_terminate_and_stay_bounded():
+    """NaN / inf positions, zero and huge scales, opacity 0 and 1: the launch chain must terminate with a bounded instance count
+    (every rectangle is clamped to the tile grid) and leave the pixels no degenerate splat reaches finite; forward and backward."""
+    dev = _dev()
+    N, H, W = 4000, 64, 96
+    d = make_inputs(N, H, W, 21, 0, "sh_sr", scale_mul=2.0)
+    m = d["means3D"]
+    m[0] = float("nan"); m[1, 0] = float("inf"); m[2, 2] = float("-inf"); m[3] = 0.0
+    d["scales"][10:20] = 0.0; d["scales"][20:24] = 1e6; d["scales"][24] = float("nan")
+    d["opacities"][30:40] = 0.0; d["opacities"][40:50] = 1.0
+    d["rotations"][50:55] = 0.0                                        # zero quaternion
+    for cull in (False, True):
+        with tile_culling(cull):
+            g, out = hip_forward(d, dev)
+            hb = hip_backward(g, out, seeded_grads(H, W, 4), dev)
+        torch.cuda.synchronize()
+        n_tiles = ((H + 15) // 16) * ((W + 15) // 16)
+        assert 0 < out[0] <= N * n_tiles
+        assert int((out[4] < 0).sum()) == 0                              # radii stay non-negative
+        finite = torch.isfinite(out[1]).all(dim=0)
+        assert float(finite.float().mean()) > 0.2                        # the NaN / giant splats poison only the pixels they cover
+        assert all(t.shape[0] == N for t in hb if t.numel())
