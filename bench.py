@@ -257,7 +257,7 @@ def main():
         "config": {"workload": f"S({N},{H},{W},seed0) teacher/student, 300-frame orbit, 1 frame per GPU per step; step = "
                                + ("rasterizer fwd+bwd only (seeded upstream grads on colour/depth/alpha)" if args.op_only else
                                   ("cov3D(torch) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) (torch) + bwd + Adam" if args.torch_host_ops else
-                                   "cov3D (HIP) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) (HIP) + bwd (HIP+autograd) + Adam (HIP)")),
+                                   "render fwd (HIP; activations and cov3D inside its preprocess kernel) + 0.8 L1 + 0.2 (1-SSIM) (HIP) + bwd (HIP+autograd) + Adam (HIP)")),
                    "gaussians": N, "image": [H, W], "sh_degree": 0, "instances_R": int(R_mean), "instances_after_tile_culling": int(R_kept),
                    "sort_passes_max": passes,
                    "parallelism": f"frames sharded over {world} GPU(s), scalar all-reduce only",

@@ -84,9 +84,13 @@ def _opt(t):
     return None if t is None or t.numel() == 0 else t
 
 
+ACT_LOG_SCALES, ACT_RAW_QUATS, ACT_LOGIT_OPACITY = 1, 2, 4      # include/egs_raster.h: EGS_ACT_*
+ACT_RAW_PARAMETERS = ACT_LOG_SCALES | ACT_RAW_QUATS | ACT_LOGIT_OPACITY
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
+                        prefiltered, debug, activation_flags=0):
     """-> (num_rendered, color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer)"""
     L = _lib.load()
     means3D = _f32c(means3D, "means3D")
@@ -126,14 +130,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 raise RuntimeError("rasterize_gaussians under graph capture needs a capacity from an earlier eager call")
             _lib.check(L.egs_forward_enqueue(
                 P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier),
-                _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), _ptr(background), W, H,
+                _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), _ptr(background), W, H,
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
                 _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), None, _ptr(_running_max.get(key)), _stream()))
             R = C.c_int64(cap)                      # layout size; the true count is stats["total_view"] after a sync
             rc = 0
         else:
             rc = L.egs_forward(P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
-                               float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+                               float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
                                _ptr(campos), _ptr(background), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                                _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img), _ptr(out_color), _ptr(out_depth),
                                _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _stream(), int(bool(debug)))
@@ -165,7 +169,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alpha,
-                                 debug):
+                                 debug, activation_flags=0):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
            dL_dscales[P,3], dL_drotations[P,4])"""
     L = _lib.load()
@@ -183,19 +187,20 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     M = 0 if sh is None else sh.shape[1]
     with torch.cuda.device(dev):
         e = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
-        dmeans2D, dcolors, dopacity, dmeans3D, dcov3D = e(P, 3), e(P, 3), e(P, 1), e(P, 3), e(P, 6)
-        dsh = e(P, M, 3) if sh is not None else e(0, 0, 3)
         own_cov = cov3D_precomp is None
+        dmeans2D, dcolors, dopacity, dmeans3D = e(P, 3), e(P, 3), e(P, 1), e(P, 3)
+        dcov3D = e(0, 6) if own_cov else e(P, 6)             # not produced when the library built the covariance itself
+        dsh = e(P, M, 3) if sh is not None else e(0, 0, 3)
         dscales = e(P, 3) if own_cov else e(0, 3)          # absent inputs get empty gradients (the autograd Function maps them to None)
         drots = e(P, 4) if own_cov else e(0, 4)
         if P != 0:
             scratch = torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
             _lib.check(L.egs_backward(
                 P, int(degree), M, int(R), _ptr(background), _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
-                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
                 _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
                 _ptr(imageBuffer), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(dmeans2D), _ptr(dcolors),
-                _ptr(dopacity), _ptr(dmeans3D), _ptr(dcov3D), _ptr(dsh), _ptr(dscales) if own_cov else None,
+                _ptr(dopacity), _ptr(dmeans3D), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dscales) if own_cov else None,
                 _ptr(drots) if own_cov else None, _ptr(scratch), _stream(), int(bool(debug))))
     return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots
 

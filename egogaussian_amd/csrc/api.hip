@@ -75,7 +75,9 @@ int check_dims(int P, int W, int H) {
     if ((size_t)((W + EGS_TILE - 1) / EGS_TILE) * (size_t)((H + EGS_TILE - 1) / EGS_TILE) > EGS_MAX_TILES) return EGS_ERR_RANGE;
     return 0;
 }
-int check_modes(const float* shs, const float* colors, const float* scales, const float* rots, const float* cov) {
+int check_modes(const float* shs, const float* colors, const float* scales, const float* rots, const float* cov, int act) {
+    if (act & ~(EGS_ACT_LOG_SCALES | EGS_ACT_RAW_QUATS | EGS_ACT_LOGIT_OPACITY)) return EGS_ERR_MODE;
+    if ((act & (EGS_ACT_LOG_SCALES | EGS_ACT_RAW_QUATS)) && cov != nullptr) return EGS_ERR_MODE;   // nothing to activate: the covariance is given
     if ((shs != nullptr) == (colors != nullptr)) return EGS_ERR_MODE;
     const bool sr = scales != nullptr && rots != nullptr;
     if ((scales != nullptr) != (rots != nullptr)) return EGS_ERR_MODE;
@@ -185,7 +187,7 @@ int egs_get_image_layout(int width, int height, egs_image_layout* out) {
 
 int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs,
                          const float* colors_precomp, const float* opacities, const float* scales,
-                         float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
                          const float* viewmatrix, const float* projmatrix, const float* campos, int width, int height,
                          float tan_fovx, float tan_fovy, int prefiltered, int32_t* radii, void* geom_buffer,
                          int64_t* num_rendered, void* stream, int debug) {
@@ -195,14 +197,14 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
     *num_rendered = 0;
     if (P == 0) return 0;
     if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer) return EGS_ERR_ARG;
-    rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp); if (rc) return rc;
+    rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp, activation_flags); if (rc) return rc;
     if (shs && (sh_degree < 0 || sh_degree > EGS_MAX_SH_DEGREE || sh_coeffs < (sh_degree + 1) * (sh_degree + 1))) return EGS_ERR_RANGE;
     hipStream_t s = (hipStream_t)stream;
     EgsGeomPtrs g = geom_ptrs(geom_buffer, P);
     EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
     egs_prof_start(EGS_K_PREPROCESS, s);
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
-                                  rotations, cov3D_precomp, cam, radii, g, s));
+                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     EGS_SYNC_IF_DEBUG(s);
     // R = sum of the per-block instance counts (a few KB device->host; the only host wait of the forward)
@@ -223,7 +225,7 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
 // caller finishes with egs_forward_render on a buffer of the right size.
 static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* colors_precomp,
                 const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix, const float* campos,
                 const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                 int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                 float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
@@ -240,7 +242,7 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     if (wait_for_count && !pinned_host_counts) return EGS_ERR_ARG;
     if (capacity > 0 && !binning_buffer) return EGS_ERR_ARG;
     if (!wait_for_count && capacity <= 0) return EGS_ERR_ARG;
-    rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp); if (rc) return rc;
+    rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp, activation_flags); if (rc) return rc;
     if (shs && (sh_degree < 0 || sh_degree > EGS_MAX_SH_DEGREE || sh_coeffs < (sh_degree + 1) * (sh_degree + 1))) return EGS_ERR_RANGE;
     static thread_local hipEvent_t ev = nullptr;
     if (wait_for_count && !ev) EGS_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -248,7 +250,7 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
     egs_prof_start(EGS_K_PREPROCESS, s);
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
-                                  rotations, cov3D_precomp, cam, radii, g, s));
+                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     const size_t nb = ((size_t)P + 255) / 256;
     if (pinned_host_counts) EGS_TRY(hipMemcpyAsync(pinned_host_counts, g.scan_scratch, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -274,13 +276,13 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
 
 int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* colors_precomp,
                 const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix, const float* campos,
                 const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                 int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                 float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, int64_t* num_rendered,
                 void* stream, int debug) {
     return forward_impl(1, P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
-                        cov3D_precomp, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
+                        cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
                         pinned_host_counts, nullptr, num_rendered, stream, debug);
 }
@@ -291,14 +293,14 @@ int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const
 // of instances it bucketed whenever that is larger -- one word a caller can read after any number of replays).
 int egs_forward_enqueue(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* colors_precomp,
                         const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                        const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix, const float* campos,
                         const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                         int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                         float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
                         void* stream) {
     int64_t unused = 0;
     return forward_impl(0, P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
-                        cov3D_precomp, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
+                        cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
                         pinned_host_counts, running_max, &unused, stream, 0);
 }
@@ -333,7 +335,7 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
 
 int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* background, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* rotations, const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix,
                  const float* campos, int width, int height, float tan_fovx, float tan_fovy, const int32_t* radii,
                  const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
                  const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
@@ -343,12 +345,13 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
     if (P == 0) return 0;
     if (R < 0 || R >= (1ll << 31)) return EGS_ERR_RANGE;
     if (!background || !means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer ||
-        !dL_dout_color || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !scratch)
+        !dL_dout_color || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !scratch)
         return EGS_ERR_ARG;
     if (R > 0 && !binning_buffer) return EGS_ERR_ARG;
-    rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp); if (rc) return rc;
+    rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp, activation_flags); if (rc) return rc;
     if (shs && !dL_dsh) return EGS_ERR_ARG;
     if (!cov3D_precomp && (!dL_dscales || !dL_drotations)) return EGS_ERR_ARG;
+    if (cov3D_precomp && !dL_dcov3D) return EGS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
     EgsBinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), P, R, width, height);
@@ -367,7 +370,7 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
     egs_prof_start(EGS_K_PREPROCESS_BWD, s);
     EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
     EGS_TRY(egs_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, shs, scales, scale_modifier, rotations,
-                                           cov3D_precomp, cam, radii, g, grad_acc, colors_precomp != nullptr, dL_dmeans2D,
+                                           cov3D_precomp, activation_flags, cam, radii, g, grad_acc, colors_precomp != nullptr, dL_dmeans2D,
                                            dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
                                            dL_drotations, s));
     egs_prof_stop(EGS_K_PREPROCESS_BWD, s);

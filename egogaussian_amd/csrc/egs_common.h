@@ -67,11 +67,12 @@ struct EgsCamera {
     const float* view; const float* proj; const float* campos;
     int W, H; float tanfovx, tanfovy;
 };
+// `act`: activation flags of the raw-parameter mode (include/egs_raster.h: EGS_ACT_*)
 hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
-                                 const float* opac, const float* scales, float mod, const float* rots,
+                                 const float* opac, const float* scales, float mod, const float* rots, int act,
                                  const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, hipStream_t s);
 hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* means3D, const float* shs,
-                                          const float* scales, float mod, const float* rots, const float* cov3D,
+                                          const float* scales, float mod, const float* rots, const float* cov3D, int act,
                                           EgsCamera cam, const int32_t* radii, EgsGeomPtrs g, const float* grad_acc,
                                           int colors_given, float* dmeans2D, float* dcolors, float* dopac,
                                           float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,

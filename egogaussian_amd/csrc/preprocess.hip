@@ -60,6 +60,18 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* s, float mod, 
     c6[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
 }
 
+// Raw-parameter mode (EGS_ACT_*, egs_common.h): the model's activations -- exp on the scales, normalisation of the
+// quaternion, sigmoid on the opacity (/root/reference/scene/gaussian_model.py:36-44) -- applied in place of separate
+// PyTorch launches.  `qinv` returns 1/|q_raw| for the backward.
+__device__ __forceinline__ void activate_scale_rot(int act, float* s, float* q, float& qinv) {
+    if (act & EGS_ACT_LOG_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
+    qinv = 1.f;
+    if (act & EGS_ACT_RAW_QUATS) {
+        qinv = 1.f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        q[0] *= qinv; q[1] *= qinv; q[2] *= qinv; q[3] *= qinv;
+    }
+}
+
 // Everything the forward and backward share: camera-space point, clamped Jacobian rows (J R), Sigma*m.
 struct Ewa {
     float t[3], tx, ty, txtz, tytz, limx, limy, fx, fy;
@@ -116,7 +128,7 @@ __device__ __forceinline__ float sh_channel(int deg, const float* sh, int ch, fl
 __device__ __forceinline__ uint32_t preprocess_one(
     int i, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales, float mod,
-    const float* __restrict__ rots, const float* __restrict__ cov3D_in, const float* __restrict__ V,
+    const float* __restrict__ rots, const float* __restrict__ cov3D_in, int act, const float* __restrict__ V,
     const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
     uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible) {
@@ -129,8 +141,9 @@ __device__ __forceinline__ uint32_t preprocess_one(
 #pragma unroll
         for (int k = 0; k < 6; k++) c6[k] = cov3D_in[6 * (size_t)i + k];
     } else {
-        const float s[3] = { scales[3 * i], scales[3 * i + 1], scales[3 * i + 2] };
-        const float q[4] = { rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3] };
+        float s[3] = { scales[3 * i], scales[3 * i + 1], scales[3 * i + 2] };
+        float q[4] = { rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3] };
+        float qinv; activate_scale_rot(act, s, q, qinv);
         cov3d_from_scale_rot(s, mod, q, c6);
     }
     Ewa e; ewa_project(p, c6, V, W, H, tanfovx, tanfovy, e);
@@ -170,7 +183,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
             rgb[ch] = fmaxf(v, 0.f);
         }
     }
-    const float o = opac[i];
+    const float o = (act & EGS_ACT_LOGIT_OPACITY) ? 1.f / (1.f + expf(-opac[i])) : opac[i];
 
     // Conservative pixel bounding box of {alpha >= 1/255}: the ellipse 0.5 d^T Q d <= tau with
     // tau = ln(255 o).  Not part of the published algorithm -- it only lets the blend kernels skip
@@ -211,7 +224,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
 __global__ __launch_bounds__(256) void k_preprocess(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales, float mod,
-    const float* __restrict__ rots, const float* __restrict__ cov3D_in, const float* __restrict__ V,
+    const float* __restrict__ rots, const float* __restrict__ cov3D_in, int act, const float* __restrict__ V,
     const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
     uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible,
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
     __shared__ uint32_t wsum[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t my_tiles = 0;
-    if (i < P) my_tiles = preprocess_one(i, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D_in, V, PM, campos, W, H,
+    if (i < P) my_tiles = preprocess_one(i, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D_in, act, V, PM, campos, W, H,
                                          tanfovx, tanfovy, radii, rec, rect_out, tiles_touched, clamped_out, visible);
     // per-block instance count; the host adds the block sums to get R (no contended atomic, deterministic)
 #pragma unroll
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
 
 __global__ __launch_bounds__(256) void k_preprocess_backward(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
-    const float* __restrict__ scales, float mod, const float* __restrict__ rots, const float* __restrict__ cov3D_in,
+    const float* __restrict__ scales, float mod, const float* __restrict__ rots, const float* __restrict__ cov3D_in, int act,
     const float* __restrict__ V, const float* __restrict__ PM, const float* __restrict__ campos, int W, int H,
     float tanfovx, float tanfovy, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
     const float4* __restrict__ rec, const float* __restrict__ grad_acc, float* __restrict__ dmeans2D, float* __restrict__ dcolors,
@@ -264,26 +277,30 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     acc[0] = gmx * (0.5f * (float)W); acc[1] = gmy * (0.5f * (float)H);
     dmeans2D[3 * i] = acc[0]; dmeans2D[3 * i + 1] = acc[1]; dmeans2D[3 * i + 2] = 0.f;
     dcolors[3 * i] = acc[6]; dcolors[3 * i + 1] = acc[7]; dcolors[3 * i + 2] = acc[8];
-    dopac[i] = acc[5];
+    {   // logit opacities: chain through the sigmoid with the activated value the forward parked in the record
+        const float o = rec[(size_t)i * EGS_SPLAT_REC_F4 + 1].y;
+        dopac[i] = (vis && (act & EGS_ACT_LOGIT_OPACITY)) ? acc[5] * (o * (1.f - o)) : acc[5];
+    }
     float gmean[3] = { 0.f, 0.f, 0.f }, g6[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     if (!vis) {
 #pragma unroll
         for (int k = 0; k < 3; k++) dmeans3D[3 * i + k] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 6; k++) dcov3D[6 * (size_t)i + k] = 0.f;
+        for (int k = 0; k < 6; k++) if (dcov3D) dcov3D[6 * (size_t)i + k] = 0.f;
         if (dsh) for (int k = 0; k < M * 3; k++) dsh[(size_t)i * M * 3 + k] = 0.f;
         if (dscales) { dscales[3 * i] = 0.f; dscales[3 * i + 1] = 0.f; dscales[3 * i + 2] = 0.f; }
         if (drots) { drots[4 * i] = 0.f; drots[4 * i + 1] = 0.f; drots[4 * i + 2] = 0.f; drots[4 * i + 3] = 0.f; }
         return;
     }
     const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
-    float c6[6], s[3] = { 0.f, 0.f, 0.f }, q[4] = { 1.f, 0.f, 0.f, 0.f };
+    float c6[6], s[3] = { 0.f, 0.f, 0.f }, q[4] = { 1.f, 0.f, 0.f, 0.f }, qinv = 1.f;
     if (cov3D_in) {
 #pragma unroll
         for (int k = 0; k < 6; k++) c6[k] = cov3D_in[6 * (size_t)i + k];
     } else {
         s[0] = scales[3 * i]; s[1] = scales[3 * i + 1]; s[2] = scales[3 * i + 2];
         q[0] = rots[4 * i]; q[1] = rots[4 * i + 1]; q[2] = rots[4 * i + 2]; q[3] = rots[4 * i + 3];
+        activate_scale_rot(act, s, q, qinv);
         cov3d_from_scale_rot(s, mod, q, c6);
     }
     Ewa e; ewa_project(p, c6, V, W, H, tanfovx, tanfovy, e);
@@ -306,7 +323,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
         g6[4] = 2.f * m0[2] * m0[1] * dL_da + (m0[1] * m1[2] + m0[2] * m1[1]) * dL_db + 2.f * m1[1] * m1[2] * dL_dc;
     }
 #pragma unroll
-    for (int k = 0; k < 6; k++) dcov3D[6 * (size_t)i + k] = g6[k];
+    for (int k = 0; k < 6; k++) if (dcov3D) dcov3D[6 * (size_t)i + k] = g6[k];     // NULL: only the scale / rotation gradients are wanted
 
     // cov2D -> rows of (J R) -> J -> camera-space point -> mean
     float gJ00 = 0.f, gJ02 = 0.f, gJ11 = 0.f, gJ12 = 0.f;
@@ -410,15 +427,23 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
                 gL[3 * a + k] = 2.f * (Gs[3 * a] * L[k] + Gs[3 * a + 1] * L[3 + k] + Gs[3 * a + 2] * L[6 + k]);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            dscales[3 * i + k] = mod * (gL[k] * Rm[k] + gL[3 + k] * Rm[3 + k] + gL[6 + k] * Rm[6 + k]);
+            const float ds = mod * (gL[k] * Rm[k] + gL[3 + k] * Rm[3 + k] + gL[6 + k] * Rm[6 + k]);
+            dscales[3 * i + k] = (act & EGS_ACT_LOG_SCALES) ? ds * s[k] : ds;               // d/d log-scale = d/d scale * scale
 #pragma unroll
             for (int a = 0; a < 3; a++) gR[3 * a + k] = gL[3 * a + k] * sc[k];
         }
         const float r = q[0], qx = q[1], qy = q[2], qz = q[3];
-        drots[4 * i + 0] = 2.f * (-qz * gR[1] + qy * gR[2] + qz * gR[3] - qx * gR[5] - qy * gR[6] + qx * gR[7]);
-        drots[4 * i + 1] = 2.f * (qy * gR[1] + qz * gR[2] + qy * gR[3] - 2.f * qx * gR[4] - r * gR[5] + qz * gR[6] + r * gR[7] - 2.f * qx * gR[8]);
-        drots[4 * i + 2] = 2.f * (-2.f * qy * gR[0] + qx * gR[1] + r * gR[2] + qx * gR[3] + qz * gR[5] - r * gR[6] + qz * gR[7] - 2.f * qy * gR[8]);
-        drots[4 * i + 3] = 2.f * (-2.f * qz * gR[0] - r * gR[1] + qx * gR[2] + r * gR[3] - 2.f * qz * gR[4] + qy * gR[5] + qx * gR[6] + qy * gR[7]);
+        float gq[4];
+        gq[0] = 2.f * (-qz * gR[1] + qy * gR[2] + qz * gR[3] - qx * gR[5] - qy * gR[6] + qx * gR[7]);
+        gq[1] = 2.f * (qy * gR[1] + qz * gR[2] + qy * gR[3] - 2.f * qx * gR[4] - r * gR[5] + qz * gR[6] + r * gR[7] - 2.f * qx * gR[8]);
+        gq[2] = 2.f * (-2.f * qy * gR[0] + qx * gR[1] + r * gR[2] + qx * gR[3] + qz * gR[5] - r * gR[6] + qz * gR[7] - 2.f * qy * gR[8]);
+        gq[3] = 2.f * (-2.f * qz * gR[0] - r * gR[1] + qx * gR[2] + r * gR[3] - 2.f * qz * gR[4] + qy * gR[5] + qx * gR[6] + qy * gR[7]);
+        if (act & EGS_ACT_RAW_QUATS) {                                  // back through q = q_raw / |q_raw|
+            const float dot = q[0] * gq[0] + q[1] * gq[1] + q[2] * gq[2] + q[3] * gq[3];
+#pragma unroll
+            for (int k = 0; k < 4; k++) gq[k] = (gq[k] - q[k] * dot) * qinv;
+        }
+        drots[4 * i + 0] = gq[0]; drots[4 * i + 1] = gq[1]; drots[4 * i + 2] = gq[2]; drots[4 * i + 3] = gq[3];
     }
 }
 
@@ -457,24 +482,24 @@ hipError_t egs_launch_zero_f4(float4* p, size_t n4, hipStream_t s) {
 }
 
 hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
-                                 const float* opac, const float* scales, float mod, const float* rots,
+                                 const float* opac, const float* scales, float mod, const float* rots, int act,
                                  const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, hipStream_t s) {
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(k_preprocess, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, colors, opac, scales,
-                       mod, rots, cov3D, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.tanfovx, cam.tanfovy, radii,
+                       mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.tanfovx, cam.tanfovy, radii,
                        g.rec, g.rect, g.offsets, g.clamped, g.visible, g.scan_scratch);
     return hipGetLastError();
 }
 
 hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* means3D, const float* shs,
-                                          const float* scales, float mod, const float* rots, const float* cov3D,
+                                          const float* scales, float mod, const float* rots, const float* cov3D, int act,
                                           EgsCamera cam, const int32_t* radii, EgsGeomPtrs g, const float* grad_acc,
                                           int colors_given, float* dmeans2D, float* dcolors, float* dopac,
                                           float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,
                                           hipStream_t s) {
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(k_preprocess_backward, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D,
-                       colors_given ? nullptr : shs, scales, mod, rots, cov3D, cam.view, cam.proj, cam.campos, cam.W,
+                       colors_given ? nullptr : shs, scales, mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W,
                        cam.H, cam.tanfovx, cam.tanfovy, radii, g.clamped, g.rec, grad_acc, dmeans2D, dcolors, dopac, dmeans3D,
                        dcov3D, colors_given ? nullptr : dsh, cov3D ? nullptr : dscales, cov3D ? nullptr : drots);
     return hipGetLastError();

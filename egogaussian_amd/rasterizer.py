@@ -38,13 +38,15 @@ class GaussianRasterizationSettings(NamedTuple):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                activation_flags=0):
         rs = raster_settings
         num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
-            rs.campos, rs.prefiltered, rs.debug)
+            rs.campos, rs.prefiltered, rs.debug, activation_flags)
         ctx.raster_settings = rs
+        ctx.activation_flags = int(activation_flags)
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img,
                               alpha)
@@ -67,17 +69,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos, geom,
-            ctx.num_rendered, binning, img, alpha, rs.debug)
+            ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags)
         none_if_absent = lambda g, x: g if x.numel() != 0 else None
         return (g_means3D, g_means2D, none_if_absent(g_sh, sh), none_if_absent(g_colors, colors_precomp),
                 g_opac, none_if_absent(g_scales, scales),
-                none_if_absent(g_rots, rotations), none_if_absent(g_cov3D, cov3Ds_precomp), None)
+                none_if_absent(g_rots, rotations), none_if_absent(g_cov3D, cov3Ds_precomp), None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, activation_flags=0):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, activation_flags)
 
 
 class GaussianRasterizer(nn.Module):
@@ -91,7 +93,10 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, raw_parameters=False):
+        """Same call as upstream's.  raw_parameters=True (an extension): `scales`, `rotations` and `opacities` are the model's RAW
+        parameters (log-scales, unnormalised quaternions, opacity logits); the activations run inside the preprocess kernel and
+        the gradients come back w.r.t. the raw tensors (include/egs_raster.h, EGS_ACT_*)."""
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("GaussianRasterizer: pass exactly one of `shs` or `colors_precomp`")
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -103,5 +108,7 @@ class GaussianRasterizer(nn.Module):
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        if raw_parameters and cov3D_precomp.numel() != 0:
+            raise Exception("GaussianRasterizer: raw_parameters needs `scales` and `rotations`, not `cov3D_precomp`")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   self.raster_settings)
+                                   self.raster_settings, _C.ACT_RAW_PARAMETERS if raw_parameters else 0)

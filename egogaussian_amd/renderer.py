@@ -43,9 +43,15 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     rasterizer = GaussianRasterizer(raster_settings=get_raster_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
 
     scales = rotations = cov3D_precomp = opacity = None
+    raw = False
     if pipe.compute_cov3D_python:
         if rot_cov:
             cov3D_precomp = pc.get_rotated_covariance(accum_R, which_object, during_training, scaling_modifier)
+        elif getattr(pc, "get_raw_parameters", None) is not None and pc.get_raw_parameters() is not None:
+            # optional hook: hand the RAW parameters to the rasterizer, which applies exp / normalize / sigmoid itself and builds
+            # the covariance in its preprocess kernel -- no activation or covariance launches at all (rasterizer.py)
+            scales, rotations, opacity = pc.get_raw_parameters()
+            raw = True
         elif getattr(pc, "get_covariance_and_opacity", None) is not None:
             # optional fused producer (fused.covariance_and_opacity): covariance and activated opacity from one launch
             cov3D_precomp, opacity = pc.get_covariance_and_opacity(scaling_modifier)
@@ -69,7 +75,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
 
     image, radii, depth, alpha = rasterizer(means3D=xyz, means2D=screenspace_points, shs=shs,
                                             colors_precomp=colors_precomp, opacities=pc.get_opacity if opacity is None else opacity, scales=scales,
-                                            rotations=rotations, cov3D_precomp=cov3D_precomp)
+                                            rotations=rotations, cov3D_precomp=cov3D_precomp, **({"raw_parameters": True} if raw else {}))
     from . import _C
     visible = _C.stats.get("visible_view")                 # radii > 0, written by the preprocess kernel of the call above
     if visible is None or visible.shape != radii.shape or visible.device != radii.device:

@@ -181,6 +181,13 @@ class SynthGaussians:
             return fused.covariance_from_log_scaling(self._scaling, scaling_modifier, self._rotation)
         return self._cov.covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
 
+    def get_raw_parameters(self):
+        """Optional hook render() looks for: (log-scales, raw quaternions, opacity logits) for the rasterizer's raw-parameter
+        mode (HIP devices only; None otherwise)."""
+        if self.fused and self._xyz.is_cuda:
+            return self._scaling, self._rotation, self._opacity
+        return None
+
     def get_covariance_and_opacity(self, scaling_modifier=1):
         """Optional hook render() looks for: covariance and activated opacity from one fused launch (HIP devices only)."""
         if self.fused and self._xyz.is_cuda:

@@ -101,11 +101,21 @@ int egs_get_binning_layout(int P, int64_t R, int width, int height, egs_binning_
 int egs_get_image_layout(int width, int height, egs_image_layout* out);
 
 /* ---- forward, part 1: per-Gaussian geometry + instance count  (upstream: preprocess + InclusiveSum) ------ */
+/* Raw-parameter mode.  The reference activates its parameters with three PyTorch ops before every render
+ * (/root/reference/scene/gaussian_model.py:36-44: scaling exp, rotation normalize, opacity sigmoid).  With these flags the
+ * forward applies them inside the preprocess kernel and the backward returns the gradients w.r.t. the RAW tensors:
+ *   EGS_ACT_LOG_SCALES     `scales` holds log-scales            (only with scales + rotations, not with cov3D_precomp)
+ *   EGS_ACT_RAW_QUATS      `rotations` is not normalised        (likewise)
+ *   EGS_ACT_LOGIT_OPACITY  `opacities` holds logits
+ * Pass the SAME flags to the forward and to egs_backward. */
+#define EGS_ACT_LOG_SCALES 1
+#define EGS_ACT_RAW_QUATS 2
+#define EGS_ACT_LOGIT_OPACITY 4
 int egs_forward_geometry(
     int P, int sh_degree, int sh_coeffs /* M: coefficients per channel in `shs` */,
     const float* means3D /*[P,3]*/, const float* shs /*[P,M,3] or NULL*/, const float* colors_precomp /*[P,3] or NULL*/,
     const float* opacities /*[P]*/, const float* scales /*[P,3] or NULL*/, float scale_modifier,
-    const float* rotations /*[P,4] or NULL*/, const float* cov3D_precomp /*[P,6] or NULL*/,
+    const float* rotations /*[P,4] or NULL*/, const float* cov3D_precomp /*[P,6] or NULL*/, int activation_flags /*EGS_ACT_*, 0 = none*/,
     const float* viewmatrix /*[16]*/, const float* projmatrix /*[16]*/, const float* campos /*[3]*/,
     int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
     int32_t* radii /*[P] out*/, void* geom_buffer, int64_t* num_rendered /*HOST out: R*/,
@@ -131,7 +141,7 @@ int egs_forward_render(
 int egs_forward(
     int P, int sh_degree, int sh_coeffs,
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
-    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
     const float* viewmatrix, const float* projmatrix, const float* campos, const float* background,
     int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
     int32_t* radii /*[P] out*/, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
@@ -147,7 +157,7 @@ int egs_forward(
 int egs_forward_enqueue(
     int P, int sh_degree, int sh_coeffs,
     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
-    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
     const float* viewmatrix, const float* projmatrix, const float* campos, const float* background,
     int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
     int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
@@ -158,7 +168,7 @@ int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts /*HOST*/);
 int egs_backward(
     int P, int sh_degree, int sh_coeffs, int64_t R,
     const float* background, const float* means3D, const float* shs, const float* colors_precomp,
-    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
     const float* viewmatrix, const float* projmatrix, const float* campos,
     int width, int height, float tan_fovx, float tan_fovy,
     const int32_t* radii, const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
@@ -166,7 +176,7 @@ int egs_backward(
     const float* dL_dout_alpha /*[1,H,W] or NULL*/,
     float* dL_dmeans2D /*[P,3] out, NDC-scaled (x 0.5*W, 0.5*H), z = 0*/,
     float* dL_dcolors /*[P,3] out*/, float* dL_dopacity /*[P] out*/, float* dL_dmeans3D /*[P,3] out*/,
-    float* dL_dcov3D /*[P,6] out*/, float* dL_dsh /*[P,M,3] out or NULL*/,
+    float* dL_dcov3D /*[P,6] out; may be NULL with scales + rotations*/, float* dL_dsh /*[P,M,3] out or NULL*/,
     float* dL_dscales /*[P,3] out or NULL*/, float* dL_drotations /*[P,4] out or NULL*/,
     void* scratch /* egs_backward_scratch_bytes(P) */, void* stream, int debug);
 

@@ -495,3 +495,46 @@ def test_degenerate_inputs_terminate_and_stay_bounded():
         finite = torch.isfinite(out[1]).all(dim=0)
         assert float(finite.float().mean()) > 0.2                        # the NaN / giant splats poison only the pixels they cover
         assert all(t.shape[0] == N for t in hb if t.numel())
+
+
+@pytest.mark.parametrize("colour_mode", ["sh", "col"])
+def test_raw_parameter_mode_matches_activated_inputs(colour_mode):
+    """EGS_ACT_*: log-scales, unnormalised quaternions and opacity logits activated inside the preprocess kernel must give
+    the images of the call with torch-activated inputs, and gradients that are those of the activated call chained through
+    exp / normalize / sigmoid by autograd."""
+    from egogaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    dev = _dev()
+    N, H, W = 5000, 96, 128
+    d = make_inputs(N, H, W, 13, 0, "sh_sr" if colour_mode == "sh" else "col_sr", scale_mul=2.5)
+    g = _to(d, dev)
+    gen = torch.Generator().manual_seed(0)
+    raw_s = torch.log(g["scales"]).detach()
+    raw_q = (g["rotations"] * (0.5 + 2.0 * torch.rand(N, 1, generator=gen).to(dev))).detach()        # any positive multiple of a unit quaternion
+    raw_o = torch.logit(g["opacities"].clamp(1e-4, 1 - 1e-4)).detach()
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=g["tanfovx"], tanfovy=g["tanfovy"], bg=g["bg"],
+                                       scale_modifier=g["scale_modifier"], viewmatrix=g["viewmatrix"], projmatrix=g["projmatrix"],
+                                       sh_degree=g["sh_degree"], campos=g["campos"], prefiltered=False, debug=False)
+    grads = [t.to(dev) for t in seeded_grads(H, W, 3)]
+    res = []
+    for raw in (False, True):
+        s, q, o = [t.clone().requires_grad_(True) for t in (raw_s, raw_q, raw_o)]
+        xyz = g["means3D"].clone().requires_grad_(True)
+        kw = dict(shs=g["shs"]) if colour_mode == "sh" else dict(colors_precomp=g["colors_precomp"])
+        if raw:
+            out = GaussianRasterizer(rs)(means3D=xyz, means2D=torch.zeros_like(xyz), opacities=o, scales=s, rotations=q, raw_parameters=True, **kw)
+        else:
+            out = GaussianRasterizer(rs)(means3D=xyz, means2D=torch.zeros_like(xyz), opacities=torch.sigmoid(o), scales=torch.exp(s),
+                                         rotations=torch.nn.functional.normalize(q), **kw)
+        color, radii, depth, alpha = out
+        ((color * grads[0]).sum() + (depth * grads[1]).sum() + (alpha * grads[2]).sum()).backward()
+        res.append((color.detach(), depth.detach(), alpha.detach(), radii, xyz.grad, s.grad, q.grad, o.grad))
+    a, b = res
+    assert float((a[3] != b[3]).float().mean()) < 1e-3                   # radii: the activations differ in the last ulp at most
+    for k, name in ((0, "colour"), (1, "depth"), (2, "alpha")):
+        assert outlier_fraction(b[k].cpu().numpy(), a[k].cpu().numpy(), TOL) <= 1e-4, name
+    for k, name in ((4, "d/dxyz"), (5, "d/dlog-scale"), (6, "d/dquat"), (7, "d/dlogit")):
+        assert outlier_fraction(b[k].cpu().numpy(), a[k].cpu().numpy(), 2e-4) <= 2e-4, name
+        assert rel_err(b[k].cpu().numpy(), a[k].cpu().numpy()) < 5e-3, name
+    with pytest.raises(Exception, match="raw_parameters"):
+        GaussianRasterizer(rs)(means3D=g["means3D"], means2D=g["means3D"], opacities=raw_o, cov3D_precomp=torch.zeros(N, 6, device=dev),
+                               raw_parameters=True, **kw)
