@@ -169,7 +169,10 @@ class SynthGaussians:
     @property
     def get_opacity(self): return torch.sigmoid(self._opacity)
     @property
-    def get_features(self): return torch.cat((self._features_dc, self._features_rest), dim=1)
+    def get_features(self):
+        if self._features_rest.shape[1] == 0:                # SH degree 0: nothing to concatenate (torch.cat would still copy)
+            return self._features_dc
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
     @property
     def get_label(self): return self._label
     @property
