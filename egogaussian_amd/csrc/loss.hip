@@ -79,25 +79,26 @@ __device__ __forceinline__ void vblur(const Window<NV>& w, float (&out)[NV]) {
 
 struct FwdCtx {
     int H, W, gx, y_first, y_end; size_t plane; bool col_ok, col_out; unsigned lane;
-    const float* img; const float* gt; float* dm_dmu1; float* dm_dexx; float* dm_dexy; float* rows;   // rows: [5][80] floats
+    const float* img; const float* gt; float* dm_dmu1; float* dm_dexx; float* dm_dexy; float* rows;   // rows: [4][80] floats
     float l1, sm;
 };
 
 // One input row enters (slot NEWEST); if 11 rows are in, the output row 5 above it leaves.
 template <int NEWEST>
-__device__ __forceinline__ void fwd_step(FwdCtx& c, Window<5>& w, int y_in, float u, float v) {
-    w.v[0][NEWEST] = u; w.v[1][NEWEST] = v; w.v[2][NEWEST] = u * u; w.v[3][NEWEST] = v * v; w.v[4][NEWEST] = u * v;
+__device__ __forceinline__ void fwd_step(FwdCtx& c, Window<4>& w, int y_in, float u, float v) {
+    // SSIM uses the two variances only as their sum, so E[x^2] and E[y^2] are blurred together: four maps, not five
+    w.v[0][NEWEST] = u; w.v[1][NEWEST] = v; w.v[2][NEWEST] = fmaf(u, u, v * v); w.v[3][NEWEST] = u * v;
     const int y_out = y_in - HALO;
     if (y_out < c.y_first || y_out >= c.y_end) return;                  // wave-uniform
-    float vb[5];
-    vblur<5, NEWEST>(w, vb);
-    float hbv[5];
-    hblur<5>(vb, hbv, c.rows, c.lane);
-    const float mu1 = hbv[0], mu2 = hbv[1], exx = hbv[2], eyy = hbv[3], exy = hbv[4];
+    float vb[4];
+    vblur<4, NEWEST>(w, vb);
+    float hbv[4];
+    hblur<4>(vb, hbv, c.rows, c.lane);
+    const float mu1 = hbv[0], mu2 = hbv[1], exx_eyy = hbv[2], exy = hbv[3];
     if (c.col_out) {
         const float C1 = 0.0001f, C2 = 0.0009f;
-        const float s1 = exx - mu1 * mu1, s2 = eyy - mu2 * mu2, s12 = exy - mu1 * mu2;
-        const float A = 2.f * mu1 * mu2 + C1, B = 2.f * s12 + C2, D = mu1 * mu1 + mu2 * mu2 + C1, E = s1 + s2 + C2;
+        const float s12 = exy - mu1 * mu2;
+        const float A = 2.f * mu1 * mu2 + C1, B = 2.f * s12 + C2, D = mu1 * mu1 + mu2 * mu2 + C1, E = (exx_eyy - (D - C1)) + C2;
         const float invDE = 1.f / (D * E);
         const float sm = A * B * invDE;
         // partial derivatives of the map holding the other windowed moments fixed
@@ -116,11 +117,11 @@ __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_forward(int H, int W, int 
                                                                const float* __restrict__ gt, float* __restrict__ partial,
                                                                float* __restrict__ dm_dmu1, float* __restrict__ dm_dexx,
                                                                float* __restrict__ dm_dexy) {
-    __shared__ float lds[WPB][5 * 80];
+    __shared__ float lds[WPB][4 * 80];
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int strip = blockIdx.x * WPB + (int)wv;
     if (strip >= strips_x * strips_y) return;
-    for (int k = lane; k < 5 * 80; k += 64) lds[wv][k] = 0.f;           // the padding words stay zero
+    for (int k = lane; k < 4 * 80; k += 64) lds[wv][k] = 0.f;           // the padding words stay zero
     __builtin_amdgcn_wave_barrier();
     FwdCtx c;
     c.H = H; c.W = W; c.lane = lane; c.img = img; c.gt = gt; c.dm_dmu1 = dm_dmu1; c.dm_dexx = dm_dexx; c.dm_dexy = dm_dexy;
@@ -130,9 +131,9 @@ __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_forward(int H, int W, int 
     c.col_ok = c.gx >= 0 && c.gx < W;
     c.col_out = c.col_ok && lane >= HALO && lane < HALO + SW;
     c.y_first = sy * SR; c.y_end = min(c.y_first + SR, H);
-    Window<5> w;
+    Window<4> w;
 #pragma unroll
-    for (int m = 0; m < 5; m++)
+    for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int k = 0; k < 11; k++) w.v[m][k] = 0.f;
     // input rows y_first - 5 .. y_end + 4, eleven per trip so that every window slot index is a compile-time constant;
