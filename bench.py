@@ -40,12 +40,12 @@ def algorithmic_bytes(stage, N, R, npix):
     """Bytes one launch of `stage` must move at minimum: per-unit figures x units.  R = instances the
     launch actually processes (after tile culling)."""
     return {
-        "preprocess": 52 * N + 48 * N,                 # xyz 12 + cov 24 + opacity 4 + sh 12 in; record 48 out
+        "preprocess": 56 * N + 48 * N,                 # xyz 12 + log-scale 12 + quaternion 16 + opacity logit 4 + sh 12 in; record 48 out
         "tile_bucket": 2 * (16 + 32) * N + 8 * R,      # two walks over (tiles_touched, rect, depth | ellipse) per Gaussian; one pair out per instance
         "tile_sort": 8 * R + 4 * R,                    # pair in, index out; the radix passes stay in registers/LDS
         "render_forward": 4 * R + 48 * R + 28 * npix,  # id + record per instance; 7 floats per pixel out
         "render_backward": 4 * R + 48 * R + 40 * R + 32 * npix,   # + one 40-byte accumulate per instance; 8 floats/pixel in
-        "preprocess_backward": 48 * N + 52 * N + 100 * N,          # accumulator + inputs in; grads out
+        "preprocess_backward": 48 * N + 56 * N + 32 * N + 80 * N,  # accumulator + inputs + record head in; grads out (xyz, mean2D, scale, quat, sh, colour, opacity)
     }[stage]
 
 
