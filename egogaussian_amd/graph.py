@@ -87,7 +87,8 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         _C.set_running_max(dev, self._max_r)
         try:
-            with torch.cuda.graph(self.graph):
+            # thread_local: calls other threads make meanwhile (e.g. the RCCL watchdog polling its events) must not abort the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss, out = self._body()
                 self.image = out["render"].detach()
                 self.radii = out["radii"]
