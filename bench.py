@@ -134,12 +134,16 @@ def main():
     eager_step = step
     if use_graph:                                               # the whole iteration as one hipGraph (egogaussian_amd/graph.py)
         from egogaussian_amd.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(pc, opt, bg, 0.2).capture(cams[0], gts[0], warmup=2)
-
-        def step(i):                                            # noqa: F811
-            k = i % n_used
-            loss_acc.add_(graphed(cams[k], gts[k]))
-            r_sum[1] += 1
+        try:
+            graphed = GraphedTrainStep(pc, opt, bg, 0.2).capture(cams[0], gts[0], warmup=2)
+        except Exception as exc:                                # keep measuring, eagerly, rather than lose the run
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); stepping eagerly", file=sys.stderr)
+            graphed, use_graph = None, False
+        if graphed is not None:
+            def step(i):                                        # noqa: F811
+                k = i % n_used
+                loss_acc.add_(graphed(cams[k], gts[k]))
+                r_sum[1] += 1
     for i in range(args.warmup):
         step(i)
     loss_acc.zero_(); r_sum[:] = [0, 0]
