@@ -61,6 +61,8 @@ __device__ __forceinline__ float row_sum(float v) {
 // of a workgroup then work on unrelated tiles and stop sharing list and record lines in the CU's L1; (b) dealing each
 // tile's quadrants to the CU's SIMDs by cost (a wave reads its SIMD from HW_ID): per-SIMD spread +-16% -> +-10%, but the
 // CU-level spread (-12%/+8% of blended splats) then bounds the launch and the longer prologue cancels the 2 us gained.
+// (c) running this prologue on a second stream right after the forward, so that it overlaps the loss kernels (fork / join
+// captured into the hipGraph): the step got 3 % SLOWER -- the graph's cross-stream dependencies cost more than the 11 us hidden.
 #define ORDER_MAX_BAND 2048
 __global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const uint32_t* __restrict__ quad_work,
                                                              uint32_t* __restrict__ tile_order, float4* __restrict__ acc4, size_t n4) {
