@@ -46,8 +46,8 @@ def set_tile_culling(on):
 
 
 def last_instance_count(device=None, P=None):
-    """R of the most recent forward on `device`, summed from the page-locked per-workgroup counts.  Only meaningful after
-    the stream has been synchronised; this is how a graph-replayed step is checked against its capacity."""
+    """R (rectangle instances) of the most recent EAGER forward on `device`, summed from the page-locked per-workgroup counts
+    that call copied out.  Captured forwards skip the copy; they are checked through set_running_max / stats["total_view"]."""
     key = torch.cuda.current_device() if device is None else torch.device(device).index
     pinned = _pinned_counts.get(key)
     if pinned is None:
