@@ -20,12 +20,29 @@ from .renderer import render
 from .scene_synth import Pipe
 
 
+def pack_camera(cam):
+    """The three camera tensors render() reads, as one float32[35] block: world_view_transform, full_proj_transform, camera_center."""
+    return torch.cat([cam.world_view_transform.reshape(-1), cam.full_proj_transform.reshape(-1), cam.camera_center.reshape(-1)]).float()
+
+
+def pack_frame(cam, gt):
+    """One resident tensor per training frame: the ground-truth image followed by the camera block.  GraphedTrainStep(frame) then
+    refreshes both static inputs of the captured step with ONE device copy."""
+    return torch.cat([gt.reshape(-1).float(), pack_camera(cam).to(gt.device)])
+
+
 class _StaticCamera:
     """Camera whose tensors are fixed device buffers; `load(cam)` copies another camera of the same intrinsics in."""
 
-    def __init__(self, cam):
+    def __init__(self, cam, storage=None):
+        """storage: an existing float32[35] device view to live in (the tail of a packed frame), else its own block."""
         self.image_height, self.image_width, self.FoVx, self.FoVy = cam.image_height, cam.image_width, cam.FoVx, cam.FoVy
-        self.packed = torch.cat([cam.world_view_transform.reshape(-1), cam.full_proj_transform.reshape(-1), cam.camera_center.reshape(-1)])
+        packed = pack_camera(cam)
+        if storage is None:
+            self.packed = packed
+        else:
+            self.packed = storage
+            self.packed.copy_(packed)
         self.world_view_transform = self.packed[0:16].view(4, 4)
         self.full_proj_transform = self.packed[16:32].view(4, 4)
         self.camera_center = self.packed[32:35]
@@ -68,7 +85,14 @@ class GraphedTrainStep:
         """Runs `warmup` eager iterations on (cam, gt) -- they are real training steps -- then records (without executing) one
         more into the graph."""
         dev = gt.device
-        self.cam, self.gt = _StaticCamera(cam), gt.clone()
+        if isinstance(cam, _StaticCamera):                           # recapture: keep the static buffers
+            if gt is not self.gt:
+                self.gt.copy_(gt)
+        else:
+            self._frame = torch.empty(gt.numel() + 35, device=dev, dtype=torch.float32)      # image, then camera: one copy target
+            self.gt = self._frame[:gt.numel()].view(gt.shape)
+            self.gt.copy_(gt)
+            self.cam = _StaticCamera(cam, storage=self._frame[gt.numel():])
         self._one = torch.ones((), device=dev)
         P = self.pc.get_xyz.shape[0]
         side = torch.cuda.Stream(device=dev)
@@ -107,10 +131,14 @@ class GraphedTrainStep:
         self.graph = None                                            # drop the old graph and its private memory pool first
         return self.capture(cam, gt, warmup=warmup, capacity_margin=capacity_margin)
 
-    def __call__(self, cam, gt):
-        """One training iteration: copy inputs in, replay.  Returns the (device, static) loss tensor."""
-        self.cam.load(cam)
-        self.gt.copy_(gt, non_blocking=True)
+    def __call__(self, cam, gt=None):
+        """One training iteration: copy inputs in, replay.  Returns the (device, static) loss tensor.
+        Either (camera, ground-truth image) or one packed frame from pack_frame() (a single copy)."""
+        if gt is None:
+            self._frame.copy_(cam, non_blocking=True)
+        else:
+            self.cam.load(cam)
+            self.gt.copy_(gt, non_blocking=True)
         self.graph.replay()
         return self.loss
 
