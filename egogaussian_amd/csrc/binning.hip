@@ -262,12 +262,9 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, int gpb,
 // Stable ranking as in a global radix pass, but the whole bucket belongs to one workgroup: wave w owns the contiguous
 // quarter [w*chunk, (w+1)*chunk) in rounds of 64.
 // ---------------------------------------------------------------------------------------------
-#ifndef TS_WAVES
-#define TS_WAVES 8                    // waves per workgroup (one tile each)
-#endif
-#define TS_THREADS (64 * TS_WAVES)
-#define TS_CAP 4096                   // pairs held in registers, one 32 KiB LDS exchange buffer
-#define TS_ITEMS (TS_CAP / TS_THREADS)
+// Two instantiations share the launch sequence: <4 waves, 2048 pairs> (20 KiB of LDS: eight workgroups per CU, so a 960x540
+// frame's 2040 tiles are all resident at once) sorts every tile of up to 2048 instances; <8 waves, 4096 pairs> takes the
+// larger ones and, beyond 4096, the global-memory path.  Each workgroup returns at once if its tile belongs to the other.
 #define TS_DBITS 9
 #define TS_DIGITS (1 << TS_DBITS)
 
@@ -304,6 +301,7 @@ __device__ __forceinline__ uint32_t scan_first_256(uint32_t v, uint32_t* lds4) {
 // Register path: a wave's share holds at most 1024 pairs, so two digit counters share one LDS word (16 bits each).
 // After every wave has accumulated its counts: turn them into exclusive positions
 //   pos[w][d] = (#keys with digit < d) + (#keys with digit d in waves < w).       thread t < 256 owns digits 2t, 2t+1.
+template <int TS_WAVES>
 __device__ __forceinline__ void digit_bases_packed(uint32_t (*cnt)[256], uint32_t* lds4) {
     const unsigned t = threadIdx.x;
     uint32_t c[TS_WAVES], s = 0;
@@ -322,6 +320,7 @@ __device__ __forceinline__ void digit_bases_packed(uint32_t (*cnt)[256], uint32_
 }
 
 // Oversize path: full-width counters, thread t < 256 owns digits 2t and 2t+1.
+template <int TS_WAVES>
 __device__ __forceinline__ void digit_bases_wide(uint32_t (*cnt)[TS_DIGITS], uint32_t* lds4) {
     const unsigned t = threadIdx.x;
     uint32_t a[TS_WAVES], b[TS_WAVES], sa = 0, sb = 0;
@@ -375,6 +374,7 @@ __global__ void k_check_lds_atomic_order(uint32_t* __restrict__ violations) {
 }
 
 // min and max over the workgroup of one value per thread (both returned to every thread)
+template <int TS_WAVES>
 __device__ __forceinline__ void block_min_max(uint32_t& mn, uint32_t& mx, uint32_t* lds2w) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -389,23 +389,27 @@ __device__ __forceinline__ void block_min_max(uint32_t& mn, uint32_t& mx, uint32
     __syncthreads();
 }
 
-template <bool RANK_ATOMIC>
-__global__ __launch_bounds__(TS_THREADS) void k_tile_sort(int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
+template <bool RANK_ATOMIC, int TS_WAVES, int TS_CAP, uint32_t N_MIN>
+__global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
                                                     const uint64_t* __restrict__ total, uint64_t* __restrict__ running_max,
                                                     uint32_t R /* capacity */,
                                                     int index_passes, uint64_t* __restrict__ pairs,
                                                     uint64_t* __restrict__ scratch, uint32_t* __restrict__ point_list,
                                                     uint2* __restrict__ ranges) {
+    constexpr int TS_THREADS = 64 * TS_WAVES, TS_ITEMS = TS_CAP / TS_THREADS;
+    static_assert(TS_CAP * 2 >= TS_WAVES * TS_DIGITS, "the oversize path keeps its counters in the exchange buffer");
     __shared__ uint64_t xbuf[TS_CAP];
     __shared__ uint32_t cnt[TS_WAVES][256];
     __shared__ uint32_t lds8[2 * TS_WAVES];
     const int tile = blockIdx.x;
-    if (running_max && tile == 0 && threadIdx.x == 0 && *total > *running_max) *running_max = *total;   // for hipGraph replays (api.hip)
     const uint32_t beg = table_scanned[(size_t)tile * nblocks];
     const uint32_t end = tile + 1 < n_tiles ? table_scanned[(size_t)(tile + 1) * nblocks] : (uint32_t)*total;
     const uint32_t n = end > R ? 0u : end - beg;                     // end > capacity: speculative launch that overflowed
-    if (threadIdx.x == 0) ranges[tile] = n ? make_uint2(beg, end) : make_uint2(0u, 0u);
-    if (n == 0) return;
+    if (N_MIN == 0) {                                                // the first of the two launches also publishes the bookkeeping
+        if (running_max && tile == 0 && threadIdx.x == 0 && *total > *running_max) *running_max = *total;   // for hipGraph replays (api.hip)
+        if (threadIdx.x == 0) ranges[tile] = n ? make_uint2(beg, end) : make_uint2(0u, 0u);
+    }
+    if (n == 0 || (N_MIN == 0 ? n > (uint32_t)TS_CAP : n < N_MIN)) return;      // empty, or the other instantiation's tile
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
     const uint32_t chunk = ((n + TS_WAVES - 1) / TS_WAVES + 63) & ~63u;       // per-wave share, multiple of 64
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_tile_sort(int n_tiles, uint32_t 
             key[r] = ok ? pairs[beg + i] : ~0ull;
             if (ok) { const uint32_t dw = (uint32_t)(key[r] >> 32); dmin = min(dmin, dw); dmax = max(dmax, dw); }
         }
-        block_min_max(dmin, dmax, lds8);
+        block_min_max<TS_WAVES>(dmin, dmax, lds8);
         const int depth_passes = (32 - __clz((int)(dmax - dmin)) + TS_DBITS - 1) / TS_DBITS;     // 0 when every depth is equal
         const int npass = index_passes + depth_passes;
         // Barriers per pass: 4.  Every wave clears ITS OWN counters (nobody else touches them between the barrier after the
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_tile_sort(int n_tiles, uint32_t 
                     }
                 }
                 __syncthreads();
-                digit_bases_packed(cnt, lds8);
+                digit_bases_packed<TS_WAVES>(cnt, lds8);
 #pragma unroll
                 for (int r = 0; r < TS_ITEMS; r++) {
                     const uint32_t i = wbeg + r * 64 + lane;
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_tile_sort(int n_tiles, uint32_t 
     uint64_t* dst = scratch + beg;
     uint32_t dmin = 0xffffffffu, dmax = 0u;
     for (uint32_t i = threadIdx.x; i < n; i += TS_THREADS) { const uint32_t dw = (uint32_t)(src[i] >> 32); dmin = min(dmin, dw); dmax = max(dmax, dw); }
-    block_min_max(dmin, dmax, lds8);
+    block_min_max<TS_WAVES>(dmin, dmax, lds8);
     const int depth_passes = (32 - __clz((int)(dmax - dmin)) + TS_DBITS - 1) / TS_DBITS;
     const int npass = index_passes + depth_passes;
     for (int p = 0; p < npass; p++) {
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_tile_sort(int n_tiles, uint32_t 
             if (i < n) atomicAdd(&wide[w][ts_digit(src[i], p, index_passes, dmin)], 1u);     // counting only: order irrelevant
         }
         __syncthreads();
-        digit_bases_wide(wide, lds8);
+        digit_bases_wide<TS_WAVES>(wide, lds8);
         const bool last = p == npass - 1;
         for (uint32_t r0 = 0; r0 < chunk; r0 += 64) {                  // rank and move (wide[w][d] is the running cursor)
             const uint32_t i = wbeg + r0 + lane;
@@ -603,12 +607,18 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     }
     if (egs_force_ballot_rank) fast = 0;
     egs_prof_start(EGS_K_SORT, s);
-    if (fast)
-        hipLaunchKernelGGL(k_tile_sort<true>, dim3(n_tiles), dim3(TS_THREADS), 0, s, n_tiles, nblocks, b.table, b.total, running_max, R,
-                           (index_bits + TS_DBITS - 1) / TS_DBITS, b.pairs, b.scratch, b.point_list, im.ranges);
-    else
-        hipLaunchKernelGGL(k_tile_sort<false>, dim3(n_tiles), dim3(TS_THREADS), 0, s, n_tiles, nblocks, b.table, b.total, running_max, R,
-                           (index_bits + TS_DBITS - 1) / TS_DBITS, b.pairs, b.scratch, b.point_list, im.ranges);
+    const int ip = (index_bits + TS_DBITS - 1) / TS_DBITS;
+    if (fast) {
+        hipLaunchKernelGGL((k_tile_sort<true, 4, 2048, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, b.total, running_max, R,
+                           ip, b.pairs, b.scratch, b.point_list, im.ranges);
+        hipLaunchKernelGGL((k_tile_sort<true, 8, 4096, 2049u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, nblocks, b.table, b.total, running_max, R,
+                           ip, b.pairs, b.scratch, b.point_list, im.ranges);
+    } else {
+        hipLaunchKernelGGL((k_tile_sort<false, 4, 2048, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, b.total, running_max, R,
+                           ip, b.pairs, b.scratch, b.point_list, im.ranges);
+        hipLaunchKernelGGL((k_tile_sort<false, 8, 4096, 2049u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, nblocks, b.table, b.total, running_max, R,
+                           ip, b.pairs, b.scratch, b.point_list, im.ranges);
+    }
     egs_prof_stop(EGS_K_SORT, s);
     EGS_DBG(s);
     return hipGetLastError();
