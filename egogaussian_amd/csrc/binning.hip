@@ -138,10 +138,18 @@ __global__ __launch_bounds__(EGS_SCAN_THREADS) void k_scan_apply_sum(const uint3
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tile bucketing.  A workgroup (16 waves) owns `gpb` consecutive Gaussians (egs_bin_gpb), gpb / 16 per wave.  For
-// each group of 64 Gaussians the wave deals their instance slots to lanes: slot s of the group's contiguous span is
-// mapped back to its Gaussian by a 6-step search over the per-lane exclusive offsets, so lanes do equal work however
-// uneven the rectangles are.  `body(tile, gaussian_index, depth_bits)` runs once per instance.
+// Tile bucketing.  The Gaussians are cut into groups of 64 consecutive ones; group j belongs to workgroup j % nblocks, so a
+// run of heavy groups (the clones and splits densification appends at the end of the arrays are all on screen and close to
+// the camera that asked for them) is spread over all workgroups instead of landing in the last few.  A workgroup (16 waves)
+// takes `gpr` of its groups per round:
+//   set-up  wave w < gpr owns group w: loads the rectangles' tile counts, scans them into per-Gaussian span starts and parks
+//           those, the rectangles, the depth words and (when culling) the ellipse parameters in LDS;
+//   deal    the round's instance slots are cut into units of 64 consecutive slots of ONE group and unit u goes to wave
+//           u % 16, whichever wave set the group up -- the waves of a workgroup finish within one unit of each other however
+//           uneven the rectangles are.  Inside a unit slot s is mapped back to its Gaussian by a 6-step shuffle search over
+//           the group's span starts.
+// `body(tile, gaussian_index, depth_bits)` runs once per instance.  The order in which a workgroup's instances reach a
+// tile's bucket is not defined (its waves share the LDS cursors); the per-tile sort orders by (depth, index), which is unique.
 // ---------------------------------------------------------------------------------------------
 // Workgroup b runs on XCD b % 8 (observed, used for speed only).  The bucketed array interleaves, inside every tile's
 // region, the slices of consecutive table columns; giving each XCD a contiguous run of columns lets its private L2
@@ -157,36 +165,53 @@ __device__ __forceinline__ unsigned bin_logical_block(unsigned nblocks) {
 // splat can reach with alpha >= 1/255 (corners of elongated splats, faint splats).  Such an instance can never
 // contribute -- the reference skips it at every pixel -- so dropping it here changes no output bit; it only shortens the
 // sort and the lists the blend kernels scan (config C: 2.94M -> 1.87M instances).  The test is the exact, conservative
-// ellipse-vs-block test the blend kernels apply per 8x8 quadrant (blend_common.h), on the whole 16x16 tile; the wave
-// parks its 64 splats' ellipse parameters in a private LDS slice and each slot-lane reads its own.
+// ellipse-vs-block test the blend kernels apply per 8x8 quadrant (blend_common.h), on the whole 16x16 tile; each slot-lane
+// reads its Gaussian's prepared ellipse parameters from the LDS block the set-up wave wrote.
+#define EGS_BIN_WAVES (EGS_BIN_THREADS / 64)
+// LDS behind the per-tile counters, for a round of `gpr` groups (words): span starts, rectangles, depth words, 16 unit counts +
+// 16 group totals, then (culling only, 16-byte aligned) two float4 per Gaussian.
+__host__ __device__ inline size_t bin_round_words(int gpr, bool cull) { return (size_t)gpr * 64 * 4 + 32 + (cull ? (size_t)gpr * 64 * 8 : 0); }
+
 template <typename Body>
-__device__ __forceinline__ void for_each_instance(unsigned bid, int gpb, int P, const uint32_t* __restrict__ tiles_touched,
+__device__ __forceinline__ void for_each_instance(unsigned bid, unsigned nblocks, int gpr, int P, const uint32_t* __restrict__ tiles_touched,
                                                   const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
-                                                  bool need_depth, bool cull, int W, int H, float4* __restrict__ stage, Body body) {
+                                                  bool need_depth, bool cull, int W, int H, uint32_t* __restrict__ round_lds, Body body) {
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    stage += w * 128;                                                  // 64 x 2 float4 per wave
-    const int per_wave = gpb / (EGS_BIN_THREADS / 64);
-    const int first = (int)bid * gpb + (int)w * per_wave;
-    for (int g0 = first; g0 < first + per_wave && g0 < P; g0 += 64) {
-        const int i = g0 + (int)lane;
-        const bool have = i < P;
-        const uint32_t cnt = have ? tiles_touched[i] : 0u;
-        const uint32_t incl = wave_incl_scan(cnt);
-        const uint32_t total = __shfl(incl, 63, 64);
-        if (total == 0) continue;
-        const uint32_t excl = have ? incl - cnt : 0xffffffffu;       // span start; invalid lanes sort to the end
-        uint2 rc = make_uint2(0u, 0u); uint32_t dbits = 0;
-        if (cnt) { rc = rect[i]; if (need_depth) dbits = __float_as_uint(rec[(size_t)i * EGS_SPLAT_REC_F4 + 2].y); }
-        if (cull) {
-            __builtin_amdgcn_wave_barrier();                            // earlier readers of the slice are done
+    uint32_t* span = round_lds;                                        // [gpr * 64] exclusive slot offset inside the group
+    uint2* rcs = reinterpret_cast<uint2*>(span + gpr * 64);            // [gpr * 64]
+    uint32_t* dbs = span + gpr * 64 * 3;                               // [gpr * 64]
+    uint32_t* units = dbs + gpr * 64;                                  // [16] 64-slot units per group, [16] slots per group
+    float4* stage = reinterpret_cast<float4*>(units + 32);             // [gpr * 64][2]
+    const unsigned groups = ((unsigned)P + 63u) / 64u;
+    const unsigned per_block = (groups + nblocks - 1) / nblocks;       // groups of the busiest workgroup
+    for (unsigned g0 = 0; g0 < per_block; g0 += (unsigned)gpr) {
+        if (g0) __syncthreads();                                       // the previous round's readers are done
+        if ((int)w < gpr) {
+            const unsigned j = bid + nblocks * (g0 + w);
+            const int i = (int)(j * 64u + lane);
+            const bool have = g0 + w < per_block && j < groups && i < P;
+            const uint32_t cnt = have ? tiles_touched[i] : 0u;
+            const uint32_t incl = wave_incl_scan(cnt);
+            span[w * 64 + lane] = have ? incl - cnt : 0xffffffffu;   // invalid lanes sort to the end
             if (cnt) {
-                const float4 r0 = rec[(size_t)i * EGS_SPLAT_REC_F4], r1 = rec[(size_t)i * EGS_SPLAT_REC_F4 + 1];
-                stage[2 * lane] = r0; stage[2 * lane + 1] = egs_ellipse_prep(r0.z, r0.w, r1.x, r1.y);
+                rcs[w * 64 + lane] = rect[i];
+                if (need_depth) dbs[w * 64 + lane] = __float_as_uint(rec[(size_t)i * EGS_SPLAT_REC_F4 + 2].y);
+                if (cull) {
+                    const float4 r0 = rec[(size_t)i * EGS_SPLAT_REC_F4], r1 = rec[(size_t)i * EGS_SPLAT_REC_F4 + 1];
+                    stage[2 * (w * 64 + lane)] = r0; stage[2 * (w * 64 + lane) + 1] = egs_ellipse_prep(r0.z, r0.w, r1.x, r1.y);
+                }
             }
-            __builtin_amdgcn_wave_barrier();
+            if (lane == 63) { units[w] = (incl + 63u) >> 6; units[16 + w] = incl; }
         }
-        for (uint32_t s0 = 0; s0 < total; s0 += 64) {
-            const uint32_t s = s0 + lane;
+        __syncthreads();
+        const uint32_t un = (int)lane < gpr ? units[lane] : 0u, tot = (int)lane < gpr ? units[16 + lane] : 0u;
+        const uint32_t uincl = wave_incl_scan(un);
+        const uint32_t n_units = __shfl(uincl, 63, 64);
+        for (uint32_t u = w; u < n_units; u += EGS_BIN_WAVES) {
+            const int k = __popcll(__ballot(uincl <= u && (int)lane < gpr));       // the group unit u falls in (uniform)
+            const uint32_t s = ((u - (__shfl(uincl, k, 64) - __shfl(un, k, 64))) << 6) + lane;
+            const uint32_t total = __shfl(tot, k, 64);
+            const uint32_t excl = span[k * 64 + lane];
             int lo = 0;                                              // last lane whose span starts at or before s
 #pragma unroll
             for (int step = 32; step >= 1; step >>= 1) {
@@ -194,25 +219,24 @@ __device__ __forceinline__ void for_each_instance(unsigned bid, int gpb, int P, 
                 const uint32_t st = __shfl(excl, probe & 63, 64);
                 if (probe < 64 && st <= s) lo = probe;
             }
-            const uint32_t ost = __shfl(excl, lo, 64);
-            const uint2 orc = make_uint2(__shfl(rc.x, lo, 64), __shfl(rc.y, lo, 64));
-            const uint32_t odb = __shfl(dbits, lo, 64);
+            const uint32_t ost = __shfl(excl, lo, 64);               // (all lanes take part: outside the branch)
             if (s < total) {
-                const uint32_t k = s - ost;
+                const uint32_t kk = s - ost;
+                const uint2 orc = rcs[k * 64 + lo];
                 const uint32_t x0 = orc.x & 0xffffu, x1 = orc.x >> 16, y0 = orc.y & 0xffffu;
                 const uint32_t wd = x1 - x0;
-                uint32_t row = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)wd));      // k < 2^24: off by at most one
-                uint32_t col = k - row * wd;
+                uint32_t row = (uint32_t)((float)kk * __builtin_amdgcn_rcpf((float)wd));      // k < 2^24: off by at most one
+                uint32_t col = kk - row * wd;
                 if ((int)col < 0) { row--; col += wd; }
                 if (col >= wd) { row++; col -= wd; }
                 const uint32_t ty = y0 + row, tx = x0 + col;
                 bool keep = true;
                 if (cull) {
-                    const float4 e0 = stage[2 * lo], e1 = stage[2 * lo + 1];             // (x, y, qa, qb), (qc, need, sy, sx)
+                    const float4 e0 = stage[2 * (k * 64 + lo)], e1 = stage[2 * (k * 64 + lo) + 1];   // (x, y, qa, qb), (qc, need, sy, sx)
                     keep = egs_ellipse_hits_prepped(e0, e1, tx * EGS_TILE, min(tx * EGS_TILE + EGS_TILE - 1, (uint32_t)W - 1),
                                                     ty * EGS_TILE, min(ty * EGS_TILE + EGS_TILE - 1, (uint32_t)H - 1));
                 }
-                if (keep) body(ty * (uint32_t)gx + tx, (uint32_t)(g0 + lo), odb);
+                if (keep) body(ty * (uint32_t)gx + tx, (bid + nblocks * (g0 + (unsigned)k)) * 64u + (unsigned)lo, need_depth ? dbs[k * 64 + lo] : 0u);
             }
         }
     }
@@ -220,23 +244,22 @@ __device__ __forceinline__ void for_each_instance(unsigned bid, int gpb, int P, 
 
 extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
 
-__global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, int gpb, const uint32_t* __restrict__ tiles_touched,
+__global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, int gpr, const uint32_t* __restrict__ tiles_touched,
                                                     const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
                                                     int n_tiles, uint32_t nblocks, int cull, int W, int H,
                                                     uint32_t* __restrict__ table) {
     const unsigned bid = bin_logical_block(nblocks);
     if (bid >= nblocks) return;
     uint32_t* hist = dyn_lds;
-    float4* stage = reinterpret_cast<float4*>(dyn_lds + ((n_tiles + 3) & ~3));
-    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) hist[t] = 0;
-    __syncthreads();
-    for_each_instance(bid, gpb, P, tiles_touched, rect, rec, gx, false, cull != 0, W, H, stage,
+    uint32_t* round_lds = dyn_lds + ((n_tiles + 3) & ~3);
+    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) hist[t] = 0;            // (the first round's barrier orders this)
+    for_each_instance(bid, nblocks, gpr, P, tiles_touched, rect, rec, gx, false, cull != 0, W, H, round_lds,
                       [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); });
     __syncthreads();
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) table[(size_t)t * nblocks + bid] = hist[t];   // tile-major
 }
 
-__global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, int gpb, const uint32_t* __restrict__ tiles_touched,
+__global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, int gpr, const uint32_t* __restrict__ tiles_touched,
                                                       const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
                                                       int n_tiles, uint32_t nblocks, int cull, int W, int H,
                                                       const uint32_t* __restrict__ table_scanned,
@@ -244,10 +267,9 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, int gpb,
     const unsigned bid = bin_logical_block(nblocks);
     if (bid >= nblocks) return;
     uint32_t* cursor = dyn_lds;
-    float4* stage = reinterpret_cast<float4*>(dyn_lds + ((n_tiles + 3) & ~3));
+    uint32_t* round_lds = dyn_lds + ((n_tiles + 3) & ~3);
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) cursor[t] = table_scanned[(size_t)t * nblocks + bid];
-    __syncthreads();
-    for_each_instance(bid, gpb, P, tiles_touched, rect, rec, gx, true, cull != 0, W, H, stage, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
+    for_each_instance(bid, nblocks, gpr, P, tiles_touched, rect, rec, gx, true, cull != 0, W, H, round_lds, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
         const uint32_t pos = atomicAdd(&cursor[tile], 1u);
         if (pos < cap) pairs[pos] = ((uint64_t)dbits << 32) | idx;      // cap < R only in a speculative launch that will be redone
     });
@@ -570,9 +592,17 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     const uint32_t R = (uint32_t)R64;
     const uint32_t nblocks = egs_bin_blocks(P);
     int cull = egs_tile_culling;
-    // per-tile counters, then (16-byte aligned) one 2 KiB ellipse-parameter slice per wave
-    size_t lds = (size_t)((n_tiles + 3) & ~3) * sizeof(uint32_t) + (size_t)(EGS_BIN_THREADS / 64) * 128 * sizeof(float4);
-    if (lds > 160 * 1024) { cull = 0; lds = (size_t)n_tiles * sizeof(uint32_t); }     // > 30k tiles: counters alone fill the LDS
+    // per-tile counters, then (16-byte aligned) the round's set-up block; fewer groups per round, then no culling, when
+    // the counters leave too little of the 160 KiB (beyond ~28k tiles)
+    const size_t counters = (size_t)((n_tiles + 3) & ~3) * sizeof(uint32_t), room = 160 * 1024 - counters;
+    auto fits = [&](int groups, bool with_cull) { return bin_round_words(groups, with_cull) * sizeof(uint32_t) <= room; };
+    int gpr = EGS_BIN_WAVES;
+    if (cull) {
+        while (gpr > 4 && !fits(gpr, true)) gpr >>= 1;
+        if (!fits(gpr, true)) { cull = 0; gpr = EGS_BIN_WAVES; }
+    }
+    if (!cull) while (gpr > 1 && !fits(gpr, false)) gpr >>= 1;
+    const size_t lds = counters + bin_round_words(gpr, cull != 0) * sizeof(uint32_t);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -580,11 +610,11 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
         if (e != hipSuccess) return e;
     }
     egs_prof_start(EGS_K_DUPLICATE, s);
-    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, egs_bin_gpb(P), g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, W, H, b.table);
+    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, W, H, b.table);
     EGS_DBG(s);
     hipError_t e = egs_launch_scan_u32(b.table, b.table, (size_t)n_tiles * nblocks, 0, b.spine, b.total, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bin_scatter, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, egs_bin_gpb(P), g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
+    hipLaunchKernelGGL(k_bin_scatter, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
                        cull, W, H, b.table, R, b.pairs);
     egs_prof_stop(EGS_K_DUPLICATE, s);
     EGS_DBG(s);
