@@ -36,16 +36,16 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s 
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
-def algorithmic_bytes(stage, N, R, npix):
+def algorithmic_bytes(stage, N, R, npix, sh_coeffs=1):
     """Bytes one launch of `stage` must move at minimum: per-unit figures x units.  R = instances the
     launch actually processes (after tile culling)."""
     return {
-        "preprocess": 56 * N + 48 * N,                 # xyz 12 + log-scale 12 + quaternion 16 + opacity logit 4 + sh 12 in; record 48 out
+        "preprocess": (44 + 12 * sh_coeffs) * N + 48 * N,   # xyz 12 + log-scale 12 + quaternion 16 + opacity logit 4 + sh 12/coefficient in; record 48 out
         "tile_bucket": 2 * (16 + 32) * N + 8 * R,      # two walks over (tiles_touched, rect, depth | ellipse) per Gaussian; one pair out per instance
         "tile_sort": 8 * R + 4 * R,                    # pair in, index out; the radix passes stay in registers/LDS
         "render_forward": 4 * R + 48 * R + 28 * npix,  # id + record per instance; 7 floats per pixel out
         "render_backward": 4 * R + 48 * R + 40 * R + 32 * npix,   # + one 40-byte accumulate per instance; 8 floats/pixel in
-        "preprocess_backward": 48 * N + 56 * N + 32 * N + 80 * N,  # accumulator + inputs + record head in; grads out (xyz, mean2D, scale, quat, sh, colour, opacity)
+        "preprocess_backward": 48 * N + (44 + 12 * sh_coeffs) * N + 32 * N + (68 + 12 * sh_coeffs) * N,  # accumulator + inputs + record head in; grads out (xyz, mean2D, scale, quat, sh, colour, opacity)
     }[stage]
 
 
@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--gaussians", type=int, default=500_000)
     ap.add_argument("--height", type=int, default=540)
     ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--sh-degree", type=int, default=0, help="spherical-harmonics degree of the colours (0..3; the reference ends training at 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op-only", action="store_true", help="time rasterizer fwd+bwd only (seeded upstream grads)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every step from Python instead of replaying a captured hipGraph")
@@ -82,7 +83,8 @@ def main():
     egs_lib.load()
 
     N, H, W = args.gaussians, args.height, args.width
-    teacher = make_scene(N, H, W, seed=0)
+    D = args.sh_degree
+    teacher = make_scene(N, H, W, seed=0, sh_degree=D)
     student = perturb_student(teacher)
     bg = torch.zeros(3, device=dev)
     my_frames = egs_dist.shard_frames(N_FRAMES, rank, world)
@@ -90,16 +92,17 @@ def main():
     cams = [make_camera(k, H, W, device=dev) for k in my_frames[:n_used]]
 
     with torch.no_grad():                                      # ground truth = teacher rendered by the same path
-        tpc = SynthGaussians(teacher, device=dev, requires_grad=False)
+        tpc = SynthGaussians(teacher, device=dev, sh_degree=D, requires_grad=False)
         gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
         del tpc
-    pc = SynthGaussians(student, device=dev, fused=not args.torch_host_ops)
+    pc = SynthGaussians(student, device=dev, sh_degree=D, fused=not args.torch_host_ops)
     from egogaussian_amd.optim import FusedAdam
     use_graph = not (args.no_graph or args.torch_host_ops or args.op_only)
     Adam = (lambda g, **kw: torch.optim.Adam(g, fused=True, **kw)) if args.torch_host_ops else \
         (lambda g, **kw: FusedAdam(g, capturable=use_graph, **kw))
     opt = Adam([                                                # /root/reference/scene/gaussian_model.py:180-198 defaults
         {"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3},
+        *([{"params": [pc._features_rest], "lr": 2.5e-3 / 20.0}] if D > 0 else []),
         {"params": [pc._opacity], "lr": 0.05}, {"params": [pc._scaling], "lr": 5e-3},
         {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15)
 
@@ -203,7 +206,7 @@ def main():
         if n == 0:
             continue
         per = ms / n
-        ab = algorithmic_bytes(name, N, R_kept, npix)
+        ab = algorithmic_bytes(name, N, R_kept, npix, (D + 1) ** 2)
         stage_rows[name] = {"ms_per_launch": round(per, 4), "launches": n, "alg_MB": round(ab / 1e6, 2),
                             "alg_GBps": round(ab / (per * 1e-3) / 1e9, 1), "frac_hbm": round(ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if dominant is None or per * n > stages[dominant][0]:
@@ -264,7 +267,7 @@ def main():
                                + ("rasterizer fwd+bwd only (seeded upstream grads on colour/depth/alpha)" if args.op_only else
                                   ("cov3D(torch) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) (torch) + bwd + Adam" if args.torch_host_ops else
                                    "render fwd (HIP; activations and cov3D inside its preprocess kernel) + 0.8 L1 + 0.2 (1-SSIM) (HIP) + bwd (HIP+autograd) + Adam (HIP)")),
-                   "gaussians": N, "image": [H, W], "sh_degree": 0, "instances_R": int(R_mean), "instances_after_tile_culling": int(R_kept),
+                   "gaussians": N, "image": [H, W], "sh_degree": D, "instances_R": int(R_mean), "instances_after_tile_culling": int(R_kept),
                    "sort_passes_max": passes,
                    "parallelism": f"frames sharded over {world} GPU(s), scalar all-reduce only",
                    "launch": "one hipGraph replay per step" if use_graph else "eager (one launch per kernel)"},

@@ -90,8 +90,10 @@ ACT_RAW_PARAMETERS = ACT_LOG_SCALES | ACT_RAW_QUATS | ACT_LOGIT_OPACITY
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, activation_flags=0):
-    """-> (num_rendered, color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer)"""
+                        prefiltered, debug, activation_flags=0, sh_rest=None):
+    """-> (num_rendered, color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer)
+    sh_rest (extension): `sh` is then the DC block [P,1,3] and `sh_rest` the other coefficients [P,M-1,3] -- the two parameters the
+    reference's GaussianModel stores, without the torch.cat of get_features (include/egs_raster.h: split spherical harmonics)."""
     L = _lib.load()
     means3D = _f32c(means3D, "means3D")
     if means3D.dim() != 2 or means3D.shape[1] != 3:
@@ -102,7 +104,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
     colors, scales, rotations = _opt(_f32c(colors, "colors")), _opt(_f32c(scales, "scales")), _opt(_f32c(rotations, "rotations"))
     cov3D_precomp, sh = _opt(_f32c(cov3D_precomp, "cov3D_precomp")), _opt(_f32c(sh, "sh"))
+    sh_rest = _opt(_f32c(sh_rest, "sh_rest"))
     M = 0 if sh is None else sh.shape[1]
+    if sh_rest is not None:
+        if sh is None or sh.shape[1] != 1 or sh_rest.shape[0] != P:
+            raise RuntimeError("sh_rest goes with sh = the DC block [P, 1, 3]")
+        M = 1 + sh_rest.shape[1]
     with torch.cuda.device(dev):
         opts = dict(device=dev, dtype=torch.float32)
         out_color = torch.empty((3, H, W), **opts)
@@ -129,14 +136,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             if cap <= 0 or P == 0:
                 raise RuntimeError("rasterize_gaussians under graph capture needs a capacity from an earlier eager call")
             _lib.check(L.egs_forward_enqueue(
-                P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier),
+                P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), _ptr(background), W, H,
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
                 _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), None, _ptr(_running_max.get(key)), _stream()))
             R = C.c_int64(cap)                      # layout size; the true count is stats["total_view"] after a sync
             rc = 0
         else:
-            rc = L.egs_forward(P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
+            rc = L.egs_forward(P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors), _ptr(opacity), _ptr(scales),
                                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
                                _ptr(campos), _ptr(background), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                                _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img), _ptr(out_color), _ptr(out_depth),
@@ -169,9 +176,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alpha,
-                                 debug, activation_flags=0):
+                                 debug, activation_flags=0, sh_rest=None):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
-           dL_dscales[P,3], dL_drotations[P,4])"""
+           dL_dscales[P,3], dL_drotations[P,4]); with sh_rest, dL_dsh is [P,1,3] and a ninth element dL_dsh_rest[P,M-1,3] follows"""
     L = _lib.load()
     means3D = _f32c(means3D, "means3D")
     dev = means3D.device
@@ -184,24 +191,28 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     g_color = _f32c(dL_dout_color, "dL_dout_color")
     g_depth = _opt(_f32c(dL_dout_depth, "dL_dout_depth"))
     g_alpha = _opt(_f32c(dL_dout_alpha, "dL_dout_alpha"))
-    M = 0 if sh is None else sh.shape[1]
+    sh_rest = _opt(_f32c(sh_rest, "sh_rest"))
+    M = 0 if sh is None else sh.shape[1] + (0 if sh_rest is None else sh_rest.shape[1])
     with torch.cuda.device(dev):
         e = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
         own_cov = cov3D_precomp is None
         dmeans2D, dcolors, dopacity, dmeans3D = e(P, 3), e(P, 3), e(P, 1), e(P, 3)
         dcov3D = e(0, 6) if own_cov else e(P, 6)             # not produced when the library built the covariance itself
-        dsh = e(P, M, 3) if sh is not None else e(0, 0, 3)
+        dsh = e(*sh.shape) if sh is not None else e(0, 0, 3)
+        dsh_rest = e(*sh_rest.shape) if sh_rest is not None else None
         dscales = e(P, 3) if own_cov else e(0, 3)          # absent inputs get empty gradients (the autograd Function maps them to None)
         drots = e(P, 4) if own_cov else e(0, 4)
         if P != 0:
             scratch = torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
             _lib.check(L.egs_backward(
-                P, int(degree), M, int(R), _ptr(background), _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
+                P, int(degree), M, int(R), _ptr(background), _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors), _ptr(scales),
                 float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
                 _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
                 _ptr(imageBuffer), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(dmeans2D), _ptr(dcolors),
-                _ptr(dopacity), _ptr(dmeans3D), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dscales) if own_cov else None,
+                _ptr(dopacity), _ptr(dmeans3D), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
                 _ptr(drots) if own_cov else None, _ptr(scratch), _stream(), int(bool(debug))))
+    if sh_rest is not None:
+        return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots, dsh_rest
     return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots
 
 

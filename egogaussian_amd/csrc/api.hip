@@ -185,7 +185,7 @@ int egs_get_image_layout(int width, int height, egs_image_layout* out) {
     *out = img_layout(width, height).o; return 0;
 }
 
-int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs,
+int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* shs_rest,
                          const float* colors_precomp, const float* opacities, const float* scales,
                          float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
                          const float* viewmatrix, const float* projmatrix, const float* campos, int width, int height,
@@ -199,12 +199,15 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
     if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer) return EGS_ERR_ARG;
     rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp, activation_flags); if (rc) return rc;
     if (shs && (sh_degree < 0 || sh_degree > EGS_MAX_SH_DEGREE || sh_coeffs < (sh_degree + 1) * (sh_degree + 1))) return EGS_ERR_RANGE;
+    if (shs_rest && (!shs || sh_coeffs < 2)) return EGS_ERR_MODE;
     hipStream_t s = (hipStream_t)stream;
     EgsGeomPtrs g = geom_ptrs(geom_buffer, P);
     EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
     egs_prof_start(EGS_K_PREPROCESS, s);
-    EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+    const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);         // rows of 12 M bytes: the wave-tiled kernel (preprocess.hip)
+    EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
                                   rotations, activation_flags, cov3D_precomp, cam, radii, g, s));
+    if (sh_apart) EGS_TRY(egs_launch_sh_forward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     EGS_SYNC_IF_DEBUG(s);
     // R = sum of the per-block instance counts (a few KB device->host; the only host wait of the forward)
@@ -223,7 +226,7 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
 // the caller's capacity guess while the host waits only for the copy of the per-block instance counts.  The GPU never
 // idles on the host round trip.  If the guess was too small nothing valid was produced: the true R is returned and the
 // caller finishes with egs_forward_render on a buffer of the right size.
-static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* colors_precomp,
+static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp,
                 const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                 const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix, const float* campos,
                 const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
@@ -244,13 +247,16 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     if (!wait_for_count && capacity <= 0) return EGS_ERR_ARG;
     rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp, activation_flags); if (rc) return rc;
     if (shs && (sh_degree < 0 || sh_degree > EGS_MAX_SH_DEGREE || sh_coeffs < (sh_degree + 1) * (sh_degree + 1))) return EGS_ERR_RANGE;
+    if (shs_rest && (!shs || sh_coeffs < 2)) return EGS_ERR_MODE;
     static thread_local hipEvent_t ev = nullptr;
     if (wait_for_count && !ev) EGS_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     EgsGeomPtrs g = geom_ptrs(geom_buffer, P);
     EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
     egs_prof_start(EGS_K_PREPROCESS, s);
-    EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+    const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);         // rows of 12 M bytes: the wave-tiled kernel (preprocess.hip)
+    EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
                                   rotations, activation_flags, cov3D_precomp, cam, radii, g, s));
+    if (sh_apart) EGS_TRY(egs_launch_sh_forward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     const size_t nb = ((size_t)P + 255) / 256;
     if (pinned_host_counts) EGS_TRY(hipMemcpyAsync(pinned_host_counts, g.scan_scratch, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -274,14 +280,14 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     return 0;
 }
 
-int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* colors_precomp,
+int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp,
                 const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                 const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix, const float* campos,
                 const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                 int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                 float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, int64_t* num_rendered,
                 void* stream, int debug) {
-    return forward_impl(1, P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+    return forward_impl(1, P, sh_degree, sh_coeffs, means3D, shs, shs_rest, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
                         pinned_host_counts, nullptr, num_rendered, stream, debug);
@@ -291,7 +297,7 @@ int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const
 // `capacity` is detected afterwards, either from pinned_host_counts (optional copy of the per-workgroup rectangle counts;
 // egs_sum_counts after synchronising) or from `running_max` (optional device uint64 that the chain raises to the number
 // of instances it bucketed whenever that is larger -- one word a caller can read after any number of replays).
-int egs_forward_enqueue(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* colors_precomp,
+int egs_forward_enqueue(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp,
                         const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                         const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix, const float* campos,
                         const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
@@ -299,7 +305,7 @@ int egs_forward_enqueue(int P, int sh_degree, int sh_coeffs, const float* means3
                         float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
                         void* stream) {
     int64_t unused = 0;
-    return forward_impl(0, P, sh_degree, sh_coeffs, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+    return forward_impl(0, P, sh_degree, sh_coeffs, means3D, shs, shs_rest, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
                         pinned_host_counts, running_max, &unused, stream, 0);
@@ -334,12 +340,12 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
 }
 
 int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* background, const float* means3D,
-                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* shs, const float* shs_rest, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix,
                  const float* campos, int width, int height, float tan_fovx, float tan_fovy, const int32_t* radii,
                  const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
                  const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
-                 float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
                  float* dL_dscales, float* dL_drotations, void* scratch, void* stream, int debug) {
     int rc = check_dims(P, width, height); if (rc) return rc;
     if (P == 0) return 0;
@@ -350,6 +356,8 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
     if (R > 0 && !binning_buffer) return EGS_ERR_ARG;
     rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp, activation_flags); if (rc) return rc;
     if (shs && !dL_dsh) return EGS_ERR_ARG;
+    if (shs_rest && (!shs || sh_coeffs < 2)) return EGS_ERR_MODE;
+    if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr)) return EGS_ERR_ARG;
     if (!cov3D_precomp && (!dL_dscales || !dL_drotations)) return EGS_ERR_ARG;
     if (cov3D_precomp && !dL_dcov3D) return EGS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -369,10 +377,13 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
     }
     egs_prof_start(EGS_K_PREPROCESS_BWD, s);
     EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
-    EGS_TRY(egs_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, shs, scales, scale_modifier, rotations,
+    const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);
+    EGS_TRY(egs_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, scales, scale_modifier, rotations,
                                            cov3D_precomp, activation_flags, cam, radii, g, grad_acc, colors_precomp != nullptr, dL_dmeans2D,
-                                           dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
+                                           dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, sh_apart ? nullptr : dL_dsh, dL_dscales,
                                            dL_drotations, s));
+    if (sh_apart) EGS_TRY(egs_launch_sh_backward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, radii, g, dL_dcolors, dL_dsh,
+                                                 dL_dsh_rest, dL_dmeans3D, s));
     egs_prof_stop(EGS_K_PREPROCESS_BWD, s);
     EGS_SYNC_IF_DEBUG(s);
     return 0;

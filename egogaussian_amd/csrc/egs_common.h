@@ -77,6 +77,14 @@ hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* mean
                                           int colors_given, float* dmeans2D, float* dcolors, float* dopac,
                                           float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,
                                           hipStream_t s);
+// Spherical harmonics as separate launches (M > 1 coefficients, or DC / rest given as two arrays: sh_rest != NULL).  The
+// preprocess launchers are then called with shs = NULL: the forward leaves the record's colour open, the backward leaves
+// dL/dSH and the view-direction part of dL/dmean3D to egs_launch_sh_backward (which must run after it).
+hipError_t egs_launch_sh_forward(int P, int D, int M, const float* means3D, const float* sh_a, const float* sh_rest, EgsCamera cam,
+                                 EgsGeomPtrs g, hipStream_t s);
+hipError_t egs_launch_sh_backward(int P, int D, int M, const float* means3D, const float* sh_a, const float* sh_rest, EgsCamera cam,
+                                  const int32_t* radii, EgsGeomPtrs g, const float* dcolors, float* dsh_a, float* dsh_rest,
+                                  float* dmeans3D, hipStream_t s);
 hipError_t egs_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 
 // exclusive/inclusive u32 scan of n elements; scratch holds egs_scan_scratch_elems(n) u32; optionally

@@ -171,6 +171,8 @@ __device__ __forceinline__ uint32_t preprocess_one(
     float rgb[3]; uint32_t cl = 0;
     if (colors) {
         rgb[0] = colors[3 * i]; rgb[1] = colors[3 * i + 1]; rgb[2] = colors[3 * i + 2];
+    } else if (!shs) {
+        rgb[0] = rgb[1] = rgb[2] = 0.f;                            // k_sh_forward fills the colour (and the clamp flags) in afterwards
     } else {
         float dir[3] = { p[0] - campos[0], p[1] - campos[1], p[2] - campos[2] };
         const float inv = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
@@ -447,6 +449,198 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Spherical harmonics with more than one coefficient (or given as separate DC / rest arrays).  A Gaussian's row is 12 M
+// bytes; one lane walking its own row touches a different cache line per load, and the M * 3 gradient stores of the backward
+// are 4-byte writes 12 M bytes apart.  Here a wave owns 64 consecutive Gaussians and moves their rows as ONE contiguous block:
+// float4 loads / stores in lane order (full lines), transposed through an LDS tile of 64 x (3 M + 1) words whose odd row
+// stride makes the per-lane row accesses conflict-free.  Rows of invisible Gaussians and coefficients above the active degree
+// are not loaded; their gradient is written as zeros by the same coalesced stores.
+//   k_sh_forward   after k_preprocess: colour + clamp flags into the record it left open
+//   k_sh_backward  after k_preprocess_backward: reads dL/dcolour, writes dL/dSH, adds the view-direction term to dL/dmean3D
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sh_row_col(int e, int rw, float inv_rw, int& r, int& c) {
+    r = (int)(((float)e + 0.5f) * inv_rw);                             // e < 64 * 48: exact
+    c = e - r * rw;
+}
+
+// Rows [i0, i0 + nvalid) of a [P, rw] float array -> tile[row * ld + col0 + col]; elements of invisible rows or with col >= need are
+// left alone (never read).
+__device__ __forceinline__ void sh_load_rows(float* tile, int ld, int col0, const float* __restrict__ src, int rw, int i0, int nvalid,
+                                             uint64_t vmask, int need, unsigned lane) {
+    if (need <= 0) return;
+    const float inv_rw = 1.f / (float)rw;
+    const float* base = src + (size_t)i0 * rw;
+    const int n = nvalid * rw;
+    if ((((uintptr_t)base) & 15) == 0 && (n & 3) == 0) {
+        const float4* b4 = reinterpret_cast<const float4*>(base);
+        for (int q = lane; 4 * q < n; q += 64) {
+            int r0, c0, r3, c3;
+            sh_row_col(4 * q, rw, inv_rw, r0, c0); sh_row_col(4 * q + 3, rw, inv_rw, r3, c3);
+            const bool want = (((vmask >> r0) & 1) && c0 < need) || (r3 != r0 && ((vmask >> r3) & 1)) ||
+                              (r3 - r0 > 1 && ((vmask >> (r0 + 1)) & 1));
+            if (!want) continue;
+            const float4 v = b4[q];
+            const float vv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int r, c; sh_row_col(4 * q + j, rw, inv_rw, r, c);
+                tile[r * ld + col0 + c] = vv[j];
+            }
+        }
+    } else {
+        for (int e = lane; e < n; e += 64) {
+            int r, c; sh_row_col(e, rw, inv_rw, r, c);
+            if (((vmask >> r) & 1) && c < need) tile[r * ld + col0 + c] = base[e];
+        }
+    }
+}
+
+// tile[row * ld + col0 + col] -> rows [i0, i0 + nvalid) of a [P, rw] float array, every element.
+__device__ __forceinline__ void sh_store_rows(const float* tile, int ld, int col0, float* __restrict__ dst, int rw, int i0, int nvalid,
+                                              unsigned lane) {
+    const float inv_rw = 1.f / (float)rw;
+    float* base = dst + (size_t)i0 * rw;
+    const int n = nvalid * rw;
+    if ((((uintptr_t)base) & 15) == 0 && (n & 3) == 0) {
+        float4* b4 = reinterpret_cast<float4*>(base);
+        for (int q = lane; 4 * q < n; q += 64) {
+            float vv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int r, c; sh_row_col(4 * q + j, rw, inv_rw, r, c);
+                vv[j] = tile[r * ld + col0 + c];
+            }
+            b4[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        }
+    } else {
+        for (int e = lane; e < n; e += 64) {
+            int r, c; sh_row_col(e, rw, inv_rw, r, c);
+            base[e] = tile[r * ld + col0 + c];
+        }
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) float sh_tile[];
+
+// sh_rest == nullptr: sh_a is [P, M, 3]; otherwise sh_a is the DC block [P, 1, 3] and sh_rest [P, M - 1, 3].
+__global__ __launch_bounds__(64) void k_sh_forward(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ campos,
+                                                   const float* __restrict__ sh_a, const float* __restrict__ sh_rest,
+                                                   const uint8_t* __restrict__ visible, float4* __restrict__ rec, uint8_t* __restrict__ clamped) {
+    const unsigned lane = threadIdx.x;
+    const int i0 = blockIdx.x * 64, i = i0 + (int)lane;
+    const bool vis = i < P && visible[i] != 0;
+    const uint64_t vmask = __ballot(vis);
+    if (!vmask) return;
+    const int rw = 3 * M, ld = rw + 1, nvalid = min(64, P - i0), need = 3 * (D + 1) * (D + 1);
+    if (sh_rest) {
+        sh_load_rows(sh_tile, ld, 0, sh_a, 3, i0, nvalid, vmask, 3, lane);
+        sh_load_rows(sh_tile, ld, 3, sh_rest, rw - 3, i0, nvalid, vmask, need - 3, lane);
+    } else {
+        sh_load_rows(sh_tile, ld, 0, sh_a, rw, i0, nvalid, vmask, need, lane);
+    }
+    __syncthreads();                                                   // one wave: orders the LDS writes before the row reads
+    if (!vis) return;
+    const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
+    float dir[3] = { p[0] - campos[0], p[1] - campos[1], p[2] - campos[2] };
+    const float inv = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    dir[0] *= inv; dir[1] *= inv; dir[2] *= inv;
+    const float* sh = sh_tile + lane * ld;
+    float rgb[3]; uint32_t cl = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const float v = sh_channel(D, sh, ch, dir[0], dir[1], dir[2]);
+        if (v < 0.f) cl |= 1u << ch;
+        rgb[ch] = fmaxf(v, 0.f);
+    }
+    clamped[i] = (uint8_t)cl;
+    float* r = reinterpret_cast<float*>(rec + (size_t)i * EGS_SPLAT_REC_F4);
+    r[6] = rgb[0]; r[7] = rgb[1]; r[8] = rgb[2];
+}
+
+__global__ __launch_bounds__(64) void k_sh_backward(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ campos,
+                                                    const float* __restrict__ sh_a, const float* __restrict__ sh_rest,
+                                                    const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
+                                                    const float* __restrict__ dcolors, float* __restrict__ dsh_a, float* __restrict__ dsh_rest,
+                                                    float* __restrict__ dmeans3D) {
+    const unsigned lane = threadIdx.x;
+    const int i0 = blockIdx.x * 64, i = i0 + (int)lane;
+    const bool vis = i < P && radii[i] > 0;
+    const uint64_t vmask = __ballot(vis);
+    const int rw = 3 * M, ld = rw + 1, nvalid = min(64, P - i0), need = 3 * (D + 1) * (D + 1);
+    float* row = sh_tile + lane * ld;
+    if (vmask && D > 0) {                                              // the coefficients only enter through the view-direction term
+        if (sh_rest) sh_load_rows(sh_tile, ld, 3, sh_rest, rw - 3, i0, nvalid, vmask, need - 3, lane);
+        else sh_load_rows(sh_tile, ld, 0, sh_a, rw, i0, nvalid, vmask, need, lane);
+        __syncthreads();
+    }
+    if (vis) {
+        const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
+        const float d0[3] = { p[0] - campos[0], p[1] - campos[1], p[2] - campos[2] };
+        const float inv = 1.f / sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
+        const float x = d0[0] * inv, y = d0[1] * inv, z = d0[2] * inv;
+        const uint32_t cl = clamped[i];
+        float gdir[3] = { 0.f, 0.f, 0.f };
+        for (int ch = 0; ch < 3; ch++) {
+            const float g = ((cl >> ch) & 1u) ? 0.f : dcolors[3 * i + ch];
+#define SH(k) row[(k) * 3 + ch]
+            float dx_ = 0.f, dy_ = 0.f, dz_ = 0.f;                    // reads of this channel's coefficients first, then its gradient in place
+            if (D > 0) {
+                dx_ = -kC1 * SH(3); dy_ = -kC1 * SH(1); dz_ = kC1 * SH(2);
+                if (D > 1) {
+                    dx_ += kC2[0] * y * SH(4) + kC2[2] * 2.f * -x * SH(6) + kC2[3] * z * SH(7) + kC2[4] * 2.f * x * SH(8);
+                    dy_ += kC2[0] * x * SH(4) + kC2[1] * z * SH(5) + kC2[2] * 2.f * -y * SH(6) + kC2[4] * 2.f * -y * SH(8);
+                    dz_ += kC2[1] * y * SH(5) + kC2[2] * 4.f * z * SH(6) + kC2[3] * x * SH(7);
+                    if (D > 2) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        dx_ += kC3[0] * SH(9) * 6.f * xy + kC3[1] * SH(10) * yz + kC3[2] * SH(11) * -2.f * xy +
+                               kC3[3] * SH(12) * -6.f * xz + kC3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                               kC3[5] * SH(14) * 2.f * xz + kC3[6] * SH(15) * 3.f * (xx - yy);
+                        dy_ += kC3[0] * SH(9) * 3.f * (xx - yy) + kC3[1] * SH(10) * xz +
+                               kC3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + kC3[3] * SH(12) * -6.f * yz +
+                               kC3[4] * SH(13) * -2.f * xy + kC3[5] * SH(14) * -2.f * yz + kC3[6] * SH(15) * -6.f * xy;
+                        dz_ += kC3[1] * SH(10) * xy + kC3[2] * SH(11) * 8.f * yz + kC3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                               kC3[4] * SH(13) * 8.f * xz + kC3[5] * SH(14) * (xx - yy);
+                    }
+                }
+            }
+            gdir[0] += dx_ * g; gdir[1] += dy_ * g; gdir[2] += dz_ * g;
+            SH(0) = kC0 * g;
+            if (D > 0) {
+                SH(1) = -kC1 * y * g; SH(2) = kC1 * z * g; SH(3) = -kC1 * x * g;
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    SH(4) = kC2[0] * xy * g; SH(5) = kC2[1] * yz * g; SH(6) = kC2[2] * (2.f * zz - xx - yy) * g;
+                    SH(7) = kC2[3] * xz * g; SH(8) = kC2[4] * (xx - yy) * g;
+                    if (D > 2) {
+                        SH(9) = kC3[0] * y * (3.f * xx - yy) * g; SH(10) = kC3[1] * xy * z * g;
+                        SH(11) = kC3[2] * y * (4.f * zz - xx - yy) * g;
+                        SH(12) = kC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                        SH(13) = kC3[4] * x * (4.f * zz - xx - yy) * g; SH(14) = kC3[5] * z * (xx - yy) * g;
+                        SH(15) = kC3[6] * x * (xx - 3.f * yy) * g;
+                    }
+                }
+            }
+            for (int k = (D + 1) * (D + 1); k < M; k++) SH(k) = 0.f;      // coefficients above the active degree
+#undef SH
+        }
+        if (D > 0) {
+            const float dot = x * gdir[0] + y * gdir[1] + z * gdir[2];
+            dmeans3D[3 * i] += (gdir[0] - x * dot) * inv; dmeans3D[3 * i + 1] += (gdir[1] - y * dot) * inv;
+            dmeans3D[3 * i + 2] += (gdir[2] - z * dot) * inv;
+        }
+    } else {
+        for (int k = 0; k < rw; k++) row[k] = 0.f;
+    }
+    __syncthreads();
+    if (dsh_rest) {
+        sh_store_rows(sh_tile, ld, 0, dsh_a, 3, i0, nvalid, lane);
+        sh_store_rows(sh_tile, ld, 3, dsh_rest, rw - 3, i0, nvalid, lane);
+    } else {
+        sh_store_rows(sh_tile, ld, 0, dsh_a, rw, i0, nvalid, lane);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
                                                        const float* __restrict__ V, uint8_t* __restrict__ present) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -502,6 +696,24 @@ hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* mean
                        colors_given ? nullptr : shs, scales, mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W,
                        cam.H, cam.tanfovx, cam.tanfovy, radii, g.clamped, g.rec, grad_acc, dmeans2D, dcolors, dopac, dmeans3D,
                        dcov3D, colors_given ? nullptr : dsh, cov3D ? nullptr : dscales, cov3D ? nullptr : drots);
+    return hipGetLastError();
+}
+
+hipError_t egs_launch_sh_forward(int P, int D, int M, const float* means3D, const float* sh_a, const float* sh_rest, EgsCamera cam,
+                                 EgsGeomPtrs g, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    const size_t lds = (size_t)64 * (3 * M + 1) * sizeof(float);
+    hipLaunchKernelGGL(k_sh_forward, dim3((P + 63) / 64), dim3(64), lds, s, P, D, M, means3D, cam.campos, sh_a, sh_rest, g.visible, g.rec, g.clamped);
+    return hipGetLastError();
+}
+
+hipError_t egs_launch_sh_backward(int P, int D, int M, const float* means3D, const float* sh_a, const float* sh_rest, EgsCamera cam,
+                                  const int32_t* radii, EgsGeomPtrs g, const float* dcolors, float* dsh_a, float* dsh_rest,
+                                  float* dmeans3D, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    const size_t lds = (size_t)64 * (3 * M + 1) * sizeof(float);
+    hipLaunchKernelGGL(k_sh_backward, dim3((P + 63) / 64), dim3(64), lds, s, P, D, M, means3D, cam.campos, sh_a, sh_rest, radii, g.clamped,
+                       dcolors, dsh_a, dsh_rest, dmeans3D);
     return hipGetLastError();
 }
 

@@ -39,16 +39,16 @@ SIGNATURES = {
     "egs_get_geom_layout": (C.c_int, [i32, C.POINTER(GeomLayout)]),
     "egs_get_binning_layout": (C.c_int, [i32, i64, i32, i32, C.POINTER(BinningLayout)]),
     "egs_get_image_layout": (C.c_int, [i32, i32, C.POINTER(ImageLayout)]),
-    "egs_forward_geometry": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
+    "egs_forward_geometry": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
                                        i32, vp, vp, C.POINTER(i64), vp, i32]),
-    "egs_forward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, i64,
+    "egs_forward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, i64,
                                vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp, i32]),
-    "egs_forward_enqueue": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp,
+    "egs_forward_enqueue": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp,
                                        i64, vp, vp, vp, vp, vp, vp, vp, vp]),
     "egs_sum_counts": (C.c_int64, [i32, vp]),
     "egs_forward_render": (C.c_int, [i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
-    "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
-                               vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
+    "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
+                               vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "egs_cov3d_forward": (C.c_int, [i32, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_cov3d_dm_scratch_floats": (C.c_size_t, [i32]),

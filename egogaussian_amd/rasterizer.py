@@ -39,17 +39,19 @@ class GaussianRasterizationSettings(NamedTuple):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                activation_flags=0):
+                activation_flags=0, sh_rest=None):
         rs = raster_settings
+        if sh_rest is None:
+            sh_rest = torch.empty(0, device=means3D.device, dtype=torch.float32)
         num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
-            rs.campos, rs.prefiltered, rs.debug, activation_flags)
+            rs.campos, rs.prefiltered, rs.debug, activation_flags, sh_rest)
         ctx.raster_settings = rs
         ctx.activation_flags = int(activation_flags)
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img,
-                              alpha)
+                              alpha, sh_rest)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)        # unused depth/alpha outputs arrive as None in backward, not as zero images
         return color, radii, depth, alpha
@@ -57,7 +59,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
         rs = ctx.raster_settings
-        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, alpha = ctx.saved_tensors
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, alpha, sh_rest = ctx.saved_tensors
         H, W = int(rs.image_height), int(rs.image_width)
         dev = means3D.device
         if grad_color is None:
@@ -66,20 +68,23 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_depth = torch.empty(0, device=dev)
         if grad_alpha is None:
             grad_alpha = torch.empty(0, device=dev)
-        (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = _C.rasterize_gaussians_backward(
+        split = sh_rest.numel() != 0
+        grads = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos, geom,
-            ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags)
+            ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags, sh_rest if split else None)
+        (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = grads[:8]
         none_if_absent = lambda g, x: g if x.numel() != 0 else None
         return (g_means3D, g_means2D, none_if_absent(g_sh, sh), none_if_absent(g_colors, colors_precomp),
                 g_opac, none_if_absent(g_scales, scales),
-                none_if_absent(g_rots, rotations), none_if_absent(g_cov3D, cov3Ds_precomp), None, None)
+                none_if_absent(g_rots, rotations), none_if_absent(g_cov3D, cov3Ds_precomp), None, None,
+                grads[8] if split else None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, activation_flags=0):
+                        raster_settings, activation_flags=0, sh_rest=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, activation_flags)
+                                     cov3Ds_precomp, raster_settings, activation_flags, sh_rest)
 
 
 class GaussianRasterizer(nn.Module):
@@ -96,7 +101,14 @@ class GaussianRasterizer(nn.Module):
                 cov3D_precomp=None, raw_parameters=False):
         """Same call as upstream's.  raw_parameters=True (an extension): `scales`, `rotations` and `opacities` are the model's RAW
         parameters (log-scales, unnormalised quaternions, opacity logits); the activations run inside the preprocess kernel and
-        the gradients come back w.r.t. the raw tensors (include/egs_raster.h, EGS_ACT_*)."""
+        the gradients come back w.r.t. the raw tensors (include/egs_raster.h, EGS_ACT_*).
+        `shs` may also be the pair (features_dc [P,1,3], features_rest [P,M-1,3]) -- the two parameters the reference's model keeps
+        (/root/reference/scene/gaussian_model.py:157-160) -- which spares the torch.cat of get_features and the split of its gradient."""
+        shs_rest = None
+        if isinstance(shs, (tuple, list)):
+            shs, shs_rest = shs
+            if shs_rest.shape[1] == 0:
+                shs_rest = None
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("GaussianRasterizer: pass exactly one of `shs` or `colors_precomp`")
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -111,4 +123,4 @@ class GaussianRasterizer(nn.Module):
         if raw_parameters and cov3D_precomp.numel() != 0:
             raise Exception("GaussianRasterizer: raw_parameters needs `scales` and `rotations`, not `cov3D_precomp`")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   self.raster_settings, _C.ACT_RAW_PARAMETERS if raw_parameters else 0)
+                                   self.raster_settings, _C.ACT_RAW_PARAMETERS if raw_parameters else 0, shs_rest)

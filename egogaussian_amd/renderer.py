@@ -70,6 +70,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         dirs = xyz - viewpoint_camera.camera_center.repeat(feats.shape[0], 1)
         dirs = dirs / dirs.norm(dim=1, keepdim=True)
         colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dirs) + 0.5, 0.0)
+    elif getattr(pc, "get_features_split", None) is not None and pc.get_features_split() is not None:
+        shs = pc.get_features_split()             # optional hook: (features_dc, features_rest) as they are stored -- no torch.cat per render
     else:
         shs = pc.get_features
 

@@ -184,6 +184,12 @@ class SynthGaussians:
             return fused.covariance_from_log_scaling(self._scaling, scaling_modifier, self._rotation)
         return self._cov.covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
 
+    def get_features_split(self):
+        """Optional hook render() looks for: the colour coefficients as the two stored parameters (HIP devices only)."""
+        if self.fused and self._xyz.is_cuda:
+            return self._features_dc, self._features_rest
+        return None
+
     def get_raw_parameters(self):
         """Optional hook render() looks for: (log-scales, raw quaternions, opacity logits) for the rasterizer's raw-parameter
         mode (HIP devices only; None otherwise)."""

@@ -108,12 +108,17 @@ int egs_get_image_layout(int width, int height, egs_image_layout* out);
  *   EGS_ACT_RAW_QUATS      `rotations` is not normalised        (likewise)
  *   EGS_ACT_LOGIT_OPACITY  `opacities` holds logits
  * Pass the SAME flags to the forward and to egs_backward. */
+/* Split spherical harmonics.  The reference keeps the colour coefficients as two parameters, _features_dc [P,1,3] and
+ * _features_rest [P,M-1,3], and concatenates them before every render (/root/reference/scene/gaussian_model.py:157-160
+ * get_features); autograd splits the gradient again.  With shs_rest != NULL, `shs` is the DC block [P,1,3] and `shs_rest` the
+ * remaining [P,M-1,3] (sh_coeffs is still M >= 2); egs_backward then writes dL_dsh [P,1,3] and dL_dsh_rest [P,M-1,3]. */
 #define EGS_ACT_LOG_SCALES 1
 #define EGS_ACT_RAW_QUATS 2
 #define EGS_ACT_LOGIT_OPACITY 4
 int egs_forward_geometry(
     int P, int sh_degree, int sh_coeffs /* M: coefficients per channel in `shs` */,
-    const float* means3D /*[P,3]*/, const float* shs /*[P,M,3] or NULL*/, const float* colors_precomp /*[P,3] or NULL*/,
+    const float* means3D /*[P,3]*/, const float* shs /*[P,M,3] or NULL*/, const float* shs_rest /*see below; normally NULL*/,
+    const float* colors_precomp /*[P,3] or NULL*/,
     const float* opacities /*[P]*/, const float* scales /*[P,3] or NULL*/, float scale_modifier,
     const float* rotations /*[P,4] or NULL*/, const float* cov3D_precomp /*[P,6] or NULL*/, int activation_flags /*EGS_ACT_*, 0 = none*/,
     const float* viewmatrix /*[16]*/, const float* projmatrix /*[16]*/, const float* campos /*[3]*/,
@@ -140,7 +145,7 @@ int egs_forward_render(
  *      egs_forward_render(P, that_size, ...).  Keeps one hipEvent per calling thread. */
 int egs_forward(
     int P, int sh_degree, int sh_coeffs,
-    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
     const float* viewmatrix, const float* projmatrix, const float* campos, const float* background,
     int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
@@ -156,7 +161,7 @@ int egs_forward(
  *                             that is larger, so one word tells whether ANY replay so far overflowed. */
 int egs_forward_enqueue(
     int P, int sh_degree, int sh_coeffs,
-    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities,
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
     const float* viewmatrix, const float* projmatrix, const float* campos, const float* background,
     int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
@@ -167,7 +172,7 @@ int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts /*HOST*/);
 /* ---- backward  (upstream: render backward + computeCov2D backward + preprocess backward) ------- */
 int egs_backward(
     int P, int sh_degree, int sh_coeffs, int64_t R,
-    const float* background, const float* means3D, const float* shs, const float* colors_precomp,
+    const float* background, const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp,
     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
     const float* viewmatrix, const float* projmatrix, const float* campos,
     int width, int height, float tan_fovx, float tan_fovy,
@@ -177,6 +182,7 @@ int egs_backward(
     float* dL_dmeans2D /*[P,3] out, NDC-scaled (x 0.5*W, 0.5*H), z = 0*/,
     float* dL_dcolors /*[P,3] out*/, float* dL_dopacity /*[P] out*/, float* dL_dmeans3D /*[P,3] out*/,
     float* dL_dcov3D /*[P,6] out; may be NULL with scales + rotations*/, float* dL_dsh /*[P,M,3] out or NULL*/,
+    float* dL_dsh_rest /*[P,M-1,3] out with shs_rest (dL_dsh is then [P,1,3]), else NULL*/,
     float* dL_dscales /*[P,3] out or NULL*/, float* dL_drotations /*[P,4] out or NULL*/,
     void* scratch /* egs_backward_scratch_bytes(P) */, void* stream, int debug);
 

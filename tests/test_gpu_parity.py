@@ -538,3 +538,56 @@ def test_raw_parameter_mode_matches_activated_inputs(colour_mode):
     with pytest.raises(Exception, match="raw_parameters"):
         GaussianRasterizer(rs)(means3D=g["means3D"], means2D=g["means3D"], opacities=raw_o, cov3D_precomp=torch.zeros(N, 6, device=dev),
                                raw_parameters=True, **kw)
+
+
+@pytest.mark.parametrize("active,M", [(0, 16), (1, 16), (2, 9), (3, 16), (1, 4)])
+def test_split_spherical_harmonics_match_the_concatenated_call(active, M):
+    """shs=(features_dc, features_rest) -- the two tensors the reference's model stores -- must give the bits of shs=torch.cat(...)
+    (same kernels, other addressing) with the gradient arriving already split (equal up to the order of the blend's float atomics); coefficients above the active degree get zeros.
+    Also with a base address that is not 16-byte aligned (scalar path of the row transposition) and against the oracle's dL/dSH."""
+    from egogaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    dev = _dev()
+    N, H, W = 5003, 96, 128                                            # not a multiple of 64: ragged last wave
+    deg_full = {4: 1, 9: 2, 16: 3}[M]
+    d = make_inputs(N, H, W, 21, deg_full, "sh_cov", scale_mul=2.5)
+    d["sh_degree"] = active
+    g = _to(d, dev)
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=g["tanfovx"], tanfovy=g["tanfovy"], bg=g["bg"],
+                                       scale_modifier=g["scale_modifier"], viewmatrix=g["viewmatrix"], projmatrix=g["projmatrix"],
+                                       sh_degree=active, campos=g["campos"], prefiltered=False, debug=False)
+    grads = [t.to(dev) for t in seeded_grads(H, W, 5)]
+    res = {}
+    for how in ("cat", "split", "split-unaligned"):
+        xyz = g["means3D"].clone().requires_grad_(True)
+        if how == "split-unaligned":
+            store = torch.zeros(N * (M - 1) * 3 + 1, device=dev)
+            store[1:] = g["shs"][:, 1:].reshape(-1)
+            rest = store[1:].view(N, M - 1, 3).detach().requires_grad_(True)
+            assert rest.data_ptr() % 16 == 4
+        else:
+            rest = g["shs"][:, 1:].clone().requires_grad_(True)
+        dc = g["shs"][:, :1].clone().requires_grad_(True)
+        shs = torch.cat((dc, rest), dim=1) if how == "cat" else (dc, rest)
+        color, radii, depth, alpha = GaussianRasterizer(rs)(means3D=xyz, means2D=torch.zeros_like(xyz), opacities=g["opacities"], shs=shs,
+                                                            cov3D_precomp=g["cov3D_precomp"])
+        ((color * grads[0]).sum() + (depth * grads[1]).sum() + (alpha * grads[2]).sum()).backward()
+        res[how] = (color.detach(), radii, xyz.grad, dc.grad, rest.grad)
+    ref = res["cat"]
+    for how in ("split", "split-unaligned"):
+        for k, name in enumerate(("colour", "radii")):
+            assert torch.equal(res[how][k], ref[k]), f"{how}: {name} differs from the concatenated call"
+        for k, name in ((2, "d/dxyz"), (3, "d/dfeatures_dc"), (4, "d/dfeatures_rest")):       # (the blend backward sums with float atomics)
+            assert res[how][k].shape == ref[k].shape
+            assert outlier_fraction(res[how][k].cpu().numpy(), ref[k].cpu().numpy(), 1e-4) <= 1e-4, f"{how}: {name}"
+            assert torch.equal(res[how][k] == 0, ref[k] == 0), f"{how}: {name} zero pattern"
+    n_active = (active + 1) ** 2
+    assert float(ref[4][:, n_active - 1:].abs().max()) == 0.0 if n_active < M else True
+    assert float(ref[4][:, :max(n_active - 1, 0)].abs().sum()) > 0 or active == 0
+    assert float(ref[3].abs().sum()) > 0
+    # the oracle on the same inputs
+    o, st = oracle_forward(d)
+    gb = o.backward(st, *seeded_grads(H, W, 5))
+    full = torch.cat((ref[3], ref[4]), dim=1).cpu().numpy()
+    assert outlier_fraction(full, gb["dL_dsh"].reshape(full.shape), TOL) <= 2e-4
+    assert outlier_fraction(ref[2].cpu().numpy(), gb["dL_dmeans3D"], TOL) <= 2e-4
+    assert outlier_fraction(ref[0].cpu().numpy(), st["color"], TOL) <= 1e-4
