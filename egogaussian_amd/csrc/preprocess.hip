@@ -472,16 +472,24 @@ __device__ __forceinline__ void sh_load_rows(float* tile, int ld, int col0, cons
     const float inv_rw = 1.f / (float)rw;
     const float* base = src + (size_t)i0 * rw;
     const int n = nvalid * rw;
-    if ((((uintptr_t)base) & 15) == 0 && (n & 3) == 0) {
+    if ((((uintptr_t)base) & 15) == 0 && (n & 3) == 0 && rw <= 48) {
+        // all (up to 12) loads of the lane are issued before the first one is used: one HBM round trip per wave, not twelve
         const float4* b4 = reinterpret_cast<const float4*>(base);
-        for (int q = lane; 4 * q < n; q += 64) {
+        float4 v[12]; bool want[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int q = (int)lane + 64 * k;
             int r0, c0, r3, c3;
             sh_row_col(4 * q, rw, inv_rw, r0, c0); sh_row_col(4 * q + 3, rw, inv_rw, r3, c3);
-            const bool want = (((vmask >> r0) & 1) && c0 < need) || (r3 != r0 && ((vmask >> r3) & 1)) ||
-                              (r3 - r0 > 1 && ((vmask >> (r0 + 1)) & 1));
-            if (!want) continue;
-            const float4 v = b4[q];
-            const float vv[4] = { v.x, v.y, v.z, v.w };
+            want[k] = 4 * q < n && ((((vmask >> r0) & 1) && c0 < need) || (r3 != r0 && ((vmask >> r3) & 1)) ||
+                                    (r3 - r0 > 1 && ((vmask >> (r0 + 1)) & 1)));
+            if (want[k]) v[k] = b4[q];
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            if (!want[k]) continue;
+            const int q = (int)lane + 64 * k;
+            const float vv[4] = { v[k].x, v[k].y, v[k].z, v[k].w };
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 int r, c; sh_row_col(4 * q + j, rw, inv_rw, r, c);
@@ -641,6 +649,243 @@ __global__ __launch_bounds__(64) void k_sh_backward(int P, int D, int M, const f
     }
 }
 
+// ---- M = 16 (the reference's max_sh_degree = 3), 16-byte aligned arrays: the same two kernels with the index arithmetic of the
+// transposition removed.
+//   CAT   [P,16,3]: float4 q of the block goes to LDS slot q + q / 12, i.e. rows of 13 float4 -- an odd stride, so the twelve
+//         ds_read_b128 / ds_write_b128 a lane does on its own row are conflict-free.
+//   SPLIT [P,1,3] + [P,15,3]: both blocks are copied linearly; rows of 3 and 45 words are odd strides already (scalar row accesses).
+// A lane keeps its row (48 coefficients, then 48 gradients) in registers.
+#define SH16_CAT 1
+#define SH16_SPLIT 2
+#define SH16_REST_WORDS (64 * 45)
+
+// gather this block's rows into LDS; `need` = words of a row's head that will be read (3 (D+1)^2)
+template <int MODE>
+__device__ __forceinline__ void sh16_stage_in(float* tile, const float* __restrict__ sh_a, const float* __restrict__ sh_rest, int i0, int nvalid,
+                                              uint64_t vmask, int need, unsigned lane) {
+    if (MODE == SH16_CAT) {
+        const float4* b4 = reinterpret_cast<const float4*>(sh_a + (size_t)i0 * 48);
+        float4* t4 = reinterpret_cast<float4*>(tile);
+        // (twelve named registers, not an array: the compiler parks an array of conditionally loaded float4 in scratch, which
+        // serialises the loads)
+#define SH16_LD(k) float4 v##k = make_float4(0.f, 0.f, 0.f, 0.f); bool w##k;                                   \
+        { const unsigned q = lane + 64u * k, row = q / 12u, j = q - row * 12u;                                 \
+          w##k = (int)row < nvalid && ((vmask >> row) & 1) && (int)(4u * j) < need; if (w##k) v##k = b4[q]; }
+#define SH16_PUT(k) { const unsigned q = lane + 64u * k; if (w##k) t4[q + q / 12u] = v##k; }
+        SH16_LD(0) SH16_LD(1) SH16_LD(2) SH16_LD(3) SH16_LD(4) SH16_LD(5) SH16_LD(6) SH16_LD(7) SH16_LD(8) SH16_LD(9) SH16_LD(10) SH16_LD(11)
+        SH16_PUT(0) SH16_PUT(1) SH16_PUT(2) SH16_PUT(3) SH16_PUT(4) SH16_PUT(5) SH16_PUT(6) SH16_PUT(7) SH16_PUT(8) SH16_PUT(9) SH16_PUT(10) SH16_PUT(11)
+#undef SH16_LD
+#undef SH16_PUT
+    } else {
+        float* tdc = tile + SH16_REST_WORDS;
+        const int n_dc = nvalid * 3, n_rest = nvalid * 45, need_rest = need - 3;
+        const float* bdc = sh_a + (size_t)i0 * 3;
+        const float* brest = sh_rest + (size_t)i0 * 45;
+        float4 vd = make_float4(0.f, 0.f, 0.f, 0.f); bool wd = false;
+        {
+            const int e = 4 * (int)lane;
+            wd = e + 3 < n_dc && ((vmask >> (e / 3)) | (vmask >> ((e + 3) / 3))) & 1;
+            if (wd) vd = reinterpret_cast<const float4*>(bdc)[lane];
+        }
+#define SH16_LD(k) float4 v##k = make_float4(0.f, 0.f, 0.f, 0.f); bool w##k;                                   \
+        { const int e = 4 * ((int)lane + 64 * k), r0 = e / 45, r1 = (e + 3) / 45;                              \
+          w##k = need_rest > 0 && e + 3 < n_rest &&                                                            \
+                 ((((vmask >> r0) & 1) && e - 45 * r0 < need_rest) || (r1 != r0 && ((vmask >> r1) & 1)));      \
+          if (w##k) v##k = reinterpret_cast<const float4*>(brest)[lane + 64 * k]; }
+#define SH16_PUT(k) if (w##k) reinterpret_cast<float4*>(tile)[lane + 64 * k] = v##k;
+        SH16_LD(0) SH16_LD(1) SH16_LD(2) SH16_LD(3) SH16_LD(4) SH16_LD(5) SH16_LD(6) SH16_LD(7) SH16_LD(8) SH16_LD(9) SH16_LD(10) SH16_LD(11)
+        if (wd) reinterpret_cast<float4*>(tdc)[lane] = vd;
+        SH16_PUT(0) SH16_PUT(1) SH16_PUT(2) SH16_PUT(3) SH16_PUT(4) SH16_PUT(5) SH16_PUT(6) SH16_PUT(7) SH16_PUT(8) SH16_PUT(9) SH16_PUT(10) SH16_PUT(11)
+#undef SH16_LD
+#undef SH16_PUT
+        if (lane < 3) {                                                // ragged last block: the words after the last whole float4
+            const int ed = (n_dc & ~3) + (int)lane, er = (n_rest & ~3) + (int)lane;
+            if (ed < n_dc) tdc[ed] = bdc[ed];
+            if (er < n_rest && need_rest > 0) tile[er] = brest[er];
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void sh16_row_to_regs(const float* tile, unsigned lane, int need, float (&c)[48]) {
+    if (MODE == SH16_CAT) {
+        const float4* t4 = reinterpret_cast<const float4*>(tile) + lane * 13u;
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * j < need) t = t4[j];
+            c[4 * j] = t.x; c[4 * j + 1] = t.y; c[4 * j + 2] = t.z; c[4 * j + 3] = t.w;
+        }
+    } else {
+        const float* tdc = tile + SH16_REST_WORDS + lane * 3u;
+        const float* tr = tile + lane * 45u;
+        c[0] = tdc[0]; c[1] = tdc[1]; c[2] = tdc[2];
+#pragma unroll
+        for (int t = 0; t < 45; t++) c[3 + t] = t < need - 3 ? tr[t] : 0.f;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void sh16_regs_to_row(float* tile, unsigned lane, const float (&g)[48]) {
+    if (MODE == SH16_CAT) {
+        float4* t4 = reinterpret_cast<float4*>(tile) + lane * 13u;
+#pragma unroll
+        for (int j = 0; j < 12; j++) t4[j] = make_float4(g[4 * j], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]);
+    } else {
+        float* tdc = tile + SH16_REST_WORDS + lane * 3u;
+        float* tr = tile + lane * 45u;
+        tdc[0] = g[0]; tdc[1] = g[1]; tdc[2] = g[2];
+#pragma unroll
+        for (int t = 0; t < 45; t++) tr[t] = g[3 + t];
+    }
+}
+
+// LDS rows -> this block's rows of the gradient arrays, every word, in lane order
+template <int MODE>
+__device__ __forceinline__ void sh16_stage_out(const float* tile, float* __restrict__ dsh_a, float* __restrict__ dsh_rest, int i0, int nvalid,
+                                               unsigned lane) {
+    if (MODE == SH16_CAT) {
+        float4* b4 = reinterpret_cast<float4*>(dsh_a + (size_t)i0 * 48);
+        const float4* t4 = reinterpret_cast<const float4*>(tile);
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const unsigned q = lane + 64u * k, row = q / 12u;
+            if ((int)row < nvalid) b4[q] = t4[q + row];
+        }
+    } else {
+        const float* tdc = tile + SH16_REST_WORDS;
+        const int n_dc = nvalid * 3, n_rest = nvalid * 45;
+        float* bdc = dsh_a + (size_t)i0 * 3;
+        float* brest = dsh_rest + (size_t)i0 * 45;
+        if (4 * (int)lane + 3 < n_dc) reinterpret_cast<float4*>(bdc)[lane] = reinterpret_cast<const float4*>(tdc)[lane];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int q = (int)lane + 64 * k;
+            if (4 * q + 3 < n_rest) reinterpret_cast<float4*>(brest)[q] = reinterpret_cast<const float4*>(tile)[q];
+        }
+        if (lane < 3) {
+            const int ed = (n_dc & ~3) + (int)lane, er = (n_rest & ~3) + (int)lane;
+            if (ed < n_dc) bdc[ed] = tdc[ed];
+            if (er < n_rest) brest[er] = tile[er];
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_sh16_forward(int P, int D, const float* __restrict__ means3D, const float* __restrict__ campos,
+                                                     const float* __restrict__ sh_a, const float* __restrict__ sh_rest,
+                                                     const uint8_t* __restrict__ visible, float4* __restrict__ rec, uint8_t* __restrict__ clamped) {
+    const unsigned lane = threadIdx.x;
+    const int i0 = blockIdx.x * 64, i = i0 + (int)lane;
+    const bool inb = i < P;
+    const bool vis = inb && visible[i] != 0;
+    float p[3] = { 0.f, 0.f, 1.f };
+    if (inb) { p[0] = means3D[3 * i]; p[1] = means3D[3 * i + 1]; p[2] = means3D[3 * i + 2]; }   // (in flight together with the rows)
+    const uint64_t vmask = __ballot(vis);
+    if (!vmask) return;
+    const int need = 3 * (D + 1) * (D + 1);
+    sh16_stage_in<MODE>(sh_tile, sh_a, sh_rest, i0, min(64, P - i0), vmask, need, lane);
+    __syncthreads();
+    if (!vis) return;
+    float c[48];
+    sh16_row_to_regs<MODE>(sh_tile, lane, need, c);
+    float dir[3] = { p[0] - campos[0], p[1] - campos[1], p[2] - campos[2] };
+    const float inv = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    dir[0] *= inv; dir[1] *= inv; dir[2] *= inv;
+    float rgb[3]; uint32_t cl = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const float v = sh_channel(D, c, ch, dir[0], dir[1], dir[2]);
+        if (v < 0.f) cl |= 1u << ch;
+        rgb[ch] = fmaxf(v, 0.f);
+    }
+    clamped[i] = (uint8_t)cl;
+    float* r = reinterpret_cast<float*>(rec + (size_t)i * EGS_SPLAT_REC_F4);
+    r[6] = rgb[0]; r[7] = rgb[1]; r[8] = rgb[2];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_sh16_backward(int P, int D, const float* __restrict__ means3D, const float* __restrict__ campos,
+                                                      const float* __restrict__ sh_a, const float* __restrict__ sh_rest,
+                                                      const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
+                                                      const float* __restrict__ dcolors, float* __restrict__ dsh_a, float* __restrict__ dsh_rest,
+                                                      float* __restrict__ dmeans3D) {
+    const unsigned lane = threadIdx.x;
+    const int i0 = blockIdx.x * 64, i = i0 + (int)lane;
+    const bool inb = i < P;
+    const bool vis = inb && radii[i] > 0;
+    float p[3] = { 0.f, 0.f, 1.f }, dc[3] = { 0.f, 0.f, 0.f }, gm[3] = { 0.f, 0.f, 0.f };
+    uint32_t cl = 0;
+    if (inb) {                                                         // everything the row math needs besides the rows, issued up front
+        p[0] = means3D[3 * i]; p[1] = means3D[3 * i + 1]; p[2] = means3D[3 * i + 2];
+        dc[0] = dcolors[3 * i]; dc[1] = dcolors[3 * i + 1]; dc[2] = dcolors[3 * i + 2];
+        cl = clamped[i];
+        if (D > 0) { gm[0] = dmeans3D[3 * i]; gm[1] = dmeans3D[3 * i + 1]; gm[2] = dmeans3D[3 * i + 2]; }
+    }
+    const uint64_t vmask = __ballot(vis);
+    const int nvalid = min(64, P - i0), need = 3 * (D + 1) * (D + 1);
+    float c[48], g[48];
+#pragma unroll
+    for (int k = 0; k < 48; k++) { c[k] = 0.f; g[k] = 0.f; }
+    if (vmask && D > 0) {                                              // the coefficients only enter through the view-direction term
+        sh16_stage_in<MODE>(sh_tile, sh_a, sh_rest, i0, nvalid, vmask, need, lane);
+        __syncthreads();
+        if (vis) sh16_row_to_regs<MODE>(sh_tile, lane, need, c);
+    }
+    if (vis) {
+        const float d0[3] = { p[0] - campos[0], p[1] - campos[1], p[2] - campos[2] };
+        const float inv = 1.f / sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
+        const float x = d0[0] * inv, y = d0[1] * inv, z = d0[2] * inv;
+        float gdir[3] = { 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float gg = ((cl >> ch) & 1u) ? 0.f : dc[ch];
+#define SH(k) c[(k) * 3 + ch]
+#define GSH(k) g[(k) * 3 + ch]
+            float dx_ = 0.f, dy_ = 0.f, dz_ = 0.f;
+            GSH(0) = kC0 * gg;
+            if (D > 0) {
+                GSH(1) = -kC1 * y * gg; GSH(2) = kC1 * z * gg; GSH(3) = -kC1 * x * gg;
+                dx_ = -kC1 * SH(3); dy_ = -kC1 * SH(1); dz_ = kC1 * SH(2);
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    GSH(4) = kC2[0] * xy * gg; GSH(5) = kC2[1] * yz * gg; GSH(6) = kC2[2] * (2.f * zz - xx - yy) * gg;
+                    GSH(7) = kC2[3] * xz * gg; GSH(8) = kC2[4] * (xx - yy) * gg;
+                    dx_ += kC2[0] * y * SH(4) + kC2[2] * 2.f * -x * SH(6) + kC2[3] * z * SH(7) + kC2[4] * 2.f * x * SH(8);
+                    dy_ += kC2[0] * x * SH(4) + kC2[1] * z * SH(5) + kC2[2] * 2.f * -y * SH(6) + kC2[4] * 2.f * -y * SH(8);
+                    dz_ += kC2[1] * y * SH(5) + kC2[2] * 4.f * z * SH(6) + kC2[3] * x * SH(7);
+                    if (D > 2) {
+                        GSH(9) = kC3[0] * y * (3.f * xx - yy) * gg; GSH(10) = kC3[1] * xy * z * gg;
+                        GSH(11) = kC3[2] * y * (4.f * zz - xx - yy) * gg;
+                        GSH(12) = kC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * gg;
+                        GSH(13) = kC3[4] * x * (4.f * zz - xx - yy) * gg; GSH(14) = kC3[5] * z * (xx - yy) * gg;
+                        GSH(15) = kC3[6] * x * (xx - 3.f * yy) * gg;
+                        dx_ += kC3[0] * SH(9) * 6.f * xy + kC3[1] * SH(10) * yz + kC3[2] * SH(11) * -2.f * xy +
+                               kC3[3] * SH(12) * -6.f * xz + kC3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                               kC3[5] * SH(14) * 2.f * xz + kC3[6] * SH(15) * 3.f * (xx - yy);
+                        dy_ += kC3[0] * SH(9) * 3.f * (xx - yy) + kC3[1] * SH(10) * xz +
+                               kC3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + kC3[3] * SH(12) * -6.f * yz +
+                               kC3[4] * SH(13) * -2.f * xy + kC3[5] * SH(14) * -2.f * yz + kC3[6] * SH(15) * -6.f * xy;
+                        dz_ += kC3[1] * SH(10) * xy + kC3[2] * SH(11) * 8.f * yz + kC3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                               kC3[4] * SH(13) * 8.f * xz + kC3[5] * SH(14) * (xx - yy);
+                    }
+                }
+            }
+#undef SH
+#undef GSH
+            gdir[0] += dx_ * gg; gdir[1] += dy_ * gg; gdir[2] += dz_ * gg;
+        }
+        if (D > 0) {
+            const float dot = x * gdir[0] + y * gdir[1] + z * gdir[2];
+            dmeans3D[3 * i] = gm[0] + (gdir[0] - x * dot) * inv; dmeans3D[3 * i + 1] = gm[1] + (gdir[1] - y * dot) * inv;
+            dmeans3D[3 * i + 2] = gm[2] + (gdir[2] - z * dot) * inv;
+        }
+    }
+    sh16_regs_to_row<MODE>(sh_tile, lane, g);                          // (a lane touches only its own row: no barrier since the reads above)
+    __syncthreads();
+    sh16_stage_out<MODE>(sh_tile, dsh_a, dsh_rest, i0, nvalid, lane);
+}
+
 __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
                                                        const float* __restrict__ V, uint8_t* __restrict__ present) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -699,11 +944,23 @@ hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* mean
     return hipGetLastError();
 }
 
+static bool sh16_fast(int M, const void* a, const void* b, const void* c, const void* d) {
+    return M == 16 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
+}
+
 hipError_t egs_launch_sh_forward(int P, int D, int M, const float* means3D, const float* sh_a, const float* sh_rest, EgsCamera cam,
                                  EgsGeomPtrs g, hipStream_t s) {
     if (P == 0) return hipSuccess;
+    const dim3 grid((P + 63) / 64), block(64);
+    if (sh16_fast(M, sh_a, sh_rest, nullptr, nullptr)) {
+        if (sh_rest) hipLaunchKernelGGL(k_sh16_forward<SH16_SPLIT>, grid, block, (SH16_REST_WORDS + 192) * sizeof(float), s, P, D, means3D, cam.campos,
+                                        sh_a, sh_rest, g.visible, g.rec, g.clamped);
+        else hipLaunchKernelGGL(k_sh16_forward<SH16_CAT>, grid, block, 64 * 13 * sizeof(float4), s, P, D, means3D, cam.campos, sh_a, sh_rest,
+                                g.visible, g.rec, g.clamped);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)64 * (3 * M + 1) * sizeof(float);
-    hipLaunchKernelGGL(k_sh_forward, dim3((P + 63) / 64), dim3(64), lds, s, P, D, M, means3D, cam.campos, sh_a, sh_rest, g.visible, g.rec, g.clamped);
+    hipLaunchKernelGGL(k_sh_forward, grid, block, lds, s, P, D, M, means3D, cam.campos, sh_a, sh_rest, g.visible, g.rec, g.clamped);
     return hipGetLastError();
 }
 
@@ -711,8 +968,16 @@ hipError_t egs_launch_sh_backward(int P, int D, int M, const float* means3D, con
                                   const int32_t* radii, EgsGeomPtrs g, const float* dcolors, float* dsh_a, float* dsh_rest,
                                   float* dmeans3D, hipStream_t s) {
     if (P == 0) return hipSuccess;
+    const dim3 grid((P + 63) / 64), block(64);
+    if (sh16_fast(M, sh_a, sh_rest, dsh_a, dsh_rest)) {
+        if (sh_rest) hipLaunchKernelGGL(k_sh16_backward<SH16_SPLIT>, grid, block, (SH16_REST_WORDS + 192) * sizeof(float), s, P, D, means3D, cam.campos,
+                                        sh_a, sh_rest, radii, g.clamped, dcolors, dsh_a, dsh_rest, dmeans3D);
+        else hipLaunchKernelGGL(k_sh16_backward<SH16_CAT>, grid, block, 64 * 13 * sizeof(float4), s, P, D, means3D, cam.campos, sh_a, sh_rest,
+                                radii, g.clamped, dcolors, dsh_a, dsh_rest, dmeans3D);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)64 * (3 * M + 1) * sizeof(float);
-    hipLaunchKernelGGL(k_sh_backward, dim3((P + 63) / 64), dim3(64), lds, s, P, D, M, means3D, cam.campos, sh_a, sh_rest, radii, g.clamped,
+    hipLaunchKernelGGL(k_sh_backward, grid, block, lds, s, P, D, M, means3D, cam.campos, sh_a, sh_rest, radii, g.clamped,
                        dcolors, dsh_a, dsh_rest, dmeans3D);
     return hipGetLastError();
 }

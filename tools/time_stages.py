@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-stage HIP-event timing of the rasterizer alone (forward + backward) on a synthetic scene.
-   python tools/time_stages.py [N] [H] [W] [iters]     (EGS_RASTER_LIB=path selects an A/B build of the library)"""
+   python tools/time_stages.py [N] [H] [W] [iters]     (EGS_RASTER_LIB=path selects an A/B build of the library;
+   SH_DEGREE=d for more colour coefficients, SH_SPLIT=0 to hand them over concatenated as the reference's get_features does)"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +11,12 @@ from egogaussian_amd.renderer import render
 
 N, H, W, iters = [int(a) for a in (sys.argv[1:5] + ["500000", "540", "960", "30"][len(sys.argv) - 1:])]
 dev = "cuda:0"
-pc = SynthGaussians(make_scene(N, H, W, 0), device=dev)
+D = int(os.environ.get("SH_DEGREE", "0"))
+pc = SynthGaussians(make_scene(N, H, W, 0, sh_degree=D), device=dev, sh_degree=D)
+if os.environ.get("SH_SPLIT", "1") == "0":
+    pc.get_features_split = lambda: None
+vis = render(make_camera(0, H, W, device=dev), pc, Pipe, torch.zeros(3, device=dev))["visibility_filter"]
+print("visible fraction", float(vis.float().mean()))
 cams = [make_camera(k, H, W, device=dev) for k in range(8)]
 bg = torch.zeros(3, device=dev)
 g = torch.Generator().manual_seed(1)
