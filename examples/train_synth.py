@@ -35,19 +35,20 @@ def main(argv=None):
     ap.add_argument("--opacity-reset-interval", type=int, default=300)
     ap.add_argument("--grad-threshold", type=float, default=2e-4)
     ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--sh-degree", type=int, default=0, help="spherical-harmonics degree of the colour model (0..3)")
     ap.add_argument("--out", default="")
     a = ap.parse_args(argv)
     dev = torch.device("cuda", 0)
     H, W = a.height, a.width
-    teacher = make_scene(a.gaussians, H, W, seed=0)
+    teacher = make_scene(a.gaussians, H, W, seed=0, sh_degree=a.sh_degree)
     if a.gaussians < 100_000:
         teacher["log_scale"] += math.log(2.0)                       # few splats: make them larger so the image is covered
     cams = [make_camera(k * (N_FRAMES // a.frames), H, W, device=dev) for k in range(a.frames)]
     bg = torch.zeros(3, device=dev)
     with torch.no_grad():
-        tpc = SynthGaussians(teacher, device=dev, requires_grad=False)
+        tpc = SynthGaussians(teacher, device=dev, sh_degree=a.sh_degree, requires_grad=False)
         gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
-    pc = SynthGaussians(perturb_student(teacher), device=dev)
+    pc = SynthGaussians(perturb_student(teacher), device=dev, sh_degree=a.sh_degree)
     pc.training_setup(capturable=True)
     extent = 10.0
 
@@ -77,7 +78,7 @@ def main(argv=None):
     print(f"end: {pc._xyz.shape[0]} Gaussians, PSNR {quality():.2f} dB, {a.iters / dt:.0f} it/s including densification and re-captures")
     if a.out:
         ply.save_ply(pc, a.out)
-        back = ply.load_ply(SynthGaussians(teacher, device=dev), a.out, device=dev)
+        back = ply.load_ply(SynthGaussians(teacher, device=dev, sh_degree=a.sh_degree), a.out, device=dev)
         assert torch.equal(back._xyz.detach(), pc._xyz.detach())
         print(f"wrote {a.out} ({os.path.getsize(a.out) / 1e6:.1f} MB) and read it back")
     return pc
