@@ -11,6 +11,12 @@ Validity: a replayed frame whose instance count exceeded the captured capacity i
 tracks the running maximum of R on the device (`max_instances()`); callers check it at their next synchronisation point
 (the reference synchronises every iteration anyway through `loss.item()`, trainers/train_static.py:112) and re-capture
 with a larger capacity if needed (`recapture()`).
+
+What is baked into the captured launches and therefore needs `recapture()` when it changes: the tensors themselves (densification
+and pruning replace them), the number of Gaussians, the image size, `pc.active_sh_degree` (the reference raises it every 1000
+iterations, scene/gaussian_model.py:176-178), the background tensor's address, `lambda_dssim`.  What does not: camera and
+ground-truth contents (copied in per call) and the learning rates (device scalars; `__call__` pushes host-side edits of
+`param_groups[i]["lr"]` -- the reference's per-iteration `update_learning_rate` -- before each replay).
 """
 import torch
 
@@ -147,6 +153,7 @@ class GraphedTrainStep:
         else:
             self.cam.load(cam)
             self.gt.copy_(gt, non_blocking=True)
+        self.opt.sync_lr()                                           # a fill per group whose learning rate was edited since the last call
         self.graph.replay()
         return self.loss
 

@@ -193,7 +193,7 @@ def test_knn_fewer_than_four_points():
 
 def test_graphed_train_step_matches_eager():
     """A hipGraph-captured training step (covariance, render, loss, backward, Adam) replayed K times leaves the parameters
-    where K eager steps leave them."""
+    where K eager steps leave them -- including a learning rate that is edited on the host between replays."""
     import math
     from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
     from egogaussian_amd.renderer import render
@@ -217,7 +217,10 @@ def test_graphed_train_step_matches_eager():
     pa = SynthGaussians(student, device=DEV)
     oa = FusedAdam(groups(pa), lr=0.0, eps=1e-15)
     seq = [0] * WARM + [k % 4 for k in range(1, K + 1)]
-    for k in seq:
+    xyz_lr = lambda it: 1.6e-4 * (0.5 ** it)                         # a schedule edited on the host every iteration, as the reference's
+    for it, k in enumerate(seq):                                     # update_learning_rate does (scene/gaussian_model.py:200-206)
+        if it >= WARM:
+            oa.param_groups[0]["lr"] = xyz_lr(it - WARM + 1)
         out = render(cams[k], pa, Pipe, bg)
         l1_ssim_loss(out["render"], gts[k], 0.2).backward()
         oa.step(); oa.zero_grad(set_to_none=True)
@@ -226,6 +229,7 @@ def test_graphed_train_step_matches_eager():
     step = GraphedTrainStep(pb, ob, bg).capture(cams[0], gts[0], warmup=WARM)
     losses = []
     for k in range(1, K + 1):
+        ob.param_groups[0]["lr"] = xyz_lr(k)                         # picked up by the replay (device scalar refreshed in __call__)
         losses.append(step(cams[k % 4], gts[k % 4]).clone())
     torch.cuda.synchronize()
     assert step.ok() and 0 < step.last_instance_count() <= step.capacity
