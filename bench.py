@@ -148,11 +148,13 @@ def main():
             frames = [pack_frame(c, g_) for c, g_ in zip(cams, gts)]      # resident: image + camera block, one copy per replay
 
             def step(i):                                        # noqa: F811
-                loss_acc.add_(graphed(frames[i % n_used]))
+                graphed(frames[i % n_used])                      # (the captured step adds its loss to graphed.loss_sum itself)
                 r_sum[1] += 1
     for i in range(args.warmup):
         step(i)
     loss_acc.zero_(); r_sum[:] = [0, 0]
+    if graphed is not None:
+        graphed.loss_sum.zero_()
     torch.cuda.synchronize()
     egs_dist.barrier()
     egs_lib.profile_begin(max_records=min(200000, 16 * (args.steps + 8)))
@@ -171,6 +173,7 @@ def main():
         # Kernels replayed from a hipGraph are not bracketed by the library's events (those are host-side records), so the
         # per-stage durations come from a second, eager timed pass over the same workload right after the replayed one.
         n_ev = min(args.steps, 50)
+        loss_acc.copy_(graphed.loss_sum)
         saved = (loss_acc.clone(), list(r_sum))
         r_sum[:] = [0, 0]
         torch.cuda.synchronize()

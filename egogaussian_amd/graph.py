@@ -76,6 +76,7 @@ class GraphedTrainStep:
         self.render_kwargs = render_kwargs or {}
         self.graph = None
         self._max_r = None
+        self.loss_sum = None
 
     def _body(self):
         out = render(self.cam, self.pc, self.pipe, self.bg, **self.render_kwargs)
@@ -85,6 +86,7 @@ class GraphedTrainStep:
             from .densify import add_densification_stats
             add_densification_stats(self.pc, out["viewspace_points"], out["visibility_filter"], radii=out["radii"])
         self.opt.step()
+        self.loss_sum.add_(loss.detach())                            # running sum for the caller's logging (no per-iteration .item())
         return loss.detach(), out
 
     def capture(self, cam, gt, warmup=3, capacity_margin=1.25):
@@ -100,6 +102,8 @@ class GraphedTrainStep:
             self.gt.copy_(gt)
             self.cam = _StaticCamera(cam, storage=self._frame[gt.numel():])
         self._one = torch.ones((), device=dev)
+        if getattr(self, "loss_sum", None) is None:
+            self.loss_sum = torch.zeros((), device=dev)                  # sum of the losses of every iteration run through this object
         P = self.pc.get_xyz.shape[0]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
