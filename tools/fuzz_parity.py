@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Randomised parity sweep: HIP path vs the C oracle on random (N, image size, colour mode, SH degree, coefficient count,
+splat size, camera) draws -- lists bit-exact with tile culling off, an ordered sub-list with it on, images and gradients
+within the test tolerances (a handful of entries may sit on the other side of an alpha threshold: the two implementations
+round alpha differently in the last place).  Complements tests/test_gpu_parity.py (fixed cases); run it for as long as you like:
+    python tools/fuzz_parity.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests.common import make_inputs, seeded_grads, rel_err, outlier_fraction, tile_culling, check_culled_lists   # noqa: E402
+from tests.test_gpu_parity import hip_forward, hip_backward, oracle_forward, TOL                                     # noqa: E402
+from egogaussian_amd import _C                                                                                       # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda:0")
+t_end, n_cases, worst = time.time() + budget, 0, {}
+while time.time() < t_end:
+    N = int(rng.choice([1, 2, 63, 64, 65, 300, 1023, 1025, 2500, 7000, 20000, 70000]))
+    H, W = int(rng.integers(1, 300)), int(rng.integers(1, 420))
+    mode = str(rng.choice(["sh_cov", "sh_sr", "col_sr", "col_cov"]))
+    deg = int(rng.integers(0, 4)) if mode.startswith("sh") else 0
+    active = int(rng.integers(0, deg + 1))
+    smul = float(rng.choice([0.5, 1.0, 2.0, 4.0, 8.0]))
+    frame = int(rng.integers(0, 300))
+    cull = bool(rng.integers(0, 2))
+    tag = f"N={N} {W}x{H} {mode} M={(deg + 1) ** 2} active={active} scale x{smul} frame {frame} culling {'on' if cull else 'off'}"
+    d = make_inputs(N, H, W, int(rng.integers(0, 1000)), deg, mode, frame=frame, scale_mul=smul, opacity_shift=float(rng.choice([0.0, 2.0, -2.0])))
+    d["sh_degree"] = active
+    o, st = oracle_forward(d)
+    with tile_culling(cull):
+        g, out = hip_forward(d, dev)
+        R, color, depth, alpha, radii, geom, binning, img = out
+        torch.cuda.synchronize()
+        assert R == st["R"], tag
+        assert np.array_equal(radii.cpu().numpy(), st["radii"]), tag
+        if R:
+            bv = _C.binning_views(binning, N, R, W, H, _C.stats["capacity"]); iv = _C.image_views(img, W, H)
+            pl = bv["point_list"].cpu().numpy().view(np.uint32); rngs = iv["ranges"].cpu().numpy().view(np.uint32)
+            if cull:
+                check_culled_lists(st, rngs, pl, H, W)
+            else:
+                assert np.array_equal(pl, st["point_list"]) and np.array_equal(rngs, st["ranges"]), tag
+        for name, hip, ora in (("colour", color, st["color"]), ("depth", depth, st["depth"]), ("alpha", alpha, st["alpha"])):
+            f = outlier_fraction(hip.cpu().numpy(), ora, TOL)
+            assert f <= max(1e-3, 8.0 / hip.numel()), f"{tag}: {name} outliers {f}"
+        grads = seeded_grads(H, W, 7)
+        hb = hip_backward(g, out, grads, dev)
+        torch.cuda.synchronize()
+    gb = o.backward(st, *grads)
+    for name, h in zip(["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot"], hb):
+        ora = gb.get(name)
+        if ora is None or h.numel() == 0:
+            continue
+        hh = h.cpu().numpy().reshape(ora.shape)
+        assert np.isfinite(hh).all() == np.isfinite(ora).all(), f"{tag}: {name} finiteness"
+        f, e = outlier_fraction(hh, ora, TOL), rel_err(hh, ora)
+        worst[name] = max(worst.get(name, 0.0), e)
+        assert f <= max(1e-3, 8.0 / hh.size) and e < 2e-2, f"{tag}: {name} outliers {f} max rel {e}"
+    n_cases += 1
+print(f"{n_cases} random cases passed in {budget:.0f} s; worst max-relative gradient errors: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
