@@ -205,12 +205,15 @@ def test_tile_culling_changes_no_output_bit(N, H, W, seed, mode, smul):
     assert np.array_equal(key_a[np.isin(key_a, key_b)], key_b)      # an ordered sub-list of the full list
 
 
-def test_4k_image_32400_tiles():
+@pytest.mark.parametrize("H,W", [(2160, 3840), (2304, 4096)], ids=["32400-tiles", "36864-tiles"])
+def test_4k_image_tile_counters_fill_the_lds(H, W):
     """3840x2160 = 32400 tiles: the per-tile counters of the bucketing kernels take 127 KiB of the 160 KiB LDS (one
-    workgroup per CU).  Lists and image vs the oracle, with the reference's rectangles and with tile culling."""
+    workgroup per CU) and a bucketing round stages 8 groups of 64 Gaussians instead of 16; 4096x2304 = 36864 tiles is the
+    largest image the ABI accepts (144 KiB of counters, 4 groups per round).  Lists and image vs the oracle, with the
+    reference's rectangles and with tile culling."""
     from egogaussian_amd import _C
     dev = _dev()
-    N, H, W = 3000, 2160, 3840
+    N = 3000
     d = make_inputs(N, H, W, 11, 0, "sh_cov", scale_mul=6.0)
     o, st = oracle_forward(d)
     for cull in (False, True):
