@@ -26,12 +26,21 @@ while time.time() < t_end:
     smul = float(rng.choice([0.5, 1.0, 2.0, 4.0, 8.0]))
     frame = int(rng.integers(0, 300))
     cull = bool(rng.integers(0, 2))
-    tag = f"N={N} {W}x{H} {mode} M={(deg + 1) ** 2} active={active} scale x{smul} frame {frame} culling {'on' if cull else 'off'}"
+    split = bool(rng.integers(0, 2)) and deg > 0                      # hand the coefficients over as (dc, rest)
+    tag = f"N={N} {W}x{H} {mode} M={(deg + 1) ** 2} active={active} scale x{smul} frame {frame} culling {'on' if cull else 'off'}{' split-SH' if split else ''}"
     d = make_inputs(N, H, W, int(rng.integers(0, 1000)), deg, mode, frame=frame, scale_mul=smul, opacity_shift=float(rng.choice([0.0, 2.0, -2.0])))
     d["sh_degree"] = active
     o, st = oracle_forward(d)
     with tile_culling(cull):
-        g, out = hip_forward(d, dev)
+        if split:
+            g = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+            e0 = torch.empty(0, device=dev)
+            dc, rest = g["shs"][:, :1].contiguous(), g["shs"][:, 1:].contiguous()
+            out = _C.rasterize_gaussians(g["bg"], g["means3D"], e0, g["opacities"], g.get("scales", e0), g.get("rotations", e0), 1.0,
+                                         g.get("cov3D_precomp", e0), g["viewmatrix"], g["projmatrix"], g["tanfovx"], g["tanfovy"], H, W, dc, active,
+                                         g["campos"], False, False, 0, rest)
+        else:
+            g, out = hip_forward(d, dev)
         R, color, depth, alpha, radii, geom, binning, img = out
         torch.cuda.synchronize()
         assert R == st["R"], tag
@@ -47,7 +56,14 @@ while time.time() < t_end:
             f = outlier_fraction(hip.cpu().numpy(), ora, TOL)
             assert f <= max(1e-3, 8.0 / hip.numel()), f"{tag}: {name} outliers {f}"
         grads = seeded_grads(H, W, 7)
-        hb = hip_backward(g, out, grads, dev)
+        if split:
+            gc, gd, ga = [x.to(dev) for x in grads]
+            full = _C.rasterize_gaussians_backward(g["bg"], g["means3D"], radii, e0, g.get("scales", e0), g.get("rotations", e0), 1.0,
+                                                   g.get("cov3D_precomp", e0), g["viewmatrix"], g["projmatrix"], g["tanfovx"], g["tanfovy"], gc, gd, ga,
+                                                   dc, active, g["campos"], geom, R, binning, img, alpha, False, 0, rest)
+            hb = list(full[:8]); hb[5] = torch.cat((full[5], full[8]), dim=1)
+        else:
+            hb = hip_backward(g, out, grads, dev)
         torch.cuda.synchronize()
     gb = o.backward(st, *grads)
     for name, h in zip(["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot"], hb):
