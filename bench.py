@@ -5,9 +5,12 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
 
 Workload (config C of BASELINE.md): synthetic scene S(500k Gaussians, 540, 960, seed 0), the 300-frame synthetic
-orbit, SH degree 0, cov3D built in PyTorch (the reference forces compute_cov3D_python, /root/reference/train.py:49).
+orbit, SH degree 0 (`--sh-degree 3` for the 16-coefficient colour model the reference ends training with; the default
+single-GPU run measures that too, in a child process, and reports it as `sh_degree_3`).
 One step = one full training iteration of /root/reference/trainers/train_static.py:67-138 without densification or
-logging: get_covariance -> render() forward (HIP) -> 0.8 L1 + 0.2 (1 - SSIM) -> backward (HIP + autograd) -> Adam.
+logging: covariance (the reference forces compute_cov3D_python, /root/reference/train.py:49; here built inside the
+rasterizer's preprocess kernel from the raw parameters) -> render() forward (HIP) -> 0.8 L1 + 0.2 (1 - SSIM) ->
+backward (HIP + autograd) -> Adam; replayed from one hipGraph per step (`--no-graph`: launched eagerly).
 Frames are sharded round-robin over ranks (1 frame per GPU per step); ranks exchange only
 scalars (loss / PSNR sums) through one RCCL all-reduce; `value` = steps of all ranks / max-over-ranks time.
 
@@ -15,8 +18,8 @@ The JSON line also carries
   roofline      the dominant rasterizer stage: algorithmic bytes per launch / its mean duration, measured with HIP
                 events recorded by the library on the launch stream inside the timed region;
   stages        the same for every stage (ms per launch, GB/s algorithmic);
-  cpu_baseline  the C oracle (oracle/raster_oracle.c, "port") timed on this box's host cores on one forward+backward
-                of the same workload (rank 0, N = 1 only).
+  cpu_baseline  the C oracle (oracle/raster_oracle.c, "port") timed on this box's host cores on a bounded sample of
+                forward+backward passes of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import json
