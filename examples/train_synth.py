@@ -36,6 +36,8 @@ def main(argv=None):
     ap.add_argument("--grad-threshold", type=float, default=2e-4)
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--sh-degree", type=int, default=0, help="spherical-harmonics degree of the colour model (0..3)")
+    ap.add_argument("--sh-up-interval", type=int, default=0,
+                    help="start at active degree 0 and raise it every this many iterations (the reference: 1000, scene/gaussian_model.py:176-178)")
     ap.add_argument("--out", default="")
     a = ap.parse_args(argv)
     dev = torch.device("cuda", 0)
@@ -50,6 +52,8 @@ def main(argv=None):
         gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
     pc = SynthGaussians(perturb_student(teacher), device=dev, sh_degree=a.sh_degree)
     pc.training_setup(capturable=True)
+    if a.sh_up_interval > 0:
+        pc.active_sh_degree = 0
     extent = 10.0
 
     def quality():
@@ -63,6 +67,11 @@ def main(argv=None):
         k = it % a.frames
         step(cams[k], gts[k])                                        # render, loss, backward, statistics, Adam: one graph launch
         it += 1
+        if a.sh_up_interval > 0 and it % a.sh_up_interval == 0 and pc.active_sh_degree < pc.max_sh_degree:
+            pc.active_sh_degree += 1                                 # oneupSHdegree: a launch argument of the captured kernels -> re-capture
+            step.recapture(warmup=1)
+            it += 1
+            print(f"iter {it}: active SH degree {pc.active_sh_degree}")
         if it <= a.densify_until and it > a.densify_from and it % a.densify_interval == 0:
             assert step.ok(), "a replayed frame outgrew the captured capacity"      # (reads a device word: synchronises)
             size_threshold = 20 if it > a.opacity_reset_interval else None
