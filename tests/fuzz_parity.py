@@ -3,7 +3,8 @@
 splat size, camera) draws -- lists bit-exact with tile culling off, an ordered sub-list with it on, images and gradients
 within the test tolerances (a handful of entries may sit on the other side of an alpha threshold: the two implementations
 round alpha differently in the last place).  Complements tests/test_gpu_parity.py (fixed cases); run it for as long as you like:
-    python tools/fuzz_parity.py [seconds] [seed]"""
+    python tests/fuzz_parity.py [seconds] [seed]
+(lives under tests/ because it uses the oracle, which is test infrastructure; pytest does not collect it)"""
 import os, sys, time
 import numpy as np
 import torch
