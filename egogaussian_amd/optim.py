@@ -97,7 +97,10 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 if "step" not in st:
                     st["step"] = torch.zeros((), dtype=torch.float32)
-                st["step"] = st["step"] + 1 if torch.is_tensor(st["step"]) else st["step"] + 1
+                if torch.is_tensor(st["step"]):
+                    st["step"] += 1                                   # in place: no new host tensor per parameter and step
+                else:
+                    st["step"] = st["step"] + 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if not (p.is_contiguous() and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
                     raise RuntimeError("FusedAdam: parameters and optimizer state must be contiguous")
