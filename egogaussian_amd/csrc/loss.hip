@@ -195,14 +195,42 @@ __device__ __forceinline__ void bwd_step(BwdCtx& c, Window<3>& w, int y_in, floa
     }
 }
 
+// The scalar loss from the per-strip partial sums, by ONE wave (fixed order, so the value is deterministic): used by the backward kernel when the caller deferred
+// the loss value to it (egs_l1_ssim_forward with loss == NULL) -- a training step replayed from a graph reads the value only after
+// the backward anyway, and every launch it does not make is ~4.5 us of GPU time.
+__device__ __forceinline__ void wave_finish_loss(size_t nblocks, const float* __restrict__ partial, float w_l1, float w_ssim, float lambda,
+                                                 float* __restrict__ loss, float* __restrict__ running_sum, unsigned lane) {
+    float a = 0.f, b = 0.f;
+    for (size_t i0 = 0; i0 < nblocks; i0 += 64 * 8) {                  // eight loads in flight per lane
+        float2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const size_t i = i0 + (size_t)k * 64 + lane; v[k] = i < nblocks ? reinterpret_cast<const float2*>(partial)[i] : make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a += v[k].x; b += v[k].y; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    if (lane == 0) {
+        const float v = w_l1 * a + lambda - w_ssim * b;
+        if (loss) loss[0] = v;
+        if (running_sum) running_sum[0] += v;
+    }
+}
+
 __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_backward(int H, int W, int strips_x, int strips_y, const float* __restrict__ img,
                                                                 const float* __restrict__ gt, float w_l1, float w_ssim,
                                                                 const float* __restrict__ upstream, const float* __restrict__ gate,
                                                                 const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dexx,
-                                                                const float* __restrict__ dm_dexy, float* __restrict__ dimg) {
+                                                                const float* __restrict__ dm_dexy, float* __restrict__ dimg,
+                                                                const float* __restrict__ fin_partial, size_t fin_n, float fin_lambda,
+                                                                float* __restrict__ fin_loss, float* __restrict__ fin_running) {
     __shared__ float lds[WPB][3 * 80];
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int strip = blockIdx.x * WPB + (int)wv;
+    if (fin_partial && blockIdx.x == gridDim.x - 1) {                  // deferred loss value: one extra workgroup per channel plane, no strip
+        if (blockIdx.z == 0 && wv == 0) wave_finish_loss(fin_n, fin_partial, w_l1, w_ssim, fin_lambda, fin_loss, fin_running, lane);
+        return;                                                        // (every resident wave ends with the kernel: a wave with a strip has no slack)
+    }
     if (strip >= strips_x * strips_y) return;
     for (int k = lane; k < 3 * 80; k += 64) lds[wv][k] = 0.f;
     __builtin_amdgcn_wave_barrier();
@@ -246,7 +274,7 @@ __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_backward(int H, int W, int
 
 // Adds up the per-block partial sums and assembles the scalar loss (one workgroup; deterministic order).
 __global__ __launch_bounds__(1024) void k_l1_ssim_finish(size_t nblocks, const float* __restrict__ partial, float w_l1, float w_ssim,
-                                                          float lambda, float* __restrict__ loss) {
+                                                          float lambda, float* __restrict__ loss, float* __restrict__ running_sum) {
     __shared__ float red[2][16];
     float a = 0.f, b = 0.f;
     for (size_t i = threadIdx.x; i < nblocks; i += 1024) { const float2 v = reinterpret_cast<const float2*>(partial)[i]; a += v.x; b += v.y; }
@@ -257,7 +285,9 @@ __global__ __launch_bounds__(1024) void k_l1_ssim_finish(size_t nblocks, const f
     if (threadIdx.x == 0) {
         float ta = 0.f, tb = 0.f;
         for (int k = 0; k < 16; k++) { ta += red[0][k]; tb += red[1][k]; }
-        loss[0] = w_l1 * ta + lambda - w_ssim * tb;                           // (1-l) mean|x-y| + l (1 - mean SSIM)
+        const float v = w_l1 * ta + lambda - w_ssim * tb;                     // (1-l) mean|x-y| + l (1 - mean SSIM)
+        loss[0] = v;
+        if (running_sum) running_sum[0] += v;
     }
 }
 
@@ -270,29 +300,34 @@ size_t egs_l1_ssim_partial_count(int channels, int height, int width) {
 }
 
 int egs_l1_ssim_forward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
-                        float* partial_sums, float* dm_dmu1, float* dm_dexx, float* dm_dexy, float* loss, void* stream) {
-    if (channels <= 0 || height <= 0 || width <= 0 || !img || !gt || !partial_sums || !dm_dmu1 || !dm_dexx || !dm_dexy || !loss)
+                        float* partial_sums, float* dm_dmu1, float* dm_dexx, float* dm_dexy, float* loss, float* loss_running_sum,
+                        void* stream) {
+    if (channels <= 0 || height <= 0 || width <= 0 || !img || !gt || !partial_sums || !dm_dmu1 || !dm_dexx || !dm_dexy)
         return EGS_ERR_ARG;
     const int strips_x = (width + SW - 1) / SW, strips_y = (height + SR - 1) / SR;
     dim3 grid((strips_x * strips_y + WPB - 1) / WPB, 1, channels);
     hipLaunchKernelGGL(k_l1_ssim_forward, grid, dim3(64 * WPB), 0, (hipStream_t)stream, height, width, strips_x, strips_y, img, gt,
                        partial_sums, dm_dmu1, dm_dexx, dm_dexy);
     const float n = (float)channels * (float)height * (float)width;
-    hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, (size_t)strips_x * strips_y * channels, partial_sums,
-                       (1.f - lambda_dssim) / n, lambda_dssim / n, lambda_dssim, loss);
+    if (loss)                                       // loss == NULL: the value is assembled by egs_l1_ssim_backward (deferred)
+        hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, (size_t)strips_x * strips_y * channels, partial_sums,
+                           (1.f - lambda_dssim) / n, lambda_dssim / n, lambda_dssim, loss, loss_running_sum);
     return (int)hipGetLastError();
 }
 
 int egs_l1_ssim_backward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
                          const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
-                         const float* dm_dexy, float* dL_dimg, void* stream) {
+                         const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
+                         float* loss_running_sum, void* stream) {
     if (channels <= 0 || height <= 0 || width <= 0 || !img || !gt || !upstream_grad || !dm_dmu1 || !dm_dexx || !dm_dexy || !dL_dimg)
         return EGS_ERR_ARG;
     const float n = (float)channels * (float)height * (float)width;
     const int strips_x = (width + SW - 1) / SW, strips_y = (height + SR - 1) / SR;
-    dim3 grid((strips_x * strips_y + WPB - 1) / WPB, 1, channels);
+    dim3 grid((strips_x * strips_y + WPB - 1) / WPB + (deferred_partial_sums ? 1 : 0), 1, channels);
     hipLaunchKernelGGL(k_l1_ssim_backward, grid, dim3(64 * WPB), 0, (hipStream_t)stream, height, width, strips_x, strips_y, img, gt,
-                       (1.f - lambda_dssim) / n, lambda_dssim / n, upstream_grad, gate, dm_dmu1, dm_dexx, dm_dexy, dL_dimg);
+                       (1.f - lambda_dssim) / n, lambda_dssim / n, upstream_grad, gate, dm_dmu1, dm_dexx, dm_dexy, dL_dimg,
+                       deferred_partial_sums, (size_t)strips_x * strips_y * channels, lambda_dssim, deferred_loss,
+                       deferred_partial_sums ? loss_running_sum : nullptr);
     return (int)hipGetLastError();
 }
 

@@ -123,7 +123,7 @@ def rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation
 
 class _L1SSIM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, gt, lambda_dssim, gate):
+    def forward(ctx, img, gt, lambda_dssim, gate, running_sum=None, defer_value=False):
         L = _lib.load()
         img, gt = _need_hip(img, "image"), _need_hip(gt, "gt")
         assert img.dim() == 3 and img.shape == gt.shape
@@ -134,9 +134,10 @@ class _L1SSIM(torch.autograd.Function):
         loss = torch.empty((), device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.egs_l1_ssim_forward(Cc, H, W, _p(img), _p(gt), float(lambda_dssim), _p(partial), _p(maps[0]), _p(maps[1]),
-                                             _p(maps[2]), _p(loss), _stream()))
+                                             _p(maps[2]), None if defer_value else _p(loss), None if defer_value else _p(running_sum), _stream()))
         ctx.save_for_backward(img, gt, maps, gate if gate is not None else torch.empty(0))
         ctx.lam, ctx.has_gate = float(lambda_dssim), gate is not None
+        ctx.deferred = (partial, loss, running_sum) if defer_value else None
         return loss
 
     @staticmethod
@@ -150,12 +151,19 @@ class _L1SSIM(torch.autograd.Function):
             g = g.float().contiguous()
         dimg = torch.empty_like(img)
         with torch.cuda.device(img.device):
+            d = ctx.deferred
             _lib.check(L.egs_l1_ssim_backward(Cc, H, W, _p(img), _p(gt), ctx.lam, _p(g), _p(gate), _p(maps[0]), _p(maps[1]),
-                                              _p(maps[2]), _p(dimg), _stream()))
-        return dimg, None, None, None
+                                              _p(maps[2]), _p(dimg), _p(d[0]) if d else None, _p(d[1]) if d else None,
+                                              _p(d[2]) if d else None, _stream()))
+        return dimg, None, None, None, None, None
 
 
-def l1_ssim_loss(image, gt, lambda_dssim=0.2, grad_gate=None):
+def l1_ssim_loss(image, gt, lambda_dssim=0.2, grad_gate=None, running_sum=None, defer_value=False):
     """(1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)).  `grad_gate` [H,W] multiplies d loss / d image
-    per pixel (the reference's `render_image.register_hook(lambda grad: grad * (1 - hand_mask))`)."""
-    return _L1SSIM.apply(image, gt, lambda_dssim, grad_gate)
+    per pixel (the reference's `render_image.register_hook(lambda grad: grad * (1 - hand_mask))`).
+    running_sum: optional device scalar the loss value is also added to (logging without a launch or a host read per iteration).
+    defer_value=True: the returned tensor receives its value during backward() instead of right away -- one launch less per
+    iteration, for steps whose loss is only read after the backward (graph.GraphedTrainStep)."""
+    if running_sum is not None:
+        running_sum = _need_hip(running_sum, "running_sum")
+    return _L1SSIM.apply(image, gt, lambda_dssim, grad_gate, running_sum, defer_value)

@@ -80,13 +80,13 @@ class GraphedTrainStep:
 
     def _body(self):
         out = render(self.cam, self.pc, self.pipe, self.bg, **self.render_kwargs)
-        loss = l1_ssim_loss(out["render"], self.gt, self.lam)
+        # the loss value and the running sum are produced by the loss BACKWARD kernel (nothing reads them before): two launches less
+        loss = l1_ssim_loss(out["render"], self.gt, self.lam, running_sum=self.loss_sum, defer_value=True)
         loss.backward(gradient=self._one)                            # a resident 1.0: no fill kernel per iteration
         if self.densify_stats:
             from .densify import add_densification_stats
             add_densification_stats(self.pc, out["viewspace_points"], out["visibility_filter"], radii=out["radii"])
         self.opt.step()
-        self.loss_sum.add_(loss.detach())                            # running sum for the caller's logging (no per-iteration .item())
         return loss.detach(), out
 
     def capture(self, cam, gt, warmup=3, capacity_margin=1.25):

@@ -54,8 +54,8 @@ SIGNATURES = {
     "egs_cov3d_dm_scratch_floats": (C.c_size_t, [i32]),
     "egs_cov3d_backward": (C.c_int, [i32, vp, i32, f32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "egs_l1_ssim_partial_count": (C.c_size_t, [i32, i32, i32]),
-    "egs_l1_ssim_forward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
-    "egs_l1_ssim_backward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "egs_l1_ssim_forward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "egs_l1_ssim_backward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "egs_adam_step": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
     "egs_adam_workgroups": (C.c_int64, [i64]),
     "egs_adam_step_capturable": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),

@@ -243,3 +243,23 @@ def test_graphed_train_step_matches_eager():
             scale = float(a.detach().abs().max())
             assert float((diff > 2e-5 * scale + 1e-6).float().mean()) < 2e-3, "graph-replayed parameters drifted from the eager ones"
             assert float(diff.max()) < 0.02, "graph-replayed parameters drifted from the eager ones"
+
+
+def test_l1_ssim_deferred_value_and_running_sum():
+    """defer_value=True moves the assembly of the scalar into the backward kernel (one launch less in a replayed training step):
+    same value, same gradient; running_sum receives the value exactly once per loss, in either mode."""
+    from egogaussian_amd.fused import l1_ssim_loss
+    g = torch.Generator().manual_seed(5)
+    img0, gt = torch.rand(3, 71, 129, generator=g).to(DEV), torch.rand(3, 71, 129, generator=g).to(DEV)
+    res = []
+    for defer in (False, True):
+        img = img0.clone().requires_grad_(True)
+        acc = torch.full((), 10.0, device=DEV)
+        loss = l1_ssim_loss(img, gt, 0.2, running_sum=acc, defer_value=defer)
+        if not defer:
+            assert abs(float(acc) - 10.0 - float(loss.detach())) < 1e-6        # available (and summed) right after the forward
+        loss.backward()
+        res.append((float(loss.detach()), float(acc), img.grad.clone()))
+    (l0, a0, g0), (l1, a1, g1) = res
+    assert abs(l0 - l1) < 1e-6 * max(1.0, abs(l0)) and abs(a0 - a1) < 1e-5 and abs(a1 - 10.0 - l1) < 1e-5
+    assert torch.equal(g0, g1)

@@ -19,3 +19,9 @@ wall = rows[-1][2] - rows[0][1]
 print(f"{steps} steps; per step: wall {wall / steps / 1e3:.1f} us, kernels busy {busy / steps / 1e3:.1f} us, idle {(wall - busy) / steps / 1e3:.1f} us")
 for n, g in sorted(gap_by.items(), key=lambda kv: -kv[1])[:12]:
     print(f"  GPU idle before {n:46s} {g / steps / 1e3:7.1f} us / step")
+per = collections.defaultdict(lambda: [0.0, 0])
+for n, s0, e0 in rows:
+    per[short(n)][0] += e0 - s0; per[short(n)][1] += 1
+print("kernel time per step (us):")
+for n, (t, k) in sorted(per.items(), key=lambda kv: -kv[1][0])[:24]:
+    print(f"  {n:46s} {t / steps / 1e3:7.1f}   ({k / steps:.1f} launches / step, {t / k / 1e3:.1f} us each)")
