@@ -53,8 +53,9 @@ __device__ __forceinline__ float row_sum(float v) {
 // Work-aware placement of tiles for the backward blend.  All workgroups of that launch are resident at once (8 per CU),
 // so its duration is the busiest CU's total; with tiles dealt in index order the busiest CU carries 1.2-1.3x the mean.
 // Workgroup b runs on XCD b % 8 and, inside the XCD, on CU (b / 8) % 32 (tools/ubench/dispatch_map.hip; used for speed
-// only -- any placement gives the same results).  One workgroup per XCD band ranks the band's tiles by the replay depth
-// the forward recorded and deals them to the 32 CUs in snake order (rank r -> round r/32, CU r%32 or 31 - r%32).
+// only -- any placement gives the same results).  One workgroup per XCD band ranks the band's tiles by the cost the forward
+// recorded -- a counting sort over 1024 cost levels, O(tiles): the exact O(tiles^2) rank it replaces took 45 us at 1920x1080 --
+// and deals them to the 32 CUs in snake order (rank r -> round r/32, CU r%32 or 31 - r%32).
 // The same launch clears the gradient accumulator (workgroups 8..): two short kernels cost more than one.
 // Tried and rejected (round 1, config C, per-wave timelines from tools/lane_use.py): (a) persistent waves pulling
 // (tile, quadrant) tasks, sorted by cost, from one queue per XCD: perfectly balanced and 2.2x slower -- the four waves
@@ -63,7 +64,8 @@ __device__ __forceinline__ float row_sum(float v) {
 // CU-level spread (-12%/+8% of blended splats) then bounds the launch and the longer prologue cancels the 2 us gained.
 // (c) running this prologue on a second stream right after the forward, so that it overlaps the loss kernels (fork / join
 // captured into the hipGraph): the step got 3 % SLOWER -- the graph's cross-stream dependencies cost more than the 11 us hidden.
-#define ORDER_MAX_BAND 2048
+#define ORDER_MAX_BAND 8192
+#define ORDER_LEVELS 1024
 __global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const uint32_t* __restrict__ quad_work,
                                                              uint32_t* __restrict__ tile_order, float4* __restrict__ acc4, size_t n4) {
     if (blockIdx.x >= EGS_XCDS) {
@@ -71,7 +73,10 @@ __global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const u
         for (size_t i = (size_t)(blockIdx.x - EGS_XCDS) * 1024 + threadIdx.x; i < n4; i += stride) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
-    __shared__ __attribute__((aligned(16))) uint32_t work[ORDER_MAX_BAND];
+    // Order of one band: a counting sort on the cost quantised to ORDER_LEVELS levels (descending).  Ties land in arrival order --
+    // the order only decides which workgroup blends which tile, never a result.
+    __shared__ uint32_t work[ORDER_MAX_BAND];
+    __shared__ uint32_t level_base[ORDER_LEVELS], level_fill[ORDER_LEVELS], wsum[16], wmax_s;
     const int per = egs_tiles_per_xcd(n_tiles), x = blockIdx.x;
     const int t0 = x * per, n = max(0, min(per, n_tiles - t0));
     const int slots = ((per + 31) / 32) * 32;
@@ -79,24 +84,43 @@ __global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const u
         for (int sl = threadIdx.x; sl < per; sl += blockDim.x) tile_order[8 * sl + x] = sl < n ? (uint32_t)(t0 + sl) : 0xffffffffu;
         return;
     }
-    const int n_pad = (n + 3) & ~3;
-    for (int i = threadIdx.x; i < n_pad; i += blockDim.x) {
-        uint32_t wsum = 0;                                           // padding entries never outrank a real one
-        if (i < n) { const uint4 w4 = *reinterpret_cast<const uint4*>(quad_work + 4 * (size_t)(t0 + i)); wsum = w4.x + w4.y + w4.z + w4.w; }
-        work[i] = wsum;
+    if (threadIdx.x == 0) wmax_s = 1u;
+    level_fill[threadIdx.x] = 0u;                                    // (ORDER_LEVELS == blockDim.x)
+    __syncthreads();
+    uint32_t mx = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint4 w4 = *reinterpret_cast<const uint4*>(quad_work + 4 * (size_t)(t0 + i));
+        const uint32_t wsum_i = w4.x + w4.y + w4.z + w4.w;
+        work[i] = wsum_i; mx = max(mx, wsum_i);
     }
     for (int sl = threadIdx.x; sl < per; sl += blockDim.x) tile_order[8 * sl + x] = 0xffffffffu;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&wmax_s, mx);
+    __syncthreads();
+    const float to_level = (float)(ORDER_LEVELS - 1) / (float)wmax_s;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t lv = (uint32_t)(ORDER_LEVELS - 1) - min((uint32_t)((float)work[i] * to_level), (uint32_t)(ORDER_LEVELS - 1));
+        work[i] = lv;                                                // 0 = most expensive
+        atomicAdd(&level_fill[lv], 1u);
+    }
+    __syncthreads();
+    {   // exclusive scan of the level counts (one level per thread)
+        const uint32_t c = level_fill[threadIdx.x];
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)(threadIdx.x & 63) >= d) incl += o; }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t base = incl - c;
+        for (unsigned k = 0; k < (threadIdx.x >> 6); k++) base += wsum[k];
+        level_base[threadIdx.x] = base;
+        level_fill[threadIdx.x] = 0u;
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t wi = work[i];
-        int rank = 0;
-        for (int j = 0; j < n_pad; j += 4) {
-            const uint4 wj = *reinterpret_cast<const uint4*>(work + j);
-            rank += (wj.x > wi) || (wj.x == wi && j < i);
-            rank += (wj.y > wi) || (wj.y == wi && j + 1 < i);
-            rank += (wj.z > wi) || (wj.z == wi && j + 2 < i);
-            rank += (wj.w > wi) || (wj.w == wi && j + 3 < i);
-        }
+        const uint32_t lv = work[i];
+        const int rank = (int)(level_base[lv] + atomicAdd(&level_fill[lv], 1u));
         const int round = rank / 32, pos = rank % 32;
         int slot = round * 32 + ((round & 1) ? 31 - pos : pos);
         if (slot >= per) slot = round * 32 + pos;                    // last, partial round: no room to mirror
