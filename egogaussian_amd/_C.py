@@ -252,7 +252,7 @@ def binning_views(binning, P, R, W, H, capacity=None):
     nt = ((W + 15) // 16) * ((H + 15) // 16)
     return dict(point_list=binning[lay.point_list:lay.point_list + R * 4].view(torch.int32),
                 pairs=binning[lay.pairs:lay.pairs + R * 8].view(torch.int64),
-                table=binning[lay.table:lay.table + nt * lay.bin_blocks * 4].view(torch.int32).view(nt, lay.bin_blocks) if R else None,
+                table=binning[lay.table:lay.table + nt * lay.table_stride * 4].view(torch.int32).view(nt, lay.table_stride)[:, :lay.bin_blocks] if R else None,
                 key_bits=lay.key_bits, index_passes=lay.index_passes, bin_blocks=lay.bin_blocks)
 
 

@@ -26,17 +26,19 @@ GeomLayout geom_layout(int P) {
 BinLayout bin_layout(int P, int64_t R, int W, int H) {
     BinLayout L; size_t off = 0; const size_t n = (size_t)(R > 0 ? R : 0);
     const size_t gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
-    const size_t nblocks = egs_bin_blocks(P > 0 ? P : 0), tab = gx * gy * nblocks;
+    const size_t nblocks = egs_bin_blocks(P > 0 ? P : 0), stride = egs_table_stride((uint32_t)nblocks), tab = gx * gy * stride;
+    const size_t sums = EGS_BIN_GROUPS * egs_table_chunks(gx * gy, (uint32_t)stride);
     L.o.key_bits = egs_key_bits_for_tiles((int)(gx * gy));
     L.o.bin_blocks = (int)nblocks;
+    L.o.table_stride = (int)stride;
     int ib = 0; while (P > 1 && (((unsigned)(P - 1)) >> ib) != 0) ib++;
     L.o.index_passes = (ib + 8) / 9;
     L.o.point_list = off; off = egs_align(off + n * sizeof(uint32_t));          // first: the backward needs nothing else
     L.o.pairs = off;      off = egs_align(off + n * sizeof(uint64_t));
     L.o.scratch = off;    off = egs_align(off + n * sizeof(uint64_t));
     L.o.table = off;      off = egs_align(off + (n ? tab : 0) * sizeof(uint32_t));
-    L.o.spine = off;      off = egs_align(off + (n ? egs_scan_scratch_elems(tab) + 64 : 0) * sizeof(uint32_t));
-    L.o.total = L.o.spine + (egs_scan_scratch_elems(tab) + 32) * sizeof(uint32_t);
+    L.o.spine = off;      off = egs_align(off + (n ? sums + 64 + 4 : 0) * sizeof(uint32_t));
+    L.o.total = L.o.spine + ((sums + 32 + 1) & ~(size_t)1) * sizeof(uint32_t);
     L.bytes = off; return L;
 }
 ImgLayout img_layout(int W, int H) {
@@ -58,8 +60,9 @@ EgsGeomPtrs geom_ptrs(void* buf, int P) {
 EgsBinPtrs bin_ptrs(void* buf, int P, int64_t R, int W, int H) {
     const BinLayout L = bin_layout(P, R, W, H); char* b = (char*)buf; EgsBinPtrs p;
     p.pairs = (uint64_t*)(b + L.o.pairs); p.scratch = (uint64_t*)(b + L.o.scratch);
-    p.point_list = (uint32_t*)(b + L.o.point_list); p.table = (uint32_t*)(b + L.o.table); p.spine = (uint32_t*)(b + L.o.spine);
+    p.point_list = (uint32_t*)(b + L.o.point_list); p.table = (uint32_t*)(b + L.o.table); p.chunk_sum = (uint32_t*)(b + L.o.spine);
     p.total = (uint64_t*)(b + L.o.total);
+    p.flag = (uint32_t*)p.total - 32;                                 // (the 32 words before `total`)
     return p;
 }
 EgsImgPtrs img_ptrs(void* buf, int W, int H) {
@@ -206,7 +209,7 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
     egs_prof_start(EGS_K_PREPROCESS, s);
     const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);         // rows of 12 M bytes: the wave-tiled kernel (preprocess.hip)
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
-                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, s));
+                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, nullptr, 0, s));
     if (sh_apart) EGS_TRY(egs_launch_sh_forward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     EGS_SYNC_IF_DEBUG(s);
@@ -254,17 +257,26 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
     egs_prof_start(EGS_K_PREPROCESS, s);
     const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);         // rows of 12 M bytes: the wave-tiled kernel (preprocess.hip)
+    // the speculative bucketing that follows needs its chunk sums cleared: the preprocess launch does that on the side (a launch of
+    // its own costs ~4.5 us of GPU time whatever it does)
+    EgsBinPtrs b_spec = {};
+    size_t n_sums = 0;
+    if (capacity > 0) {
+        b_spec = bin_ptrs(binning_buffer, P, capacity, width, height);
+        const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
+        n_sums = EGS_BIN_GROUPS * egs_table_chunks(nt, egs_table_stride(egs_bin_blocks(P)));
+    }
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
-                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, s));
+                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, capacity > 0 ? b_spec.chunk_sum : nullptr, n_sums, s));
     if (sh_apart) EGS_TRY(egs_launch_sh_forward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     const size_t nb = ((size_t)P + 255) / 256;
     if (pinned_host_counts) EGS_TRY(hipMemcpyAsync(pinned_host_counts, g.scan_scratch, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (wait_for_count) EGS_TRY(hipEventRecord(ev, s));
     if (capacity > 0) {                                              // speculative: sized by the caller's guess
-        EgsBinPtrs b = bin_ptrs(binning_buffer, P, capacity, width, height);
+        EgsBinPtrs b = b_spec;
         EgsImgPtrs im = img_ptrs(image_buffer, width, height);
-        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, s, 0));
+        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, 1, s, 0));
         egs_prof_start(EGS_K_RENDER_FWD, s);
         EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, s));
         egs_prof_stop(EGS_K_RENDER_FWD, s);
@@ -330,7 +342,7 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
     EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
     EgsBinPtrs b = bin_ptrs(binning_buffer, P, R, width, height);
     EgsImgPtrs im = img_ptrs(image_buffer, width, height);
-    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, nullptr, s, debug));
+    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, nullptr, 0, s, debug));
     const uint32_t* point_list = b.point_list;
     egs_prof_start(EGS_K_RENDER_FWD, s);
     EGS_TRY(egs_launch_render_forward(width, height, background, g, point_list, im, out_color, out_depth, out_alpha, s));

@@ -137,6 +137,36 @@ __global__ __launch_bounds__(EGS_SCAN_THREADS) void k_scan_apply_sum(const uint3
     if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == EGS_SCAN_THREADS - 1) *total = run;
 }
 
+// Exclusive scan, in place, of the bucketing's count table [n_tiles][stride] (columns >= nblocks hold nothing and count as zero):
+// one kernel, because the sums of the 2048-entry chunks arrive with the table -- k_bin_count accumulated them (EGS_BIN_GROUPS partial
+// accumulators per chunk).  Workgroup i adds up the chunks before it and scans its own.
+__global__ __launch_bounds__(EGS_SCAN_THREADS) void k_table_scan(uint32_t* __restrict__ table, size_t n, uint32_t stride, uint32_t nblocks,
+                                                                  const uint32_t* __restrict__ chunk_sum, uint32_t n_chunks,
+                                                                  uint64_t* __restrict__ total) {
+    __shared__ uint32_t lds4[4];
+    uint32_t before = 0;
+    for (unsigned k = threadIdx.x; k < blockIdx.x; k += EGS_SCAN_THREADS) {
+#pragma unroll
+        for (unsigned g = 0; g < EGS_BIN_GROUPS; g++) before += chunk_sum[(size_t)g * n_chunks + k];
+    }
+    const size_t base = (size_t)blockIdx.x * EGS_SCAN_EPB + (size_t)threadIdx.x * EGS_SCAN_ITEMS;
+    uint32_t v[EGS_SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < EGS_SCAN_ITEMS; k++) {
+        const size_t e = base + k;
+        v[k] = (e < n && (uint32_t)(e & (stride - 1)) < nblocks) ? table[e] : 0u;
+        s += v[k];
+    }
+    uint32_t carry; block_excl_scan(before, lds4, &carry);
+    uint32_t tot; uint32_t run = block_excl_scan(s, lds4, &tot) + carry;
+#pragma unroll
+    for (int k = 0; k < EGS_SCAN_ITEMS; k++) {
+        const uint32_t ex = run; run += v[k];
+        if (base + k < n) table[base + k] = ex;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == EGS_SCAN_THREADS - 1) *total = run;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tile bucketing.  The Gaussians are cut into groups of 64 consecutive ones; group j belongs to workgroup j % nblocks, so a
 // run of heavy groups (the clones and splits densification appends at the end of the arrays are all on screen and close to
@@ -247,7 +277,7 @@ extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
 __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, int gpr, const uint32_t* __restrict__ tiles_touched,
                                                     const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
                                                     int n_tiles, uint32_t nblocks, int cull, int W, int H,
-                                                    uint32_t* __restrict__ table) {
+                                                    uint32_t* __restrict__ table, uint32_t stride, uint32_t* __restrict__ chunk_sum) {
     const unsigned bid = bin_logical_block(nblocks);
     if (bid >= nblocks) return;
     uint32_t* hist = dyn_lds;
@@ -256,19 +286,28 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, int gpr, c
     for_each_instance(bid, nblocks, gpr, P, tiles_touched, rect, rec, gx, false, cull != 0, W, H, round_lds,
                       [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); });
     __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) table[(size_t)t * nblocks + bid] = hist[t];   // tile-major
+    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) table[(size_t)t * stride + bid] = hist[t];    // tile-major
+    // This workgroup's share of every scan chunk of the table (2048 entries = 2048 / stride whole rows), added to one of
+    // EGS_BIN_GROUPS partial accumulators: the scan then needs no reduction pass of its own (one launch less; the atomics return nothing)
+    const int rpc = 2048 / (int)stride, n_chunks = (n_tiles + rpc - 1) / rpc;
+    uint32_t* sums = chunk_sum + (size_t)(blockIdx.x % EGS_BIN_GROUPS) * n_chunks;
+    for (int c = threadIdx.x; c < n_chunks; c += EGS_BIN_THREADS) {
+        uint32_t sum = 0;
+        for (int t = c * rpc; t < min((c + 1) * rpc, n_tiles); t++) sum += hist[t];
+        if (sum) atomicAdd(&sums[c], sum);
+    }
 }
 
 __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, int gpr, const uint32_t* __restrict__ tiles_touched,
                                                       const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
                                                       int n_tiles, uint32_t nblocks, int cull, int W, int H,
-                                                      const uint32_t* __restrict__ table_scanned,
+                                                      const uint32_t* __restrict__ table_scanned, uint32_t stride,
                                                       uint32_t cap, uint64_t* __restrict__ pairs) {
     const unsigned bid = bin_logical_block(nblocks);
     if (bid >= nblocks) return;
     uint32_t* cursor = dyn_lds;
     uint32_t* round_lds = dyn_lds + ((n_tiles + 3) & ~3);
-    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) cursor[t] = table_scanned[(size_t)t * nblocks + bid];
+    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) cursor[t] = table_scanned[(size_t)t * stride + bid];
     for_each_instance(bid, nblocks, gpr, P, tiles_touched, rect, rec, gx, true, cull != 0, W, H, round_lds, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
         const uint32_t pos = atomicAdd(&cursor[tile], 1u);
         if (pos < cap) pairs[pos] = ((uint64_t)dbits << 32) | idx;      // cap < R only in a speculative launch that will be redone
@@ -412,7 +451,7 @@ __device__ __forceinline__ void block_min_max(uint32_t& mn, uint32_t& mx, uint32
 }
 
 template <bool RANK_ATOMIC, int TS_WAVES, int TS_CAP, uint32_t N_MIN>
-__global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32_t nblocks, const uint32_t* __restrict__ table_scanned,
+__global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32_t stride, const uint32_t* __restrict__ table_scanned,
                                                     const uint64_t* __restrict__ total, uint64_t* __restrict__ running_max,
                                                     uint32_t R /* capacity */,
                                                     int index_passes, uint64_t* __restrict__ pairs,
@@ -424,8 +463,8 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
     __shared__ uint32_t cnt[TS_WAVES][256];
     __shared__ uint32_t lds8[2 * TS_WAVES];
     const int tile = blockIdx.x;
-    const uint32_t beg = table_scanned[(size_t)tile * nblocks];
-    const uint32_t end = tile + 1 < n_tiles ? table_scanned[(size_t)(tile + 1) * nblocks] : (uint32_t)*total;
+    const uint32_t beg = table_scanned[(size_t)tile * stride];
+    const uint32_t end = tile + 1 < n_tiles ? table_scanned[(size_t)(tile + 1) * stride] : (uint32_t)*total;
     const uint32_t n = end > R ? 0u : end - beg;                     // end > capacity: speculative launch that overflowed
     if (N_MIN == 0) {                                                // the first of the two launches also publishes the bookkeeping
         if (running_max && tile == 0 && threadIdx.x == 0 && *total > *running_max) *running_max = *total;   // for hipGraph replays (api.hip)
@@ -585,7 +624,7 @@ int egs_bin_gpb(int P) { const int k = (P + EGS_BIN_GPB * 512 - 1) / (EGS_BIN_GP
 uint32_t egs_bin_blocks(int P) { const int g = egs_bin_gpb(P); return (uint32_t)((P + g - 1) / g); }
 
 hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
-                              uint64_t* running_max, hipStream_t s, int debug) {
+                              uint64_t* running_max, int sums_zeroed, hipStream_t s, int debug) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
     if (R64 == 0 || P == 0) return egs_launch_zero_u32((uint32_t*)im.ranges, 2 * (size_t)n_tiles, s);
@@ -609,13 +648,18 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
         e = hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    const uint32_t stride = egs_table_stride(nblocks), n_chunks = (uint32_t)egs_table_chunks((size_t)n_tiles, stride);
     egs_prof_start(EGS_K_DUPLICATE, s);
-    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, W, H, b.table);
+    if (!sums_zeroed) {
+        hipError_t e0 = egs_launch_zero_u32(b.chunk_sum, (size_t)EGS_BIN_GROUPS * n_chunks, s);
+        if (e0 != hipSuccess) return e0;
+    }
+    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, W, H,
+                       b.table, stride, b.chunk_sum);
     EGS_DBG(s);
-    hipError_t e = egs_launch_scan_u32(b.table, b.table, (size_t)n_tiles * nblocks, 0, b.spine, b.total, s);
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_table_scan, dim3(n_chunks), dim3(EGS_SCAN_THREADS), 0, s, b.table, (size_t)n_tiles * stride, stride, nblocks, b.chunk_sum, n_chunks, b.total);
     hipLaunchKernelGGL(k_bin_scatter, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
-                       cull, W, H, b.table, R, b.pairs);
+                       cull, W, H, b.table, stride, R, b.pairs);
     egs_prof_stop(EGS_K_DUPLICATE, s);
     EGS_DBG(s);
     int index_bits = 0; while (((unsigned)(P - 1) >> index_bits) != 0) index_bits++;
@@ -623,7 +667,7 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     static std::atomic<int> lds_rank_ok{-1};
     int fast = lds_rank_ok.load();
     if (fast < 0) {
-        uint32_t* flag = b.spine;                                   // free at this point (the scan is done with it)
+        uint32_t* flag = b.flag;
         hipError_t e2 = egs_launch_zero_u32(flag, 1, s);
         if (e2 != hipSuccess) return e2;
         hipLaunchKernelGGL(k_check_lds_atomic_order, dim3(64), dim3(256), 0, s, flag);
@@ -639,14 +683,14 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     egs_prof_start(EGS_K_SORT, s);
     const int ip = (index_bits + TS_DBITS - 1) / TS_DBITS;
     if (fast) {
-        hipLaunchKernelGGL((k_tile_sort<true, 4, 2048, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, b.total, running_max, R,
+        hipLaunchKernelGGL((k_tile_sort<true, 4, 2048, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, R,
                            ip, b.pairs, b.scratch, b.point_list, im.ranges);
-        hipLaunchKernelGGL((k_tile_sort<true, 8, 4096, 2049u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, nblocks, b.table, b.total, running_max, R,
+        hipLaunchKernelGGL((k_tile_sort<true, 8, 4096, 2049u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, R,
                            ip, b.pairs, b.scratch, b.point_list, im.ranges);
     } else {
-        hipLaunchKernelGGL((k_tile_sort<false, 4, 2048, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, nblocks, b.table, b.total, running_max, R,
+        hipLaunchKernelGGL((k_tile_sort<false, 4, 2048, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, R,
                            ip, b.pairs, b.scratch, b.point_list, im.ranges);
-        hipLaunchKernelGGL((k_tile_sort<false, 8, 4096, 2049u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, nblocks, b.table, b.total, running_max, R,
+        hipLaunchKernelGGL((k_tile_sort<false, 8, 4096, 2049u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, R,
                            ip, b.pairs, b.scratch, b.point_list, im.ranges);
     }
     egs_prof_stop(EGS_K_SORT, s);

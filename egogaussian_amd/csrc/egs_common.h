@@ -33,10 +33,14 @@ struct EgsBinPtrs {
     uint64_t* pairs;        // [R] (depth<<32 | index), bucketed by tile
     uint64_t* scratch;      // [R] ping-pong space for oversize buckets
     uint32_t* point_list;   // [R] sorted Gaussian indices
-    uint32_t* table;        // [n_tiles][bin_blocks] per-(tile, block) instance counts, scanned in place
-    uint32_t* spine;        // scan scratch
+    uint32_t* table;        // [n_tiles][table_stride] per-(tile, bucketing workgroup) instance counts, scanned in place (columns >= bin_blocks unused)
+    uint32_t* chunk_sum;    // [EGS_BIN_GROUPS][chunks] sums of the table's 2048-entry scan chunks, accumulated by k_bin_count; ZERO before it
+    uint32_t* flag;         // [32] scratch words
     uint64_t* total;        // [1] number of instances found by the scan (== R)
 };
+#define EGS_BIN_GROUPS 8            // partial accumulators per scan chunk (a same-address atomic chain is bin_blocks / 8 long)
+static inline uint32_t egs_table_stride(uint32_t bin_blocks) { uint32_t s = 4; while (s < bin_blocks) s <<= 1; return s; }   // power of two <= 2048
+static inline size_t egs_table_chunks(size_t n_tiles, uint32_t stride) { const size_t rpc = 2048 / stride; return (n_tiles + rpc - 1) / rpc; }
 struct EgsImgPtrs { uint2* ranges; float* final_T; uint32_t* n_contrib; uint32_t* quad_work; uint32_t* tile_order; };
 
 static inline size_t egs_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -68,9 +72,11 @@ struct EgsCamera {
     int W, H; float tanfovx, tanfovy;
 };
 // `act`: activation flags of the raw-parameter mode (include/egs_raster.h: EGS_ACT_*)
+// zero_words / zero_n: an unrelated region this launch also clears (the bucketing's chunk sums of the same frame; may be NULL)
 hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
                                  const float* opac, const float* scales, float mod, const float* rots, int act,
-                                 const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, hipStream_t s);
+                                 const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, uint32_t* zero_words, size_t zero_n,
+                                 hipStream_t s);
 hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* means3D, const float* shs,
                                           const float* scales, float mod, const float* rots, const float* cov3D, int act,
                                           EgsCamera cam, const int32_t* radii, EgsGeomPtrs g, const float* grad_acc,
@@ -91,8 +97,9 @@ hipError_t egs_launch_mark_visible(int P, const float* means3D, const float* vie
 // writes the grand total (u64) to *total.
 hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int inclusive, uint32_t* scratch,
                                uint64_t* total, hipStream_t s);
+// sums_zeroed: b.chunk_sum was cleared by this frame's preprocess launch (else a zero-fill launch comes first)
 hipError_t egs_launch_binning(int P, int64_t R, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
-                              uint64_t* running_max, hipStream_t s, int debug);
+                              uint64_t* running_max, int sums_zeroed, hipStream_t s, int debug);
 hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                      EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha,
                                      hipStream_t s);

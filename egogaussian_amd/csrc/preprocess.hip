@@ -230,9 +230,10 @@ __global__ __launch_bounds__(256) void k_preprocess(
     const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
     uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible,
-    uint32_t* __restrict__ block_sums) {
+    uint32_t* __restrict__ block_sums, uint32_t* __restrict__ zero_words, size_t zero_n) {
     __shared__ uint32_t wsum[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t z = (size_t)i; z < zero_n; z += (size_t)gridDim.x * blockDim.x) zero_words[z] = 0u;   // on the side (egs_common.h)
     uint32_t my_tiles = 0;
     if (i < P) my_tiles = preprocess_one(i, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D_in, act, V, PM, campos, W, H,
                                          tanfovx, tanfovy, radii, rec, rect_out, tiles_touched, clamped_out, visible);
@@ -922,11 +923,13 @@ hipError_t egs_launch_zero_f4(float4* p, size_t n4, hipStream_t s) {
 
 hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
                                  const float* opac, const float* scales, float mod, const float* rots, int act,
-                                 const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, hipStream_t s) {
+                                 const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, uint32_t* zero_words, size_t zero_n,
+                                 hipStream_t s) {
     if (P == 0) return hipSuccess;
+    if (!zero_words) zero_n = 0;
     hipLaunchKernelGGL(k_preprocess, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, colors, opac, scales,
                        mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.tanfovx, cam.tanfovy, radii,
-                       g.rec, g.rect, g.offsets, g.clamped, g.visible, g.scan_scratch);
+                       g.rec, g.rect, g.offsets, g.clamped, g.visible, g.scan_scratch, zero_words, zero_n);
     return hipGetLastError();
 }
 

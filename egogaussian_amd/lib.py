@@ -20,7 +20,7 @@ class GeomLayout(C.Structure):
 
 class BinningLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("point_list", "pairs", "scratch", "table", "spine", "total")] + \
-               [(n, C.c_int) for n in ("bin_blocks", "key_bits", "index_passes")]
+               [(n, C.c_int) for n in ("bin_blocks", "key_bits", "index_passes", "table_stride")]
 
 
 class ImageLayout(C.Structure):

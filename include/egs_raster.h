@@ -81,13 +81,14 @@ typedef struct egs_binning_layout {
     size_t point_list;     /* uint32[R]  Gaussian indices ordered by (tile, depth bits, index); ALWAYS at offset 0 */
     size_t pairs;          /* uint64[R]  (float bits of depth << 32 | Gaussian index), bucketed by tile */
     size_t scratch;        /* uint64[R]  ping-pong space for buckets too large for the in-register sort */
-    size_t table;          /* uint32[tiles][bin_blocks] per-(tile, block) counts, exclusive-scanned in place */
-    size_t spine;          /* uint32[..] scan scratch */
+    size_t table;          /* uint32[tiles][table_stride] per-(tile, bucketing workgroup) counts, exclusive-scanned in place; columns >= bin_blocks unused */
+    size_t spine;          /* uint32[..] sums of the table's 2048-entry scan chunks (8 partial accumulators each), scratch words */
     size_t total;          /* uint64[1]  instance count found by the bucketing scan (== R; may exceed a speculative capacity) */
     int    bin_blocks;     /* workgroups of the bucketing kernels: ceil(P / gpb), gpb = 1024 * ceil(P / 524288) */
     int    key_bits;       /* significant bits of the canonical (tile<<32 | depth) key: 32 + bits(tile count) */
     int    index_passes;   /* 9-bit radix passes on the Gaussian index inside the per-tile sort, run only for tiles with depth ties
                              (+ up to 4 on depth: ceil(bits(zmax - zmin of the tile) / 9)) */
+    int    table_stride;   /* row length of `table`: the power of two >= max(bin_blocks, 4) */
 } egs_binning_layout;
 typedef struct egs_image_layout {
     size_t ranges;         /* uint32[tiles][2] */
