@@ -176,9 +176,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alpha,
-                                 debug, activation_flags=0, sh_rest=None):
+                                 debug, activation_flags=0, sh_rest=None, densify_stats=None):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
-           dL_dscales[P,3], dL_drotations[P,4]); with sh_rest, dL_dsh is [P,1,3] and a ninth element dL_dsh_rest[P,M-1,3] follows"""
+           dL_dscales[P,3], dL_drotations[P,4]); with sh_rest, dL_dsh is [P,1,3] and a ninth element dL_dsh_rest[P,M-1,3] follows.
+    densify_stats (extension): (xyz_gradient_accum[P,1], denom[P,1], max_radii2D[P] or None), float32, updated in place by the kernel
+    that produces dL_dmeans2D (include/egs_raster.h) -- the caller then skips its add_densification_stats for this iteration."""
     L = _lib.load()
     means3D = _f32c(means3D, "means3D")
     dev = means3D.device
@@ -210,10 +212,20 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
                 _ptr(imageBuffer), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(dmeans2D), _ptr(dcolors),
                 _ptr(dopacity), _ptr(dmeans3D), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
-                _ptr(drots) if own_cov else None, _ptr(scratch), _stream(), int(bool(debug))))
+                _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(scratch), _stream(), int(bool(debug))))
     if sh_rest is not None:
         return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots, dsh_rest
     return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots
+
+
+def _stat_ptrs(stats_tensors, P, dev):
+    if stats_tensors is None:
+        return None, None, None
+    acc, den, mr = stats_tensors
+    for t in (acc, den) + ((mr,) if mr is not None else ()):
+        if not (t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == P):
+            raise RuntimeError("densify_stats: contiguous float32 tensors of P elements on the rasterizer's device")
+    return _ptr(acc), _ptr(den), _ptr(mr)
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

@@ -358,7 +358,8 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
                  const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
                  const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
                  float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
-                 float* dL_dscales, float* dL_drotations, void* scratch, void* stream, int debug) {
+                 float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
+                 void* scratch, void* stream, int debug) {
     int rc = check_dims(P, width, height); if (rc) return rc;
     if (P == 0) return 0;
     if (R < 0 || R >= (1ll << 31)) return EGS_ERR_RANGE;
@@ -370,6 +371,7 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
     if (shs && !dL_dsh) return EGS_ERR_ARG;
     if (shs_rest && (!shs || sh_coeffs < 2)) return EGS_ERR_MODE;
     if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr)) return EGS_ERR_ARG;
+    if ((stat_grad_accum != nullptr) != (stat_denom != nullptr) || (stat_max_radii && !stat_grad_accum)) return EGS_ERR_ARG;
     if (!cov3D_precomp && (!dL_dscales || !dL_drotations)) return EGS_ERR_ARG;
     if (cov3D_precomp && !dL_dcov3D) return EGS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -393,7 +395,7 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
     EGS_TRY(egs_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, scales, scale_modifier, rotations,
                                            cov3D_precomp, activation_flags, cam, radii, g, grad_acc, colors_precomp != nullptr, dL_dmeans2D,
                                            dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, sh_apart ? nullptr : dL_dsh, dL_dscales,
-                                           dL_drotations, s));
+                                           dL_drotations, stat_grad_accum, stat_denom, stat_max_radii, s));
     if (sh_apart) EGS_TRY(egs_launch_sh_backward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, radii, g, dL_dcolors, dL_dsh,
                                                  dL_dsh_rest, dL_dmeans3D, s));
     egs_prof_stop(EGS_K_PREPROCESS_BWD, s);

@@ -82,7 +82,7 @@ hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* mean
                                           EgsCamera cam, const int32_t* radii, EgsGeomPtrs g, const float* grad_acc,
                                           int colors_given, float* dmeans2D, float* dcolors, float* dopac,
                                           float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,
-                                          hipStream_t s);
+                                          float* stat_grad_accum, float* stat_denom, float* stat_max_radii, hipStream_t s);
 // Spherical harmonics as separate launches (M > 1 coefficients, or DC / rest given as two arrays: sh_rest != NULL).  The
 // preprocess launchers are then called with shs = NULL: the forward leaves the record's colour open, the backward leaves
 // dL/dSH and the view-direction part of dL/dmean3D to egs_launch_sh_backward (which must run after it).

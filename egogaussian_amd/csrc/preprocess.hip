@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     float tanfovx, float tanfovy, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
     const float4* __restrict__ rec, const float* __restrict__ grad_acc, float* __restrict__ dmeans2D, float* __restrict__ dcolors,
     float* __restrict__ dopac, float* __restrict__ dmeans3D, float* __restrict__ dcov3D, float* __restrict__ dsh,
-    float* __restrict__ dscales, float* __restrict__ drots) {
+    float* __restrict__ dscales, float* __restrict__ drots,
+    float* __restrict__ stat_grad_accum, float* __restrict__ stat_denom, float* __restrict__ stat_max_radii) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const bool vis = radii[i] > 0;
@@ -279,6 +280,13 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     }
     acc[0] = gmx * (0.5f * (float)W); acc[1] = gmy * (0.5f * (float)H);
     dmeans2D[3 * i] = acc[0]; dmeans2D[3 * i + 1] = acc[1]; dmeans2D[3 * i + 2] = 0.f;
+    if (stat_grad_accum && vis) {
+        // the trainer's per-iteration densification statistics, where their inputs are produced
+        // (/root/reference/scene/gaussian_model.py:735-737 add_densification_stats, trainers/train_static.py:125 max_radii2D)
+        stat_grad_accum[i] += sqrtf(acc[0] * acc[0] + acc[1] * acc[1]);
+        stat_denom[i] += 1.f;
+        if (stat_max_radii) stat_max_radii[i] = fmaxf(stat_max_radii[i], (float)radii[i]);
+    }
     dcolors[3 * i] = acc[6]; dcolors[3 * i + 1] = acc[7]; dcolors[3 * i + 2] = acc[8];
     {   // logit opacities: chain through the sigmoid with the activated value the forward parked in the record
         const float o = rec[(size_t)i * EGS_SPLAT_REC_F4 + 1].y;
@@ -938,12 +946,13 @@ hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* mean
                                           EgsCamera cam, const int32_t* radii, EgsGeomPtrs g, const float* grad_acc,
                                           int colors_given, float* dmeans2D, float* dcolors, float* dopac,
                                           float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,
-                                          hipStream_t s) {
+                                          float* stat_grad_accum, float* stat_denom, float* stat_max_radii, hipStream_t s) {
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(k_preprocess_backward, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D,
                        colors_given ? nullptr : shs, scales, mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W,
                        cam.H, cam.tanfovx, cam.tanfovy, radii, g.clamped, g.rec, grad_acc, dmeans2D, dcolors, dopac, dmeans3D,
-                       dcov3D, colors_given ? nullptr : dsh, cov3D ? nullptr : dscales, cov3D ? nullptr : drots);
+                       dcov3D, colors_given ? nullptr : dsh, cov3D ? nullptr : dscales, cov3D ? nullptr : drots,
+                       stat_grad_accum, stat_denom, stat_max_radii);
     return hipGetLastError();
 }
 

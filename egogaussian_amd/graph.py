@@ -67,8 +67,8 @@ class _StaticCamera:
 
 class GraphedTrainStep:
     def __init__(self, pc, optimizer, bg, lambda_dssim=0.2, pipe=Pipe, render_kwargs=None, densify_stats=False):
-        """densify_stats: also run the per-iteration densification statistics (egogaussian_amd.densify.add_densification_stats,
-        i.e. trainers/train_static.py:125-127) inside the captured step."""
+        """densify_stats: the captured step also keeps the per-iteration densification statistics (trainers/train_static.py:125-127:
+        max_radii2D, xyz_gradient_accum, denom) -- updated by the rasterizer's backward itself, no launch of their own."""
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True)")
         self.pc, self.opt, self.bg, self.lam, self.pipe = pc, optimizer, bg, lambda_dssim, pipe
@@ -79,13 +79,10 @@ class GraphedTrainStep:
         self.loss_sum = None
 
     def _body(self):
-        out = render(self.cam, self.pc, self.pipe, self.bg, **self.render_kwargs)
+        out = render(self.cam, self.pc, self.pipe, self.bg, fused_densify_stats=self.densify_stats, **self.render_kwargs)
         # the loss value and the running sum are produced by the loss BACKWARD kernel (nothing reads them before): two launches less
         loss = l1_ssim_loss(out["render"], self.gt, self.lam, running_sum=self.loss_sum, defer_value=True)
         loss.backward(gradient=self._one)                            # a resident 1.0: no fill kernel per iteration
-        if self.densify_stats:
-            from .densify import add_densification_stats
-            add_densification_stats(self.pc, out["viewspace_points"], out["visibility_filter"], radii=out["radii"])
         self.opt.step()
         return loss.detach(), out
 

@@ -48,7 +48,7 @@ SIGNATURES = {
     "egs_sum_counts": (C.c_int64, [i32, vp]),
     "egs_forward_render": (C.c_int, [i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
-                               vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
+                               vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "egs_cov3d_forward": (C.c_int, [i32, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_cov3d_dm_scratch_floats": (C.c_size_t, [i32]),

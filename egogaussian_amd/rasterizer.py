@@ -39,7 +39,7 @@ class GaussianRasterizationSettings(NamedTuple):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                activation_flags=0, sh_rest=None):
+                activation_flags=0, sh_rest=None, densify_stats=None):
         rs = raster_settings
         if sh_rest is None:
             sh_rest = torch.empty(0, device=means3D.device, dtype=torch.float32)
@@ -49,6 +49,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.campos, rs.prefiltered, rs.debug, activation_flags, sh_rest)
         ctx.raster_settings = rs
         ctx.activation_flags = int(activation_flags)
+        ctx.densify_stats = densify_stats           # (tensors updated in place by the backward; not autograd inputs)
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img,
                               alpha, sh_rest)
@@ -72,19 +73,19 @@ class _RasterizeGaussians(torch.autograd.Function):
         grads = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos, geom,
-            ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags, sh_rest if split else None)
+            ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags, sh_rest if split else None, ctx.densify_stats)
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = grads[:8]
         none_if_absent = lambda g, x: g if x.numel() != 0 else None
         return (g_means3D, g_means2D, none_if_absent(g_sh, sh), none_if_absent(g_colors, colors_precomp),
                 g_opac, none_if_absent(g_scales, scales),
                 none_if_absent(g_rots, rotations), none_if_absent(g_cov3D, cov3Ds_precomp), None, None,
-                grads[8] if split else None)
+                grads[8] if split else None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, activation_flags=0, sh_rest=None):
+                        raster_settings, activation_flags=0, sh_rest=None, densify_stats=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, activation_flags, sh_rest)
+                                     cov3Ds_precomp, raster_settings, activation_flags, sh_rest, densify_stats)
 
 
 class GaussianRasterizer(nn.Module):
@@ -98,12 +99,14 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, raw_parameters=False):
+                cov3D_precomp=None, raw_parameters=False, densify_stats=None):
         """Same call as upstream's.  raw_parameters=True (an extension): `scales`, `rotations` and `opacities` are the model's RAW
         parameters (log-scales, unnormalised quaternions, opacity logits); the activations run inside the preprocess kernel and
         the gradients come back w.r.t. the raw tensors (include/egs_raster.h, EGS_ACT_*).
         `shs` may also be the pair (features_dc [P,1,3], features_rest [P,M-1,3]) -- the two parameters the reference's model keeps
         (/root/reference/scene/gaussian_model.py:157-160) -- which spares the torch.cat of get_features and the split of its gradient."""
+        # densify_stats (an extension): (xyz_gradient_accum, denom, max_radii2D or None) -- the backward updates the trainer's
+        # densification statistics in place, in the kernel that produces the screen-space gradient (include/egs_raster.h)
         shs_rest = None
         if isinstance(shs, (tuple, list)):
             shs, shs_rest = shs
@@ -123,4 +126,4 @@ class GaussianRasterizer(nn.Module):
         if raw_parameters and cov3D_precomp.numel() != 0:
             raise Exception("GaussianRasterizer: raw_parameters needs `scales` and `rotations`, not `cov3D_precomp`")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   self.raster_settings, _C.ACT_RAW_PARAMETERS if raw_parameters else 0, shs_rest)
+                                   self.raster_settings, _C.ACT_RAW_PARAMETERS if raw_parameters else 0, shs_rest, densify_stats)

@@ -37,7 +37,9 @@ def _screenspace_leaf(xyz):
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, rot_cov=False,
-           accum_R=None, which_object=None, during_training=False):
+           accum_R=None, which_object=None, during_training=False, fused_densify_stats=False):
+    """fused_densify_stats (an extension, default off): the backward of this render also updates pc.xyz_gradient_accum, pc.denom and
+    pc.max_radii2D in place (the trainer then skips add_densification_stats / the max_radii2D update for this iteration)."""
     xyz = pc.get_xyz
     screenspace_points = _screenspace_leaf(xyz)
     rasterizer = GaussianRasterizer(raster_settings=get_raster_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
@@ -77,7 +79,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
 
     image, radii, depth, alpha = rasterizer(means3D=xyz, means2D=screenspace_points, shs=shs,
                                             colors_precomp=colors_precomp, opacities=pc.get_opacity if opacity is None else opacity, scales=scales,
-                                            rotations=rotations, cov3D_precomp=cov3D_precomp, **({"raw_parameters": True} if raw else {}))
+                                            rotations=rotations, cov3D_precomp=cov3D_precomp, **({"raw_parameters": True} if raw else {}),
+                                            **({"densify_stats": (pc.xyz_gradient_accum, pc.denom, pc.max_radii2D)} if fused_densify_stats else {}))
     from . import _C
     visible = _C.stats.get("visible_view")                 # radii > 0, written by the preprocess kernel of the call above
     if visible is None or visible.shape != radii.shape or visible.device != radii.device:

@@ -185,6 +185,11 @@ int egs_backward(
     float* dL_dcov3D /*[P,6] out; may be NULL with scales + rotations*/, float* dL_dsh /*[P,M,3] out or NULL*/,
     float* dL_dsh_rest /*[P,M-1,3] out with shs_rest (dL_dsh is then [P,1,3]), else NULL*/,
     float* dL_dscales /*[P,3] out or NULL*/, float* dL_drotations /*[P,4] out or NULL*/,
+    /* Optional (all NULL = off): the trainer's per-iteration densification statistics updated IN PLACE by the same launch that
+     * produces dL_dmeans2D -- for Gaussians with radii > 0: grad_accum[i] += |dL_dmeans2D[i, :2]|, denom[i] += 1
+     * (/root/reference/scene/gaussian_model.py:735-737) and max_radii[i] = max(max_radii[i], radii[i])
+     * (/root/reference/trainers/train_static.py:125).  Same arithmetic as egs_densify_stats, one launch less per iteration. */
+    float* stat_grad_accum /*[P] in/out or NULL*/, float* stat_denom /*[P] in/out or NULL*/, float* stat_max_radii /*[P] in/out or NULL*/,
     void* scratch /* egs_backward_scratch_bytes(P) */, void* stream, int debug);
 
 /* ---- frustum test only  (upstream: markVisible) -------------------------------------------------- */

@@ -204,3 +204,32 @@ def test_example_trainer_runs(tmp_path):
     pc = mod.main(["--gaussians", "6000", "--height", "96", "--width", "160", "--iters", "130", "--densify-from", "40", "--densify-until", "120",
                    "--densify-interval", "40", "--opacity-reset-interval", "80", "--frames", "8", "--out", out])
     assert os.path.getsize(out) > 6000 * 4 * 20 and pc._xyz.shape[0] != 6000
+
+
+@pytest.mark.parametrize("sh_degree", [0, 3])
+def test_statistics_fused_into_the_backward_equal_the_separate_kernel(sh_degree):
+    """render(..., fused_densify_stats=True): xyz_gradient_accum, denom and max_radii2D updated by the rasterizer's backward itself
+    must equal add_densification_stats applied to the same backward's outputs, iteration after iteration."""
+    import math
+    from egogaussian_amd import densify
+    from egogaussian_amd.scene_synth import make_scene, make_camera, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    H, W = 96, 160
+    sc = make_scene(5003, H, W, 0, sh_degree=sh_degree); sc["log_scale"] += math.log(2.0)
+    bg = torch.zeros(3, device=DEV)
+    models = [SynthGaussians(sc, device=DEV, sh_degree=sh_degree) for _ in range(2)]
+    gup = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).to(DEV)
+    for it in range(3):
+        cam = make_camera(10 * it, H, W, device=DEV)
+        for fused, pc in zip((False, True), models):
+            out = render(cam, pc, Pipe, bg, fused_densify_stats=fused)
+            (out["render"] * gup).sum().backward()
+            if not fused:
+                densify.add_densification_stats(pc, out["viewspace_points"], out["visibility_filter"], radii=out["radii"])
+            for p in pc.parameters():
+                p.grad = None
+    a, b = models
+    assert float(a.denom.max()) == 3.0 and torch.equal(a.denom, b.denom) and torch.equal(a.max_radii2D, b.max_radii2D)
+    # the screen-space gradient itself is summed with float atomics in the blend: equal up to their order
+    err = (a.xyz_gradient_accum - b.xyz_gradient_accum).abs().max() / a.xyz_gradient_accum.abs().max()
+    assert float(err) < 1e-5 and float(a.xyz_gradient_accum.abs().sum()) > 0
