@@ -55,8 +55,8 @@ def algorithmic_bytes(stage, N, R, npix, sh_coeffs=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gaussians", type=int, default=500_000)
     ap.add_argument("--height", type=int, default=540)
     ap.add_argument("--width", type=int, default=960)
