@@ -328,6 +328,7 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, int gpr,
 // larger ones and, beyond 4096, the global-memory path.  Each workgroup returns at once if its tile belongs to the other.
 #define TS_DBITS 9
 #define TS_DIGITS (1 << TS_DBITS)
+#define TS_BUCKET_MAX 96u           // largest top-digit bucket the in-bucket comparison takes (see k_tile_sort)
 
 __device__ __forceinline__ uint64_t digit_peers(uint32_t d, bool ok) {
     uint64_t peers = __ballot(ok);
@@ -496,6 +497,51 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
         // Barriers per pass: 4.  Every wave clears ITS OWN counters (nobody else touches them between the barrier after the
         // scatter and the one after the ranking), so clearing needs no workgroup barrier.
         for (int k = lane; k < 256; k += 64) cnt[w][k] = 0;
+        if (depth_passes >= 2) {
+            // ---- one pass on the TOP nine bits of (depth - tile minimum), then every key counts the smaller keys of its own bucket ----
+            // The top digit spreads a tile's instances over up to 512 buckets in depth order (a couple of keys each unless the depths
+            // cluster); inside a bucket the full 64-bit (depth, index) keys are compared directly, which also settles depth ties.  One
+            // ranking pass + a short loop instead of three passes (-7 us per frame at config C).  A bucket of more than TS_BUCKET_MAX keys
+            // (depths piled up in one 1/512 of the range) sends the tile to the digit-by-digit passes below.
+            const int sh = (32 - __clz((int)(dmax - dmin))) - TS_DBITS;
+            uint32_t rank[TS_ITEMS];
+#pragma unroll
+            for (int r = 0; r < TS_ITEMS; r++) {
+                rank[r] = 0;
+                if (r * 64u < chunk) {
+                    const uint32_t i = wbeg + r * 64 + lane;
+                    rank[r] = wave_digit_rank<RANK_ATOMIC, true>(cnt[w], ((uint32_t)(key[r] >> 32) - dmin) >> sh, i < n, lane, lt);
+                }
+            }
+            __syncthreads();
+            digit_bases_packed<TS_WAVES>(cnt, lds8);
+#pragma unroll
+            for (int r = 0; r < TS_ITEMS; r++) {
+                const uint32_t i = wbeg + r * 64 + lane;
+                if (r * 64u < chunk && i < n) {
+                    const uint32_t d = ((uint32_t)(key[r] >> 32) - dmin) >> sh;
+                    xbuf[((cnt[w][d >> 1] >> (16u * (d & 1u))) & 0xffffu) + rank[r]] = key[r];
+                }
+            }
+            __syncthreads();
+            bool big = false;
+#pragma unroll
+            for (int r = 0; r < TS_ITEMS; r++) {
+                const uint32_t i = wbeg + r * 64 + lane;
+                if (r * 64u < chunk && i < n) {
+                    const uint64_t k = xbuf[i];
+                    const uint32_t d = ((uint32_t)(k >> 32) - dmin) >> sh;
+                    const uint32_t bs = (cnt[0][d >> 1] >> (16u * (d & 1u))) & 0xffffu;           // wave 0's base = start of the bucket
+                    const uint32_t be = d + 1 < TS_DIGITS ? (cnt[0][(d + 1) >> 1] >> (16u * ((d + 1) & 1u))) & 0xffffu : n;
+                    if (be - bs > TS_BUCKET_MAX) { big = true; continue; }
+                    uint32_t smaller = 0;
+                    for (uint32_t q = bs; q < be; q++) smaller += xbuf[q] < k ? 1u : 0u;
+                    point_list[beg + bs + smaller] = (uint32_t)k;
+                }
+            }
+            if (!__syncthreads_or(big ? 1 : 0)) return;
+            for (int k = lane; k < 256; k += 64) cnt[w][k] = 0;             // an overfull bucket: start over, digit by digit (keys are still in registers)
+        }
         for (int phase = depth_passes ? 0 : 1; phase < 2; phase++) {
             for (int p = phase == 0 ? index_passes : 0; p < npass; p++) {
                 uint32_t rank[TS_ITEMS];

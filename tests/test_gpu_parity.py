@@ -288,6 +288,37 @@ def test_depth_ties_keep_index_order():
     assert rel_err(out[1].cpu().numpy(), st["color"]) < 1e-5
 
 
+@pytest.mark.parametrize("layout", ["two-surfaces", "pile-with-ties", "one-outlier"])
+def test_clustered_depths_take_the_sorts_fallback_and_still_match(layout):
+    """The per-tile sort first spreads a tile's instances over 512 buckets by the top bits of (depth - tile minimum) and orders
+    each bucket by direct comparison; depths piled up in a sliver of the range overflow a bucket and send the tile to the
+    digit-by-digit passes.  Lists must stay bit-exact either way: two thin surfaces, a pile with exact depth ties in it, and
+    a single far outlier that stretches the range (so that everything else lands in one bucket)."""
+    from egogaussian_amd import _C
+    from egogaussian_amd.scene_synth import make_camera
+    dev = _dev()
+    N, H, W = 6000, 64, 96
+    d = make_inputs(N, H, W, 8, 0, "col_sr", scale_mul=5.0)
+    gen = torch.Generator().manual_seed(3)
+    z = d["means3D"][:, 2]
+    if layout == "two-surfaces":
+        z[:] = torch.where(torch.rand(N, generator=gen) < 0.5, 3.0, 7.0) + 1e-4 * torch.randn(N, generator=gen)
+    elif layout == "pile-with-ties":
+        z[:] = 5.0 + 1e-5 * torch.randint(0, 40, (N,), generator=gen).float()     # 40 distinct depths, hundreds of ties each
+        z[::50] = 2.0 + 6.0 * torch.rand(len(z[::50]), generator=gen)
+    else:
+        z[:] = 4.0 + 1e-3 * torch.rand(N, generator=gen)
+        z[0] = 9.5; d["means3D"][0, :2] = 0.0; d["scales"][0] = 3.0                 # one huge far splat over the whole image
+    cam = make_camera(0, H, W)
+    d.update(viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, campos=cam.camera_center)
+    o, st = oracle_forward(d)
+    g, out = hip_forward(d, dev)
+    bv = _C.binning_views(out[6], N, out[0], W, H, _C.stats["capacity"])
+    assert out[0] == st["R"] and st["R"] > 2 * N
+    assert np.array_equal(bv["point_list"].cpu().numpy().view(np.uint32), st["point_list"])
+    assert outlier_fraction(out[1].cpu().numpy(), st["color"], TOL) <= 1e-4
+
+
 def test_ballot_rank_fallback_sorts_identically():
     """The per-tile sort has two rankers (LDS-atomic, verified on the device at first use; ballot-based fallback)."""
     from egogaussian_amd import _C, lib
