@@ -173,3 +173,75 @@ def test_render_through_hip_matches_reference_end_to_end():
     lab = get_render_label(cam, pc, bg)
     (lab * wc).sum().backward()
     assert close(lab, g["m2_label_render"]) and close(pc._label.grad, g["m2_g_label"])
+
+
+# ---- config 4 call shape: render(..., rot_cov=True, accum_R, which_object=1) -- fixture boundary_rot.npz ---------------
+def _model_from_boundary_rot(g, device="cpu", fused=True):
+    from egogaussian_amd.scene_synth import SynthGaussians
+    scene = dict(xyz=g["xyz"], features=g["features_dc"], log_scale=g["log_scale"], quat=g["quat"], opacity_logit=g["opacity_logit"])
+    pc = SynthGaussians(scene, device=device, fused=fused)
+    pc._is_object = torch.tensor(g["is_object"], device=device)           # [N,1], as the reference stores it
+    return pc
+
+
+def _cam_from_boundary_rot(g, f, device="cpu"):
+    from egogaussian_amd.scene_synth import SynthCamera
+    return SynthCamera(g[f"f{f}_wvt"].T, int(g["H"]), int(g["W"]), float(g["fov"][0]), float(g["fov"][1]), device=device)
+
+
+def test_rot_cov_arguments_match_reference_render():
+    """My render(rot_cov=True, accum_R, which_object=1) hands the rasterizer the covariance the reference's does
+    (/root/reference/scene/gaussian_model.py:46-63 incl. the [N,1]-index quirk on Gaussian 0), and the C oracle reproduces the
+    images the reference got back for it."""
+    from oracle.oracle import Oracle
+    g = load("boundary_rot.npz")
+    pc = _model_from_boundary_rot(g)
+    assert g["is_object"][0, 0] == 0 and g["is_object"].sum() > 50
+    for f in range(2):
+        cam = _cam_from_boundary_rot(g, f)
+        k = f"f{f}_"
+        assert np.array_equal(cam.world_view_transform.numpy(), g[k + "wvt"])
+        assert np.allclose(cam.full_proj_transform.numpy(), g[k + "full"], rtol=1e-6, atol=1e-7)
+        cov = pc.get_rotated_covariance(T(g[k + "accum_R"]), 1, False, 1.0)
+        assert np.allclose(cov.detach().numpy(), g[k + "cov3D_precomp"], rtol=1e-5, atol=1e-10)
+        assert not np.allclose(pc.get_covariance(1.0).detach().numpy()[0], g[k + "cov3D_precomp"][0], rtol=1e-3)   # row 0 IS rotated
+        assert all(g[k + a + "_rg"] for a in ("means3D", "opacities", "shs", "cov3D_precomp")) and g[k + "absent"].all()
+        H, W = int(g["H"]), int(g["W"])
+        st = Oracle(np.float32).forward(means3D=g[k + "means3D"], opacities=g[k + "opacities"], shs=g[k + "shs"],
+                                        cov3D_precomp=g[k + "cov3D_precomp"], viewmatrix=g[k + "wvt"], projmatrix=g[k + "full"],
+                                        campos=g[k + "center"], bg=g["bg"], image_height=H, image_width=W,
+                                        tanfovx=math.tan(float(g["fov"][0]) / 2), tanfovy=math.tan(float(g["fov"][1]) / 2))
+        assert np.array_equal(st["radii"], g[k + "radii"])
+        for name, key in (("color", "render"), ("depth", "depth"), ("alpha", "alpha")):
+            assert np.abs(st[name] - g[k + key]).max() < 2e-5 * max(1.0, np.abs(g[k + key]).max()), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_rot_cov_render_through_hip_matches_reference_end_to_end(fused):
+    """GPU, BASELINE.json config 4's call shape (/root/reference/trainers/fine_all.py:88-94): render(rot_cov=True, accum_R,
+    which_object=1) through the HIP covariance producer (fused=True: cov3d.hip; False: the PyTorch mirror) and the HIP rasterizer
+    reproduces the images and the PARAMETER gradients the reference's render() + GaussianModel produced, including the
+    hand-mask gradient hook on the second frame."""
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.scene_synth import Pipe
+    g = load("boundary_rot.npz")
+    dev = "cuda:0"
+    pc = _model_from_boundary_rot(g, dev, fused=fused)
+    bg = torch.tensor(g["bg"], device=dev)
+    close = lambda a, b, tol=1e-4: np.abs(a.detach().cpu().numpy() - b).max() <= tol * max(np.abs(b).max(), 1e-12)
+    for f in range(2):
+        k = f"f{f}_"
+        cam = _cam_from_boundary_rot(g, f, dev)
+        out = render(cam, pc, Pipe, bg, rot_cov=True, accum_R=torch.tensor(g[k + "accum_R"], device=dev), which_object=1, during_training=False)
+        img = out["render"]
+        if bool(g[k + "masked"]):
+            hand = torch.tensor(g[k + "hand"], device=dev)
+            img.register_hook(lambda grad: grad * (1 - hand))
+        (img * torch.tensor(g[k + "wc"], device=dev)).sum().backward()
+        assert np.array_equal(out["radii"].cpu().numpy(), g[k + "radii"])
+        assert close(img, g[k + "render"]) and close(out["depth"], g[k + "depth"]) and close(out["alpha"], g[k + "alpha"])
+        for p, name in ((pc._xyz, "g_xyz"), (pc._features_dc, "g_features_dc"), (pc._scaling, "g_scaling"), (pc._rotation, "g_rotation"),
+                        (pc._opacity, "g_opacity"), (out["viewspace_points"], "g_viewspace")):
+            assert close(p.grad, g[k + name]), (f, name)
+            p.grad = None
