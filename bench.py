@@ -2,11 +2,12 @@
 """bench.py -- BASELINE.json's metric on its quoted configuration, one process per GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+N > 1 launched plainly re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 ...`; launched by torchrun / the driver it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
-Workload (config C of BASELINE.md): synthetic scene S(500k Gaussians, 540, 960, seed 0), the 300-frame synthetic
-orbit, SH degree 0 (`--sh-degree 3` for the 16-coefficient colour model the reference ends training with; the default
-single-GPU run measures that too, in a child process, and reports it as `sh_degree_3`).
+Workload (config C of BASELINE.md): synthetic scene S(500k Gaussians, 540, 960, seed 0), the 300-frame synthetic orbit, SH
+degree 0 (`--sh-degree 3` for the 16-coefficient colour model the reference ends training with; the default single-GPU
+run measures that too, in a child process, and reports it as `sh_degree_3`).
 One step = one full training iteration of /root/reference/trainers/train_static.py:67-138 without densification or
 logging: covariance (the reference forces compute_cov3D_python, /root/reference/train.py:49; here built inside the
 rasterizer's preprocess kernel from the raw parameters) -> render() forward (HIP) -> 0.8 L1 + 0.2 (1 - SSIM) ->
@@ -14,9 +15,15 @@ backward (HIP + autograd) -> Adam; replayed from one hipGraph per step (`--no-gr
 Frames are sharded round-robin over ranks (1 frame per GPU per step); ranks exchange only
 scalars (loss / PSNR sums) through one RCCL all-reduce; `value` = steps of all ranks / max-over-ranks time.
 
+Second leg, `fine_all_shape` in the same JSON line (BASELINE.json config 4, /root/reference/trainers/fine_all.py:74-101): 30 % of
+the Gaussians are the object; every frame carries its own accumulated object rotation and a hand mask; the step is
+render(..., rot_cov=True, accum_R=R_k, which_object=1) -> hand-mask-gated loss -> backward -> Adam, replayed from its own
+hipGraph.  Same sharding, same timing rules.  `--dynamic` makes that leg the headline instead (the static one is then skipped).
+
 The JSON line also carries
   roofline      the dominant rasterizer stage: algorithmic bytes per launch / its mean duration, measured with HIP
-                events recorded by the library on the launch stream inside the timed region;
+                events recorded by the library on the launch stream inside the timed region; pixel-splat pair throughput;
+                HBM traffic and VALU counters from profiles/*.json when those were collected on THESE kernel sources;
   stages        the same for every stage (ms per launch, GB/s algorithmic);
   cpu_baseline  the C oracle (oracle/raster_oracle.c, "port") timed on this box's host cores on a bounded sample of
                 forward+backward passes of the same workload (rank 0, N = 1 only).
@@ -25,6 +32,7 @@ import argparse
 import json
 import math
 import os
+import socket
 import sys
 import time
 
@@ -36,7 +44,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+CLOCK_HZ, N_SIMD = 2.4e9, 1024  # same guide: 2400 MHz max clock, 256 CUs x 4 SIMDs
+VALU_CYCLES_PER_WAVE_INSTR = 2.4   # tools/ubench/valu_rate.hip at 8 waves/SIMD
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+SQ_FILE = os.path.join(ROOT, "profiles", "sq_counters.json")
 
 
 def algorithmic_bytes(stage, N, R, npix, sh_coeffs=1):
@@ -52,6 +63,50 @@ def algorithmic_bytes(stage, N, R, npix, sh_coeffs=1):
     }[stage]
 
 
+def spawn_command(gpus, argv, port=None):
+    """The command a plain `python bench.py --gpus N` re-executes itself as (one rank per GPU, rendezvous on 127.0.0.1)."""
+    if port is None:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def stamped(path, key, current_hash):
+    """Counter file -> (entry for the workload `key`, None) when it was collected on the present kernel sources, else (None, reason)."""
+    if not os.path.exists(path):
+        return None, f"{os.path.basename(path)} absent"
+    try:
+        data = json.load(open(path))
+    except Exception as exc:
+        return None, f"{os.path.basename(path)} unreadable ({type(exc).__name__})"
+    h = data.get("_source_hash")
+    if h != current_hash:
+        return None, f"{os.path.basename(path)} was collected at kernel-source hash {h}, the library is now {current_hash}"
+    ent = data.get(key)
+    return (ent, None) if ent else (None, f"{os.path.basename(path)} has no entry for {key}")
+
+
+def object_rotation(k, device):
+    """Accumulated object rotation of frame k of the synthetic fine_all sequence (the object turns while the camera orbits)."""
+    from egogaussian_amd.scene_synth import N_FRAMES
+    ph = 2.0 * math.pi * (k % N_FRAMES) / N_FRAMES
+    ax, ay, az = 0.35 * math.sin(ph), 0.5 * math.sin(2 * ph), 0.25 * (1 - math.cos(ph))
+    cx, sx, cy, sy, cz, sz = math.cos(ax), math.sin(ax), math.cos(ay), math.sin(ay), math.cos(az), math.sin(az)
+    R = (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+         @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    return torch.tensor(R, dtype=torch.float32, device=device)
+
+
+def hand_gate(k, H, W, device):
+    """1 - hand mask of frame k: a hand-sized box (a quarter of the width, a third of the height) wandering over the image."""
+    from egogaussian_amd.scene_synth import N_FRAMES
+    ph = 2.0 * math.pi * (k % N_FRAMES) / N_FRAMES
+    cx, cy = int(W * (0.5 + 0.3 * math.cos(ph))), int(H * (0.6 + 0.25 * math.sin(2 * ph)))
+    g = torch.ones((H, W), device=device)
+    g[max(cy - H // 6, 0):cy + H // 6, max(cx - W // 8, 0):cx + W // 8] = 0.0
+    return g
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,12 +117,18 @@ def main():
     ap.add_argument("--width", type=int, default=960)
     ap.add_argument("--sh-degree", type=int, default=0, help="spherical-harmonics degree of the colours (0..3; the reference ends training at 3)")
     ap.add_argument("--no-sh3-leg", action="store_true", help="skip the extra SH-degree-3 measurement of the default single-GPU run")
+    ap.add_argument("--no-fine-all-leg", action="store_true", help="skip the fine_all-shaped (dynamic object) leg")
+    ap.add_argument("--dynamic", action="store_true", help="headline = the fine_all call shape (rot_cov + accum_R + hand-mask gate) instead of the static step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op-only", action="store_true", help="time rasterizer fwd+bwd only (seeded upstream grads)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every step from Python instead of replaying a captured hipGraph")
     ap.add_argument("--torch-host-ops", action="store_true",
                     help="build cov3D and the loss with PyTorch ops (as the reference does) instead of the fused HIP kernels")
+    ap.add_argument("--verify-ranks", action="store_true", help="add per-rank frame lists, start-of-run parameter checksums and loss sums to the JSON line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # launched plainly: become N ranks
+        os.execv(sys.executable, spawn_command(args.gpus, sys.argv[1:]))
 
     from egogaussian_amd import dist as egs_dist
     rank, world, local_rank = egs_dist.env_world()
@@ -84,116 +145,177 @@ def main():
     from egogaussian_amd.renderer import render
     from egogaussian_amd.losses import training_loss, psnr
     from egogaussian_amd.fused import l1_ssim_loss
+    from egogaussian_amd.optim import FusedAdam
+    from egogaussian_amd.graph import GraphedTrainStep, pack_frame
     egs_lib.load()
 
     N, H, W = args.gaussians, args.height, args.width
     D = args.sh_degree
     teacher = make_scene(N, H, W, seed=0, sh_degree=D)
     student = perturb_student(teacher)
+    is_object = (np.random.default_rng(5).uniform(size=(N, 1)) < 0.3).astype(np.float32)      # fine_all leg: 30 % object Gaussians
     bg = torch.zeros(3, device=dev)
     my_frames = egs_dist.shard_frames(N_FRAMES, rank, world)
     n_used = min(len(my_frames), args.warmup + args.steps)
-    cams = [make_camera(k, H, W, device=dev) for k in my_frames[:n_used]]
-
-    with torch.no_grad():                                      # ground truth = teacher rendered by the same path
-        tpc = SynthGaussians(teacher, device=dev, sh_degree=D, requires_grad=False)
-        gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
-        del tpc
-    pc = SynthGaussians(student, device=dev, sh_degree=D, fused=not args.torch_host_ops)
-    from egogaussian_amd.optim import FusedAdam
-    use_graph = not (args.no_graph or args.torch_host_ops or args.op_only)
-    Adam = (lambda g, **kw: torch.optim.Adam(g, fused=True, **kw)) if args.torch_host_ops else \
-        (lambda g, **kw: FusedAdam(g, capturable=use_graph, **kw))
-    opt = Adam([                                                # /root/reference/scene/gaussian_model.py:180-198 defaults
-        {"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3},
-        *([{"params": [pc._features_rest], "lr": 2.5e-3 / 20.0}] if D > 0 else []),
-        {"params": [pc._opacity], "lr": 0.05}, {"params": [pc._scaling], "lr": 5e-3},
-        {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15)
-
-    def eval_psnr():
-        with torch.no_grad():
-            vals = [psnr(render(cams[i], pc, Pipe, bg)["render"][None], gts[i][None]).item() for i in range(min(4, n_used))]
-        return float(np.mean(vals))
-
+    frame_ids = my_frames[:n_used]
+    cams = [make_camera(k, H, W, device=dev) for k in frame_ids]
+    # held-out views: eight half-frame phases spread over the orbit; no rank ever trains on them
+    held_cams = [make_camera(k + 0.5, H, W, device=dev) for k in range(18, N_FRAMES, N_FRAMES // 8)][:8]
     g = torch.Generator().manual_seed(1234)
     up_c, up_d, up_a = [torch.rand(s, generator=g).to(dev) for s in ((3, H, W), (1, H, W), (1, H, W))]
-    loss_acc = torch.zeros((), device=dev)
-    r_sum = [0, 0]
 
-    def step(i):
-        k = i % n_used
-        out = render(cams[k], pc, Pipe, bg)
-        if args.op_only:
-            loss = (out["render"] * up_c).sum() + (out["depth"] * up_d).sum() + (out["alpha"] * up_a).sum()
-        elif args.torch_host_ops:
-            loss = training_loss(out["render"], gts[k])
-        else:
-            loss = l1_ssim_loss(out["render"], gts[k], 0.2)
-        loss.backward()
-        if not args.op_only:
-            opt.step()
-        opt.zero_grad(set_to_none=True)
-        loss_acc.add_(loss.detach())
-        r_sum[0] += _C.stats["num_rendered"]; r_sum[1] += 1
+    def run_leg(dynamic):
+        """One measured leg: build teacher / student, capture, warm up, time args.steps steps.  -> dict of per-rank results."""
+        rot = [object_rotation(k, dev) for k in frame_ids] if dynamic else None
+        gates = [hand_gate(k, H, W, dev) for k in frame_ids] if dynamic else None
+        held_rot = [object_rotation(k + 0.5, dev) for k in range(18, N_FRAMES, N_FRAMES // 8)][:8] if dynamic else None
+        rkw = lambda R: dict(rot_cov=True, accum_R=R, which_object=1, during_training=False) if dynamic else {}
 
-    psnr_start = eval_psnr()
-    graphed = None
-    eager_step = step
-    if use_graph:                                               # the whole iteration as one hipGraph (egogaussian_amd/graph.py)
-        from egogaussian_amd.graph import GraphedTrainStep
-        try:
-            graphed = GraphedTrainStep(pc, opt, bg, 0.2).capture(cams[0], gts[0], warmup=2)
-        except Exception as exc:                                # keep measuring, eagerly, rather than lose the run
-            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); stepping eagerly", file=sys.stderr)
-            graphed, use_graph = None, False
+        with torch.no_grad():                                      # ground truth = teacher rendered by the same path
+            tpc = SynthGaussians(teacher, device=dev, sh_degree=D, requires_grad=False)
+            tpc._is_object = torch.tensor(is_object, device=dev)
+            gts = [render(c, tpc, Pipe, bg, **rkw(rot[i] if dynamic else None))["render"].clone() for i, c in enumerate(cams)]
+            held_gts = [render(c, tpc, Pipe, bg, **rkw(held_rot[i] if dynamic else None))["render"].clone() for i, c in enumerate(held_cams)]
+            del tpc
+        pc = SynthGaussians(student, device=dev, sh_degree=D, fused=not args.torch_host_ops)
+        pc._is_object = torch.tensor(is_object, device=dev)
+        use_graph = not (args.no_graph or args.torch_host_ops or args.op_only)
+        Adam = (lambda gr, **kw: torch.optim.Adam(gr, fused=True, **kw)) if args.torch_host_ops else \
+            (lambda gr, **kw: FusedAdam(gr, capturable=use_graph, **kw))
+        opt = Adam([                                                # /root/reference/scene/gaussian_model.py:180-198 defaults
+            {"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3},
+            *([{"params": [pc._features_rest], "lr": 2.5e-3 / 20.0}] if D > 0 else []),
+            {"params": [pc._opacity], "lr": 0.05}, {"params": [pc._scaling], "lr": 5e-3},
+            {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15)
+        with torch.no_grad():
+            checksum = float(sum(p.double().sum().item() for p in (pc._xyz, pc._features_dc, pc._opacity, pc._scaling, pc._rotation)))
+
+        def eval_psnr():
+            """Mean PSNR over the held-out views (/root/reference/utils/image_utils.py:17-19)."""
+            with torch.no_grad():
+                vals = [psnr(render(c, pc, Pipe, bg, **rkw(held_rot[i] if dynamic else None))["render"][None], held_gts[i][None]).item()
+                        for i, c in enumerate(held_cams)]
+            return float(np.mean(vals))
+
+        loss_acc = torch.zeros((), device=dev)
+        r_sum = [0, 0]
+
+        def eager_step(i):
+            k = i % n_used
+            out = render(cams[k], pc, Pipe, bg, **rkw(rot[k] if dynamic else None))
+            if args.op_only:
+                loss = (out["render"] * up_c).sum() + (out["depth"] * up_d).sum() + (out["alpha"] * up_a).sum()
+            elif args.torch_host_ops:
+                img = out["render"]
+                if dynamic:
+                    gk = gates[k]
+                    img.register_hook(lambda grad: grad * gk)
+                loss = training_loss(img, gts[k])
+            else:
+                loss = l1_ssim_loss(out["render"], gts[k], 0.2, grad_gate=gates[k] if dynamic else None)
+            loss.backward()
+            if not args.op_only:
+                opt.step()
+            opt.zero_grad(set_to_none=True)
+            loss_acc.add_(loss.detach())
+            r_sum[0] += _C.stats["num_rendered"]; r_sum[1] += 1
+
+        psnr_start = eval_psnr()
+        step, graphed = eager_step, None
+        if use_graph:                                               # the whole iteration as one hipGraph (egogaussian_amd/graph.py)
+            try:
+                graphed = GraphedTrainStep(pc, opt, bg, 0.2, dynamic=dynamic, gated=dynamic)
+                graphed.capture(cams[0], gts[0], warmup=2, accum_R=rot[0] if dynamic else None, gate=gates[0] if dynamic else None,
+                                capacity_cams=cams[::max(1, n_used // 6)])
+            except Exception as exc:                                # keep measuring, eagerly, rather than lose the run
+                print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); stepping eagerly", file=sys.stderr)
+                graphed, use_graph = None, False
+            if graphed is not None:
+                # resident: image + camera block (+ object rotation + gate), one copy per replay
+                frames = [pack_frame(c, g_, rot[i] if dynamic else None, gates[i] if dynamic else None) for i, (c, g_) in enumerate(zip(cams, gts))]
+
+                def step(i):                                        # noqa: F811
+                    graphed(frames[i % n_used])                      # (the captured step adds its loss to graphed.loss_sum itself)
+                    r_sum[1] += 1
+        for i in range(args.warmup):
+            step(i)
+        loss_acc.zero_(); r_sum[:] = [0, 0]
         if graphed is not None:
-            from egogaussian_amd.graph import pack_frame
-            frames = [pack_frame(c, g_) for c, g_ in zip(cams, gts)]      # resident: image + camera block, one copy per replay
-
-            def step(i):                                        # noqa: F811
-                graphed(frames[i % n_used])                      # (the captured step adds its loss to graphed.loss_sum itself)
-                r_sum[1] += 1
-    for i in range(args.warmup):
-        step(i)
-    loss_acc.zero_(); r_sum[:] = [0, 0]
-    if graphed is not None:
-        graphed.loss_sum.zero_()
-    torch.cuda.synchronize()
-    egs_dist.barrier()
-    egs_lib.profile_begin(max_records=min(200000, 16 * (args.steps + 8)))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    egs_dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    stages = egs_lib.profile_end()
-    stage_timing = "HIP events recorded by the library on the launch stream inside the timed region"
-    if graphed is not None:
-        assert graphed.ok(), f"a replayed frame exceeded the captured capacity ({graphed.max_instances()} > {graphed.capacity})"
-        # Kernels replayed from a hipGraph are not bracketed by the library's events (those are host-side records), so the
-        # per-stage durations come from a second, eager timed pass over the same workload right after the replayed one.
-        n_ev = min(args.steps, 50)
-        loss_acc.copy_(graphed.loss_sum)
-        saved = (loss_acc.clone(), list(r_sum))
-        r_sum[:] = [0, 0]
+            graphed.loss_sum.zero_()
         torch.cuda.synchronize()
-        egs_lib.profile_begin(max_records=16 * (n_ev + 8))
-        for i in range(n_ev):
-            eager_step(args.warmup + args.steps + i)
+        egs_dist.barrier()
+        egs_lib.profile_begin(max_records=min(200000, 16 * (args.steps + 8)))
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        egs_dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
         stages = egs_lib.profile_end()
-        r_mean_eager = float(r_sum[0]) / max(r_sum[1], 1)
-        loss_acc.copy_(saved[0]); r_sum[:] = [int(r_mean_eager * saved[1][1]), saved[1][1]]
-        stage_timing = f"HIP events recorded by the library on the launch stream over {n_ev} eager steps of the same workload, run inside bench.py right after the graph-replayed timed region"
-    psnr_end = eval_psnr()
+        stage_timing = "HIP events recorded by the library on the launch stream inside the timed region"
+        overflow = None
+        if graphed is not None:
+            overflow = {"capacity": graphed.capacity, "max_instances": graphed.max_instances(), "ok": graphed.ok()}
+            assert graphed.ok(), f"a replayed frame exceeded the captured capacity ({graphed.max_instances()} > {graphed.capacity}); its update was skipped"
+            # Kernels replayed from a hipGraph are not bracketed by the library's events (those are host-side records), so the
+            # per-stage durations come from a second, eager timed pass over the same workload right after the replayed one.
+            n_ev = min(args.steps, 50)
+            loss_acc.copy_(graphed.loss_sum)
+            saved = (loss_acc.clone(), list(r_sum))
+            r_sum[:] = [0, 0]
+            torch.cuda.synchronize()
+            egs_lib.profile_begin(max_records=16 * (n_ev + 8))
+            for i in range(n_ev):
+                eager_step(args.warmup + args.steps + i)
+            torch.cuda.synchronize()
+            stages = egs_lib.profile_end()
+            r_mean_eager = float(r_sum[0]) / max(r_sum[1], 1)
+            loss_acc.copy_(saved[0]); r_sum[:] = [int(r_mean_eager * saved[1][1]), saved[1][1]]
+            stage_timing = f"HIP events recorded by the library on the launch stream over {n_ev} eager steps of the same workload, run inside bench.py right after the graph-replayed timed region"
+        psnr_end = eval_psnr()
+        # instances that survive tile culling (what the sort and the blend kernels process), pixel-splat pairs Q and (wave, splat)
+        # visits of the forward blend: sampled on four frames
+        kept = rect = pairs = visits = 0
+        with torch.no_grad():
+            for i in range(0, n_used, max(1, n_used // 4)):
+                render(cams[i], pc, Pipe, bg, **rkw(rot[i] if dynamic else None))
+                kept += int(_C.stats["total_view"].item()); rect += _C.stats["num_rendered"]
+                iv = _C.image_views(_C.stats["image_buffer"], W, H)
+                pairs += int(iv["quad_pairs"].sum().item()); visits += int(iv["quad_visits"].sum().item())
+        n_s = len(range(0, n_used, max(1, n_used // 4)))
+        return dict(elapsed=elapsed, stages=stages, stage_timing=stage_timing, loss=loss_acc.item(), psnr_end=psnr_end, psnr_start=psnr_start,
+                    R_mean=float(r_sum[0]) / max(r_sum[1], 1), kept_ratio=kept / max(rect, 1), pairs=pairs / n_s, visits=visits / n_s,
+                    use_graph=use_graph, checksum=checksum, overflow=overflow, pc=pc, cams=cams)
 
-    elapsed_max = egs_dist.reduce_scalars([elapsed], dev, "max")[0]          # max over ranks of the timed region
-    sums = egs_dist.reduce_scalars([loss_acc.item(), psnr_end, psnr_start, float(r_sum[0]) / max(r_sum[1], 1)], dev, "sum")
-    mean_loss = sums[0] / (world * args.steps)                                # scalar metrics only (RCCL over xGMI)
-    psnr_e, psnr_s, R_mean = sums[1] / world, sums[2] / world, sums[3] / world
+    def reduce_leg(r):
+        """Scalars only (RCCL over xGMI): max-over-ranks time, sums of loss / PSNR / instance counts."""
+        elapsed_max = egs_dist.reduce_scalars([r["elapsed"]], dev, "max")[0]
+        sums = egs_dist.reduce_scalars([r["loss"], r["psnr_end"], r["psnr_start"], r["R_mean"]], dev, "sum")
+        return dict(elapsed_max=elapsed_max, mean_loss=sums[0] / (world * args.steps), psnr=sums[1] / world, psnr_before=sums[2] / world,
+                    R_mean=sums[3] / world)
+
+    legs = {}
+    if not args.dynamic:
+        legs["static"] = run_leg(False)
+        legs["static"]["red"] = reduce_leg(legs["static"])
+    if args.dynamic or not (args.no_fine_all_leg or args.op_only or args.torch_host_ops or args.no_graph or D > 0):
+        legs["dynamic"] = run_leg(True)
+        legs["dynamic"]["red"] = reduce_leg(legs["dynamic"])
+    head_name = "dynamic" if args.dynamic else "static"
+    head, red = legs[head_name], legs[head_name]["red"]
+
+    ranks_info = None
+    if args.verify_ranks:
+        import torch.distributed as tdist
+        mine = {"rank": rank, "frames": frame_ids, "param_checksum_start": head["checksum"], "loss_sum": head["loss"], "steps": args.steps,
+                "device": str(dev), "graph": head["use_graph"], "overflow": head["overflow"]}
+        if world > 1:
+            ranks_info = [None] * world
+            tdist.all_gather_object(ranks_info, mine)
+        else:
+            ranks_info = [mine]
 
     if rank != 0:
         egs_dist.shutdown()
@@ -201,13 +323,9 @@ def main():
 
     npix = H * W
     passes = _C.binning_passes(N, W, H)
-    # instances that survive tile culling (what the sort and the blend kernels process): sampled on four frames
-    kept, rect = 0, 0
-    with torch.no_grad():
-        for i in range(min(4, n_used)):
-            render(cams[i], pc, Pipe, bg)
-            kept += int(_C.stats["total_view"].item()); rect += _C.stats["num_rendered"]
-    R_kept = R_mean * kept / max(rect, 1)
+    stages = head["stages"]
+    R_mean = red["R_mean"]
+    R_kept = R_mean * head["kept_ratio"]
     stage_rows, dominant = {}, None
     for name, (ms, n) in stages.items():
         if n == 0:
@@ -218,42 +336,51 @@ def main():
                             "alg_GBps": round(ab / (per * 1e-3) / 1e9, 1), "frac_hbm": round(ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if dominant is None or per * n > stages[dominant][0]:
             dominant = name
-    traffic = None
-    if os.path.exists(PMC_FILE):
-        try:
-            pmc = json.load(open(PMC_FILE))
-            ent = pmc.get(f"{N}@{W}x{H}", {}).get(dominant)
-            traffic = ent["hbm_bytes_per_launch"] if ent else None
-        except Exception:
-            traffic = None
-    valu_busy = None                                             # SQ counters of the same workload (profiles/sq_counters.json)
-    sq_file = os.path.join(os.path.dirname(PMC_FILE), "sq_counters.json")
-    if os.path.exists(sq_file):
-        try:
-            valu_busy = json.load(open(sq_file)).get(f"{N}@{W}x{H}", {}).get(dominant, {}).get("valu_busy")
-        except Exception:
-            valu_busy = None
+    # counters collected by rocprofv3 --pmc in runs of their own (tools/collect_counters.py): valid for THESE kernels only
+    src_hash = egs_lib.kernel_source_hash()
+    key = f"{N}@{W}x{H}"
+    pmc, why_pmc = stamped(PMC_FILE, key, src_hash)
+    sq, why_sq = stamped(SQ_FILE, key, src_hash)
+    traffic = (pmc or {}).get(dominant, {}).get("hbm_bytes_per_launch") if pmc else None
+    sq_dom = (sq or {}).get(dominant) if sq else None
     d = stage_rows[dominant]
+    t_dom = d["ms_per_launch"] * 1e-3
+    issue_frac = None
+    if sq_dom and sq_dom.get("valu_wave_instructions"):
+        # share of the chip's VALU issue capacity the kernel's vector instructions account for: wave-instructions x measured
+        # cycles per wave-instruction / (SIMDs x clock x kernel time)
+        issue_frac = round(sq_dom["valu_wave_instructions"] * VALU_CYCLES_PER_WAVE_INSTR / (N_SIMD * CLOCK_HZ * t_dom), 4)
+    pair_rows = {}
+    for st_name in ("render_forward", "render_backward"):
+        if st_name in stage_rows:
+            pair_rows[st_name] = round(head["pairs"] / (stage_rows[st_name]["ms_per_launch"] * 1e-3) / 1e9, 2)
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": d["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(d["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": traffic, "valu_busy": valu_busy,
-                "ms_per_launch": d["ms_per_launch"], "alg_bytes_per_launch": int(d["alg_MB"] * 1e6), "timing": stage_timing,
-                "note": "blend stages are VALU-issue-bound (per pixel-splat pair work; valu_busy = measured VALUBusy of this kernel), not HBM-bound; "
-                        "see `stages` for the streaming kernels"}
+                "frac": round(d["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_note": why_pmc or "profiles/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes, same kernel sources",
+                "valu_busy": (sq_dom or {}).get("valu_busy"), "issue_frac": issue_frac,
+                "counters_note": why_sq or "profiles/sq_counters.json: SQ counters of the same kernel sources",
+                "kernel_source_hash": src_hash,
+                "pairs_Q": int(head["pairs"]), "visits": int(head["visits"]), "lanes_kept_per_visit": round(head["pairs"] / max(head["visits"], 1), 2),
+                "pairs_per_s_G": pair_rows,
+                "ms_per_launch": d["ms_per_launch"], "alg_bytes_per_launch": int(d["alg_MB"] * 1e6), "timing": head["stage_timing"],
+                "note": "blend stages are VALU-issue-bound (per pixel-splat pair work), not HBM-bound: pairs_Q = (pixel, splat) pairs one frame "
+                        "blends, visits = (8x8-pixel wave, splat) iterations of the forward; see `stages` for the streaming kernels"}
     op_ms = sum(ms / n for ms, n in stages.values() if n)
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         from oracle.oracle import Oracle
+        pc, ccams = head["pc"], head["cams"]
         cores = os.cpu_count() or 1
         with torch.no_grad():
             inp = dict(means3D=pc.get_xyz.cpu(), opacities=pc.get_opacity.cpu(), shs=pc.get_features.cpu(),
-                       cov3D_precomp=pc.get_covariance().cpu(), viewmatrix=cams[0].world_view_transform.cpu(),
-                       projmatrix=cams[0].full_proj_transform.cpu(), campos=cams[0].camera_center.cpu(), bg=bg.cpu(),
-                       image_height=H, image_width=W, tanfovx=math.tan(cams[0].FoVx / 2), tanfovy=math.tan(cams[0].FoVy / 2))
+                       cov3D_precomp=pc.get_covariance().cpu(), viewmatrix=ccams[0].world_view_transform.cpu(),
+                       projmatrix=ccams[0].full_proj_transform.cpu(), campos=ccams[0].camera_center.cpu(), bg=bg.cpu(),
+                       image_height=H, image_width=W, tanfovx=math.tan(ccams[0].FoVx / 2), tanfovy=math.tan(ccams[0].FoVy / 2))
         o = Oracle(np.float32, nthreads=cores)
         n_cpu, tcpu = 0, 0.0
         while n_cpu < 4 or (tcpu < 10.0 and n_cpu < 64):                  # a bounded sample: >= 4 frames and >= 10 s of wall clock
-            cam = cams[n_cpu % n_used]
+            cam = ccams[n_cpu % n_used]
             inp.update(viewmatrix=cam.world_view_transform.cpu(), projmatrix=cam.full_proj_transform.cpu(), campos=cam.camera_center.cpu())
             tc = time.perf_counter()
             st = o.forward(**inp)
@@ -265,24 +392,39 @@ def main():
                          f"{N}@{W}x{H} workload, oracle/raster_oracle.c with OpenMP over tiles ({tcpu:.1f} s of wall clock on {cores} cores)"}
 
     total_steps = world * args.steps
+    step_text = {
+        "static": ("rasterizer fwd+bwd only (seeded upstream grads on colour/depth/alpha)" if args.op_only else
+                   ("cov3D(torch) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) (torch) + bwd + Adam" if args.torch_host_ops else
+                    "render fwd (HIP; activations and cov3D inside its preprocess kernel) + 0.8 L1 + 0.2 (1-SSIM) (HIP) + bwd (HIP+autograd) + Adam (HIP)")),
+        "dynamic": "fine_all shape: object-rotated cov3D + opacity (HIP, one launch) + render(rot_cov=True, accum_R=R_k, which_object=1) fwd (HIP) + "
+                   "hand-mask-gated 0.8 L1 + 0.2 (1-SSIM) (HIP) + bwd + Adam (HIP); 30 % object Gaussians"}
     out = {
         "metric": "train iters/s (fwd+bwd render) + PSNR, 500k Gaussians @ 960x540",
-        "value": round(total_steps / elapsed_max, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed_max / args.steps, 4), "higher_is_better": True,
+        "value": round(total_steps / red["elapsed_max"], 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * red["elapsed_max"] / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"S({N},{H},{W},seed0) teacher/student, 300-frame orbit, 1 frame per GPU per step; step = "
-                               + ("rasterizer fwd+bwd only (seeded upstream grads on colour/depth/alpha)" if args.op_only else
-                                  ("cov3D(torch) + render fwd (HIP) + 0.8 L1 + 0.2 (1-SSIM) (torch) + bwd + Adam" if args.torch_host_ops else
-                                   "render fwd (HIP; activations and cov3D inside its preprocess kernel) + 0.8 L1 + 0.2 (1-SSIM) (HIP) + bwd (HIP+autograd) + Adam (HIP)")),
+        "config": {"workload": f"S({N},{H},{W},seed0) teacher/student, 300-frame orbit, 1 frame per GPU per step; step = " + step_text[head_name],
                    "gaussians": N, "image": [H, W], "sh_degree": D, "instances_R": int(R_mean), "instances_after_tile_culling": int(R_kept),
                    "sort_passes_max": passes,
                    "parallelism": f"frames sharded over {world} GPU(s), scalar all-reduce only",
-                   "launch": "one hipGraph replay per step" if use_graph else "eager (one launch per kernel)"},
-        "psnr_db": round(psnr_e, 3), "psnr_db_before": round(psnr_s, 3), "mean_loss": round(mean_loss, 6),
+                   "launch": "one hipGraph replay per step" if head["use_graph"] else "eager (one launch per kernel)"},
+        "psnr_db": round(red["psnr"], 3), "psnr_db_before": round(red["psnr_before"], 3),
+        "psnr_views": "8 held-out views at half-frame phases across the orbit (never trained on)", "mean_loss": round(red["mean_loss"], 6),
         "rasterizer_ms_per_step": round(op_ms, 4),
         "roofline": roofline, "stages": stage_rows, "cpu_baseline": cpu,
     }
-    if world == 1 and D == 0 and not args.no_sh3_leg and not (args.op_only or args.torch_host_ops or args.no_graph):
+    if head_name == "static" and "dynamic" in legs:
+        dl, dr = legs["dynamic"], legs["dynamic"]["red"]
+        out["fine_all_shape"] = {
+            "value": round(total_steps / dr["elapsed_max"], 3), "unit": "iters/s", "ms_per_step": round(1e3 * dr["elapsed_max"] / args.steps, 4),
+            "steps": args.steps, "n_gpus": world, "psnr_db": round(dr["psnr"], 3), "psnr_db_before": round(dr["psnr_before"], 3),
+            "mean_loss": round(dr["mean_loss"], 6), "instances_R": int(dr["R_mean"]),
+            "stages_ms": {k: round(ms / n, 4) for k, (ms, n) in dl["stages"].items() if n},
+            "launch": "one hipGraph replay per step" if dl["use_graph"] else "eager", "step": step_text["dynamic"],
+            "reference": "/root/reference/trainers/fine_all.py:74-101 (BASELINE.json config 4)"}
+    if ranks_info is not None:
+        out["ranks"] = ranks_info
+    if world == 1 and D == 0 and not args.no_sh3_leg and not (args.op_only or args.torch_host_ops or args.no_graph or args.dynamic):
         # The same step with the colour model the reference ends training with (max_sh_degree = 3: 16 coefficients per channel,
         # /root/reference/arguments/__init__.py), measured by this script in a child process on the same GPU and reported beside
         # the headline (which stays on the degree-0 workload the earlier rounds and the profiles were measured on).

@@ -14,20 +14,24 @@ import torch
 from . import lib as _lib
 
 
-stats = {"num_rendered": 0, "capacity": 0, "retries": 0}       # of the most recent forward (read by bench.py / tests)
+# Diagnostics of the most recent forward of this process (instance count, capacity, retries, the device-side total, the image
+# buffer for the measurement views).  Read by bench.py, tools and tests; NOT part of any data path -- nothing the package
+# computes depends on it.
+stats = {"num_rendered": 0, "capacity": 0, "retries": 0}
 _capacity_hint = {}                # device index -> instance capacity the next forward is enqueued against
 _pinned_counts = {}                # device index -> page-locked host buffer for the per-workgroup instance counts
-_running_max = {}                  # device index -> int64[1] device tensor raised to the instance count of every captured forward
 
 
-def set_running_max(device, tensor):
-    """While a training step is being captured (egogaussian_amd/graph.py): the device word that every replayed forward raises
-    to its instance count when that is larger.  None switches the tracking off."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    if tensor is None:
-        _running_max.pop(key, None)
-    else:
-        _running_max[key] = tensor
+class StepGuard:
+    """Device words a captured training step shares between its forward, backward and optimizer launches (include/egs_raster.h,
+    "overflow word"):  `overflow` uint32[2] -- written by every forward: [0] = 1 when the frame needed more instances than the captured
+    capacity (its image is clipped), else 0, [1] = the frame's instance count; the backward's fused statistics and FusedAdam(capturable) read it and do nothing
+    for such a frame.  `running_max` int64[1] -- raised to the instance count of every forward, so one host read tells whether
+    ANY replay overflowed and by how much."""
+
+    def __init__(self, device):
+        self.overflow = torch.zeros(2, dtype=torch.int32, device=device)      # [0] flag, [1] instance count of the latest frame
+        self.running_max = torch.zeros(1, dtype=torch.int64, device=device)
 
 
 def binning_passes(P, W, H):
@@ -90,8 +94,10 @@ ACT_RAW_PARAMETERS = ACT_LOG_SCALES | ACT_RAW_QUATS | ACT_LOGIT_OPACITY
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, activation_flags=0, sh_rest=None):
+                        prefiltered, debug, activation_flags=0, sh_rest=None, active_count=None, guard=None):
     """-> (num_rendered, color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer)
+    active_count (extension): int32[1] device tensor, the number of live rows of a capacity-sized model (include/egs_raster.h);
+    guard (extension): a StepGuard whose words a captured forward writes.
     sh_rest (extension): `sh` is then the DC block [P,1,3] and `sh_rest` the other coefficients [P,M-1,3] -- the two parameters the
     reference's GaussianModel stores, without the torch.cat of get_features (include/egs_raster.h: split spherical harmonics)."""
     L = _lib.load()
@@ -105,6 +111,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     colors, scales, rotations = _opt(_f32c(colors, "colors")), _opt(_f32c(scales, "scales")), _opt(_f32c(rotations, "rotations"))
     cov3D_precomp, sh = _opt(_f32c(cov3D_precomp, "cov3D_precomp")), _opt(_f32c(sh, "sh"))
     sh_rest = _opt(_f32c(sh_rest, "sh_rest"))
+    if active_count is not None and not (active_count.is_cuda and active_count.dtype == torch.int32 and active_count.numel() == 1):
+        raise RuntimeError("active_count: an int32[1] tensor on the rasterizer's device")
     M = 0 if sh is None else sh.shape[1]
     if sh_rest is not None:
         if sh is None or sh.shape[1] != 1 or sh_rest.shape[0] != P:
@@ -139,7 +147,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), _ptr(background), W, H,
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
-                _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), None, _ptr(_running_max.get(key)), _stream()))
+                _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), None, _ptr(None if guard is None else guard.running_max),
+                _ptr(active_count), _ptr(None if guard is None else guard.overflow), _stream()))
             R = C.c_int64(cap)                      # layout size; the true count is stats["total_view"] after a sync
             rc = 0
         else:
@@ -147,7 +156,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
                                _ptr(campos), _ptr(background), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                                _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img), _ptr(out_color), _ptr(out_depth),
-                               _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _stream(), int(bool(debug)))
+                               _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _ptr(active_count), _stream(), int(bool(debug)))
         if rc == _lib.RETRY_LARGER:
             cap = int(R.value * 1.25) + 65536
             binning = torch.empty((L.egs_binning_bytes(P, cap, W, H),), device=dev, dtype=torch.uint8)
@@ -160,27 +169,33 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         stats["capacity"] = cap
     stats["num_rendered"] = int(R.value)
     stats["P"] = P
+    stats["image_buffer"] = img
     if cap > 0:                                     # device-side instance count of this forward (int64[1] view, for graph replays)
         lay = _lib.BinningLayout()
         L.egs_get_binning_layout(P, cap, W, H, C.byref(lay))
         stats["total_view"] = binning[lay.total:lay.total + 8].view(torch.int64)
-    if P:                                           # radii > 0 as a torch.bool view of bytes the preprocess kernel wrote (no compare kernel)
-        glay = _lib.GeomLayout()
-        L.egs_get_geom_layout(P, C.byref(glay))
-        stats["visible_view"] = geom[glay.visible:glay.visible + P].view(torch.bool)
-    else:
-        stats["visible_view"] = torch.zeros(0, dtype=torch.bool, device=dev)
     return int(R.value), out_color, out_depth, out_alpha, radii, geom, binning, img
+
+
+def visible_view(geom, P):
+    """radii > 0 as a torch.bool VIEW of the bytes the preprocess kernel wrote into the geometry buffer (no compare kernel).  It
+    aliases `geom`, which the backward reads: treat it as read-only."""
+    if P == 0:
+        return torch.zeros(0, dtype=torch.bool, device=geom.device)
+    glay = _lib.GeomLayout()
+    _lib.check(_lib.load().egs_get_geom_layout(int(P), C.byref(glay)))
+    return geom[glay.visible:glay.visible + P].view(torch.bool)
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alpha,
-                                 debug, activation_flags=0, sh_rest=None, densify_stats=None):
+                                 debug, activation_flags=0, sh_rest=None, densify_stats=None, guard=None):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
            dL_dscales[P,3], dL_drotations[P,4]); with sh_rest, dL_dsh is [P,1,3] and a ninth element dL_dsh_rest[P,M-1,3] follows.
     densify_stats (extension): (xyz_gradient_accum[P,1], denom[P,1], max_radii2D[P] or None), float32, updated in place by the kernel
-    that produces dL_dmeans2D (include/egs_raster.h) -- the caller then skips its add_densification_stats for this iteration."""
+    that produces dL_dmeans2D (include/egs_raster.h) -- the caller then skips its add_densification_stats for this iteration.
+    guard (extension): the StepGuard of the forward; the statistics are left untouched when its overflow word is set."""
     L = _lib.load()
     means3D = _f32c(means3D, "means3D")
     dev = means3D.device
@@ -212,7 +227,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
                 _ptr(imageBuffer), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(dmeans2D), _ptr(dcolors),
                 _ptr(dopacity), _ptr(dmeans3D), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
-                _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(scratch), _stream(), int(bool(debug))))
+                _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
+                _ptr(scratch), _stream(), int(bool(debug))))
     if sh_rest is not None:
         return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots, dsh_rest
     return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots
@@ -275,4 +291,6 @@ def image_views(img, W, H):
     return dict(ranges=img[lay.ranges:lay.ranges + nt * 8].view(torch.int32).view(nt, 2),
                 final_T=img[lay.final_T:lay.final_T + H * W * 4].view(torch.float32).view(H, W),
                 n_contrib=img[lay.n_contrib:lay.n_contrib + H * W * 4].view(torch.int32).view(H, W),
-                quad_work=img[lay.quad_work:lay.quad_work + nt * 16].view(torch.int32).view(nt, 4))
+                quad_work=img[lay.quad_work:lay.quad_work + nt * 16].view(torch.int32).view(nt, 4),
+                quad_pairs=img[lay.quad_pairs:lay.quad_pairs + nt * 16].view(torch.int32).view(nt, 4),
+                quad_visits=img[lay.quad_pairs + nt * 16:lay.quad_pairs + nt * 32].view(torch.int32).view(nt, 4))

@@ -19,6 +19,8 @@ struct AdamArgs {
     float step_size[ADAM_MAX_TENSORS], inv_bc2_sqrt[ADAM_MAX_TENSORS];
     float* step_dev[ADAM_MAX_TENSORS]; const float* lr_dev[ADAM_MAX_TENSORS];         // capturable variant: step out / lr in, on the device
     unsigned* counter[ADAM_MAX_TENSORS];                                               // capturable variant: launches x workgroups so far
+    int row_floats[ADAM_MAX_TENSORS];                                                  // capacity-sized models: floats per row (0 = whole tensor)
+    const unsigned* skip; const int* active_rows;                                      // device words (may be NULL), include/egs_raster.h
     int n; float b1, b2, eps;
 };
 
@@ -29,11 +31,13 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 }
 
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
+    if (a.skip && *a.skip) return;                                   // the frame behind these gradients overflowed its instance capacity: no step at all
     int t = 0;
 #pragma unroll 1
     while (t + 1 < a.n && blockIdx.x >= a.block_start[t + 1]) t++;
     const long long base = (long long)(blockIdx.x - a.block_start[t]) * ADAM_EPB;
-    const long long n = a.numel[t];
+    long long n = a.numel[t];
+    if (a.active_rows && a.row_floats[t]) n = min(n, (long long)max(*a.active_rows, 0) * a.row_floats[t]);      // live rows only (every workgroup still counts its step)
     float* __restrict__ p = a.p[t]; const float* __restrict__ g = a.g[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
     float ss = a.step_size[t], ib = a.inv_bc2_sqrt[t];
     if (a.counter[t]) {                                              // workgroup-uniform: hipGraph replays see the current step / lr
@@ -82,13 +86,14 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
 static int adam_impl(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
                      float* const* step_dev, const float* const* lr_dev, unsigned* const* counters, float beta1, float beta2, float eps,
-                     void* stream) {
+                     const uint32_t* skip_flag, const int32_t* active_rows, const int32_t* row_floats, void* stream) {
     if (n_tensors < 0) return EGS_ERR_ARG;
     const bool dev = step_dev != nullptr;
     if (n_tensors && (!params || !grads || !exp_avg || !exp_avg_sq || !numels)) return EGS_ERR_ARG;
     if (n_tensors && (dev ? (!lr_dev || !counters) : (!lrs || !steps))) return EGS_ERR_ARG;
     for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MAX_TENSORS) {
         AdamArgs a; a.n = 0; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+        a.skip = skip_flag; a.active_rows = (active_rows && row_floats) ? active_rows : nullptr;
         unsigned blocks = 0;
         for (int t = t0; t < n_tensors && a.n < ADAM_MAX_TENSORS; t++) {
             if (numels[t] <= 0) continue;
@@ -97,6 +102,7 @@ static int adam_impl(int n_tensors, float* const* params, const float* const* gr
             const int k = a.n++;
             a.step_dev[k] = dev ? step_dev[t] : nullptr; a.lr_dev[k] = dev ? lr_dev[t] : nullptr; a.counter[k] = dev ? counters[t] : nullptr;
             a.p[k] = params[t]; a.g[k] = grads[t]; a.m[k] = exp_avg[t]; a.v[k] = exp_avg_sq[t]; a.numel[k] = numels[t];
+            a.row_floats[k] = (active_rows && row_floats) ? row_floats[t] : 0;
             a.block_start[k] = blocks;
             blocks += (unsigned)((numels[t] + ADAM_EPB - 1) / ADAM_EPB);
             if (!dev) {
@@ -117,7 +123,8 @@ static int adam_impl(int n_tensors, float* const* params, const float* const* gr
 extern "C" int egs_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                              float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,
                              float beta1, float beta2, float eps, void* stream) {
-    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, lrs, steps, nullptr, nullptr, nullptr, beta1, beta2, eps, stream);
+    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, lrs, steps, nullptr, nullptr, nullptr, beta1, beta2, eps, nullptr, nullptr,
+                     nullptr, stream);
 }
 
 // hipGraph-capturable variant: the learning rate of every tensor is read from a device scalar, and the step number from
@@ -130,7 +137,9 @@ extern "C" int64_t egs_adam_workgroups(int64_t numel) { return numel <= 0 ? 0 : 
 extern "C" int egs_adam_step_capturable(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                                         float* const* exp_avg_sq, const int64_t* numels, float* const* step_dev,
                                         const float* const* lr_dev, uint32_t* const* counters, float beta1, float beta2, float eps,
-                                        void* stream) {
+                                        const uint32_t* skip_flag, const int32_t* active_rows, const int32_t* row_floats, void* stream) {
     if (n_tensors && !step_dev) return EGS_ERR_ARG;
-    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, nullptr, nullptr, step_dev, lr_dev, counters, beta1, beta2, eps, stream);
+    if (row_floats) for (int t = 0; t < n_tensors; t++) if (row_floats[t] < 0) return EGS_ERR_ARG;
+    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, numels, nullptr, nullptr, step_dev, lr_dev, counters, beta1, beta2, eps,
+                     skip_flag, active_rows, row_floats, stream);
 }

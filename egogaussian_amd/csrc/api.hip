@@ -49,6 +49,7 @@ ImgLayout img_layout(int W, int H) {
     L.o.n_contrib = off; off = egs_align(off + px * sizeof(uint32_t));
     L.o.quad_work = off; off = egs_align(off + gx * gy * 4 * sizeof(uint32_t));
     L.o.tile_order = off; off = egs_align(off + ((gx * gy + 7) / 8) * 8 * sizeof(uint32_t));
+    L.o.quad_pairs = off; off = egs_align(off + gx * gy * 8 * sizeof(uint32_t));                 // pairs [tiles][4], then visits [tiles][4]
     L.bytes = off; return L;
 }
 EgsGeomPtrs geom_ptrs(void* buf, int P) {
@@ -69,7 +70,7 @@ EgsImgPtrs img_ptrs(void* buf, int W, int H) {
     const ImgLayout L = img_layout(W, H); char* b = (char*)buf; EgsImgPtrs p;
     p.ranges = (uint2*)(b + L.o.ranges); p.final_T = (float*)(b + L.o.final_T);
     p.n_contrib = (uint32_t*)(b + L.o.n_contrib); p.quad_work = (uint32_t*)(b + L.o.quad_work);
-    p.tile_order = (uint32_t*)(b + L.o.tile_order); return p;
+    p.tile_order = (uint32_t*)(b + L.o.tile_order); p.quad_pairs = (uint32_t*)(b + L.o.quad_pairs); return p;
 }
 
 int check_dims(int P, int W, int H) {
@@ -193,7 +194,7 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
                          float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
                          const float* viewmatrix, const float* projmatrix, const float* campos, int width, int height,
                          float tan_fovx, float tan_fovy, int prefiltered, int32_t* radii, void* geom_buffer,
-                         int64_t* num_rendered, void* stream, int debug) {
+                         int64_t* num_rendered, const int32_t* active_count, void* stream, int debug) {
     (void)prefiltered;
     int rc = check_dims(P, width, height); if (rc) return rc;
     if (!num_rendered) return EGS_ERR_ARG;
@@ -209,7 +210,7 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
     egs_prof_start(EGS_K_PREPROCESS, s);
     const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);         // rows of 12 M bytes: the wave-tiled kernel (preprocess.hip)
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
-                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, nullptr, 0, s));
+                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, nullptr, 0, active_count, s));
     if (sh_apart) EGS_TRY(egs_launch_sh_forward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     EGS_SYNC_IF_DEBUG(s);
@@ -235,7 +236,7 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
                 const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                 int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                 float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
-                int64_t* num_rendered, void* stream, int debug) {
+                int64_t* num_rendered, const int32_t* active_count, uint32_t* overflow_flag, void* stream, int debug) {
     (void)prefiltered;
     int rc = check_dims(P, width, height); if (rc) return rc;
     if (!num_rendered || capacity < 0 || capacity >= (1ll << 31)) return EGS_ERR_ARG;
@@ -267,7 +268,8 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
         n_sums = EGS_BIN_GROUPS * egs_table_chunks(nt, egs_table_stride(egs_bin_blocks(P)));
     }
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
-                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, capacity > 0 ? b_spec.chunk_sum : nullptr, n_sums, s));
+                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, capacity > 0 ? b_spec.chunk_sum : nullptr, n_sums,
+                                  active_count, s));
     if (sh_apart) EGS_TRY(egs_launch_sh_forward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     const size_t nb = ((size_t)P + 255) / 256;
@@ -276,7 +278,7 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     if (capacity > 0) {                                              // speculative: sized by the caller's guess
         EgsBinPtrs b = b_spec;
         EgsImgPtrs im = img_ptrs(image_buffer, width, height);
-        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, 1, s, 0));
+        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, overflow_flag, 1, s, 0));
         egs_prof_start(EGS_K_RENDER_FWD, s);
         EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, s));
         egs_prof_stop(EGS_K_RENDER_FWD, s);
@@ -298,11 +300,11 @@ int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const
                 const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                 int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                 float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, int64_t* num_rendered,
-                void* stream, int debug) {
+                const int32_t* active_count, void* stream, int debug) {
     return forward_impl(1, P, sh_degree, sh_coeffs, means3D, shs, shs_rest, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
-                        pinned_host_counts, nullptr, num_rendered, stream, debug);
+                        pinned_host_counts, nullptr, num_rendered, active_count, nullptr, stream, debug);
 }
 
 // Same chain with NO host wait: everything is only enqueued, so the call can be captured into a hipGraph.  Overflow of
@@ -315,12 +317,12 @@ int egs_forward_enqueue(int P, int sh_degree, int sh_coeffs, const float* means3
                         const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                         int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                         float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
-                        void* stream) {
+                        const int32_t* active_count, uint32_t* overflow_flag, void* stream) {
     int64_t unused = 0;
     return forward_impl(0, P, sh_degree, sh_coeffs, means3D, shs, shs_rest, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
-                        pinned_host_counts, running_max, &unused, stream, 0);
+                        pinned_host_counts, running_max, &unused, active_count, overflow_flag, stream, 0);
 }
 
 int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts) {
@@ -342,7 +344,7 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
     EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
     EgsBinPtrs b = bin_ptrs(binning_buffer, P, R, width, height);
     EgsImgPtrs im = img_ptrs(image_buffer, width, height);
-    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, nullptr, 0, s, debug));
+    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, nullptr, nullptr, 0, s, debug));
     const uint32_t* point_list = b.point_list;
     egs_prof_start(EGS_K_RENDER_FWD, s);
     EGS_TRY(egs_launch_render_forward(width, height, background, g, point_list, im, out_color, out_depth, out_alpha, s));
@@ -359,7 +361,7 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
                  const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
                  float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
                  float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
-                 void* scratch, void* stream, int debug) {
+                 const uint32_t* skip_flag, void* scratch, void* stream, int debug) {
     int rc = check_dims(P, width, height); if (rc) return rc;
     if (P == 0) return 0;
     if (R < 0 || R >= (1ll << 31)) return EGS_ERR_RANGE;
@@ -395,7 +397,7 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
     EGS_TRY(egs_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, scales, scale_modifier, rotations,
                                            cov3D_precomp, activation_flags, cam, radii, g, grad_acc, colors_precomp != nullptr, dL_dmeans2D,
                                            dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, sh_apart ? nullptr : dL_dsh, dL_dscales,
-                                           dL_drotations, stat_grad_accum, stat_denom, stat_max_radii, s));
+                                           dL_drotations, stat_grad_accum, stat_denom, stat_max_radii, skip_flag, s));
     if (sh_apart) EGS_TRY(egs_launch_sh_backward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, radii, g, dL_dcolors, dL_dsh,
                                                  dL_dsh_rest, dL_dmeans3D, s));
     egs_prof_stop(EGS_K_PREPROCESS_BWD, s);

@@ -454,6 +454,7 @@ __device__ __forceinline__ void block_min_max(uint32_t& mn, uint32_t& mx, uint32
 template <bool RANK_ATOMIC, int TS_WAVES, int TS_CAP, uint32_t N_MIN>
 __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32_t stride, const uint32_t* __restrict__ table_scanned,
                                                     const uint64_t* __restrict__ total, uint64_t* __restrict__ running_max,
+                                                    uint32_t* __restrict__ overflow_flag, int solo,
                                                     uint32_t R /* capacity */,
                                                     int index_passes, uint64_t* __restrict__ pairs,
                                                     uint64_t* __restrict__ scratch, uint32_t* __restrict__ point_list,
@@ -469,9 +470,13 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
     const uint32_t n = end > R ? 0u : end - beg;                     // end > capacity: speculative launch that overflowed
     if (N_MIN == 0) {                                                // the first of the two launches also publishes the bookkeeping
         if (running_max && tile == 0 && threadIdx.x == 0 && *total > *running_max) *running_max = *total;   // for hipGraph replays (api.hip)
+        if (overflow_flag && tile == 0 && threadIdx.x == 0) {          // include/egs_raster.h: [0] this frame was clipped, [1] its instance count
+            overflow_flag[0] = *total > (uint64_t)R ? 1u : 0u; overflow_flag[1] = (uint32_t)min(*total, (uint64_t)0xffffffffu);
+        }
         if (threadIdx.x == 0) ranges[tile] = n ? make_uint2(beg, end) : make_uint2(0u, 0u);
     }
-    if (n == 0 || (N_MIN == 0 ? n > (uint32_t)TS_CAP : n < N_MIN)) return;      // empty, or the other instantiation's tile
+    // `solo`: the second instantiation is not launched (no tile is expected beyond TS_CAP); one that is takes the global-memory path here
+    if (n == 0 || (N_MIN == 0 ? (n > (uint32_t)TS_CAP && !solo) : n < N_MIN)) return;      // empty, or the other instantiation's tile
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
     const uint32_t chunk = ((n + TS_WAVES - 1) / TS_WAVES + 63) & ~63u;       // per-wave share, multiple of 64
@@ -670,10 +675,13 @@ int egs_bin_gpb(int P) { const int k = (P + EGS_BIN_GPB * 512 - 1) / (EGS_BIN_GP
 uint32_t egs_bin_blocks(int P) { const int g = egs_bin_gpb(P); return (uint32_t)((P + g - 1) / g); }
 
 hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
-                              uint64_t* running_max, int sums_zeroed, hipStream_t s, int debug) {
+                              uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, hipStream_t s, int debug) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
-    if (R64 == 0 || P == 0) return egs_launch_zero_u32((uint32_t*)im.ranges, 2 * (size_t)n_tiles, s);
+    if (R64 == 0 || P == 0) {
+        if (overflow_flag) { hipError_t e = egs_launch_zero_u32(overflow_flag, 2, s); if (e != hipSuccess) return e; }
+        return egs_launch_zero_u32((uint32_t*)im.ranges, 2 * (size_t)n_tiles, s);
+    }
     const uint32_t R = (uint32_t)R64;
     const uint32_t nblocks = egs_bin_blocks(P);
     int cull = egs_tile_culling;
@@ -728,16 +736,23 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     if (egs_force_ballot_rank) fast = 0;
     egs_prof_start(EGS_K_SORT, s);
     const int ip = (index_bits + TS_DBITS - 1) / TS_DBITS;
+    // A launch costs ~4.5 us of GPU time even when every workgroup returns at once.  When the buffer holds on average at most 2048
+    // instances per tile (R is the capacity: >= 1.25 x the rectangle count, itself ~1.5 x what survives culling) no tile is expected
+    // to need the second instantiation, so it is not launched; a tile that does exceed 2048 is still sorted, by the first one's
+    // global-memory path.
+    const int solo = (uint64_t)R <= 2048ull * (uint64_t)n_tiles ? 1 : 0;
     if (fast) {
-        hipLaunchKernelGGL((k_tile_sort<true, 4, 2048, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, R,
+        hipLaunchKernelGGL((k_tile_sort<true, 4, 2048, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, solo, R,
                            ip, b.pairs, b.scratch, b.point_list, im.ranges);
-        hipLaunchKernelGGL((k_tile_sort<true, 8, 4096, 2049u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, R,
-                           ip, b.pairs, b.scratch, b.point_list, im.ranges);
+        if (!solo)
+            hipLaunchKernelGGL((k_tile_sort<true, 8, 4096, 2049u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, 0, R,
+                               ip, b.pairs, b.scratch, b.point_list, im.ranges);
     } else {
-        hipLaunchKernelGGL((k_tile_sort<false, 4, 2048, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, R,
+        hipLaunchKernelGGL((k_tile_sort<false, 4, 2048, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, solo, R,
                            ip, b.pairs, b.scratch, b.point_list, im.ranges);
-        hipLaunchKernelGGL((k_tile_sort<false, 8, 4096, 2049u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, R,
-                           ip, b.pairs, b.scratch, b.point_list, im.ranges);
+        if (!solo)
+            hipLaunchKernelGGL((k_tile_sort<false, 8, 4096, 2049u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, 0, R,
+                               ip, b.pairs, b.scratch, b.point_list, im.ranges);
     }
     egs_prof_stop(EGS_K_SORT, s);
     EGS_DBG(s);

@@ -41,7 +41,7 @@ struct EgsBinPtrs {
 #define EGS_BIN_GROUPS 8            // partial accumulators per scan chunk (a same-address atomic chain is bin_blocks / 8 long)
 static inline uint32_t egs_table_stride(uint32_t bin_blocks) { uint32_t s = 4; while (s < bin_blocks) s <<= 1; return s; }   // power of two <= 2048
 static inline size_t egs_table_chunks(size_t n_tiles, uint32_t stride) { const size_t rpc = 2048 / stride; return (n_tiles + rpc - 1) / rpc; }
-struct EgsImgPtrs { uint2* ranges; float* final_T; uint32_t* n_contrib; uint32_t* quad_work; uint32_t* tile_order; };
+struct EgsImgPtrs { uint2* ranges; float* final_T; uint32_t* n_contrib; uint32_t* quad_work; uint32_t* tile_order; uint32_t* quad_pairs; };
 
 static inline size_t egs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -76,13 +76,14 @@ struct EgsCamera {
 hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
                                  const float* opac, const float* scales, float mod, const float* rots, int act,
                                  const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, uint32_t* zero_words, size_t zero_n,
-                                 hipStream_t s);
+                                 const int32_t* active_count, hipStream_t s);
 hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* means3D, const float* shs,
                                           const float* scales, float mod, const float* rots, const float* cov3D, int act,
                                           EgsCamera cam, const int32_t* radii, EgsGeomPtrs g, const float* grad_acc,
                                           int colors_given, float* dmeans2D, float* dcolors, float* dopac,
                                           float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,
-                                          float* stat_grad_accum, float* stat_denom, float* stat_max_radii, hipStream_t s);
+                                          float* stat_grad_accum, float* stat_denom, float* stat_max_radii, const uint32_t* skip_flag,
+                                          hipStream_t s);
 // Spherical harmonics as separate launches (M > 1 coefficients, or DC / rest given as two arrays: sh_rest != NULL).  The
 // preprocess launchers are then called with shs = NULL: the forward leaves the record's colour open, the backward leaves
 // dL/dSH and the view-direction part of dL/dmean3D to egs_launch_sh_backward (which must run after it).
@@ -99,7 +100,7 @@ hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int 
                                uint64_t* total, hipStream_t s);
 // sums_zeroed: b.chunk_sum was cleared by this frame's preprocess launch (else a zero-fill launch comes first)
 hipError_t egs_launch_binning(int P, int64_t R, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
-                              uint64_t* running_max, int sums_zeroed, hipStream_t s, int debug);
+                              uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, hipStream_t s, int debug);
 hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                      EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha,
                                      hipStream_t s);

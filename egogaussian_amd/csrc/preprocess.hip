@@ -230,12 +230,15 @@ __global__ __launch_bounds__(256) void k_preprocess(
     const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
     uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible,
-    uint32_t* __restrict__ block_sums, uint32_t* __restrict__ zero_words, size_t zero_n) {
+    uint32_t* __restrict__ block_sums, uint32_t* __restrict__ zero_words, size_t zero_n, const int32_t* __restrict__ active_count) {
     __shared__ uint32_t wsum[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     for (size_t z = (size_t)i; z < zero_n; z += (size_t)gridDim.x * blockDim.x) zero_words[z] = 0u;   // on the side (egs_common.h)
     uint32_t my_tiles = 0;
-    if (i < P) my_tiles = preprocess_one(i, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D_in, act, V, PM, campos, W, H,
+    // capacity-sized models (include/egs_raster.h): rows at and beyond the device-side live count are culled whatever they hold
+    const int live = active_count ? min(P, max(*active_count, 0)) : P;
+    if (i >= live && i < P) { radii[i] = 0; tiles_touched[i] = 0; visible[i] = 0; }
+    if (i < live) my_tiles = preprocess_one(i, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D_in, act, V, PM, campos, W, H,
                                          tanfovx, tanfovy, radii, rec, rect_out, tiles_touched, clamped_out, visible);
     // per-block instance count; the host adds the block sums to get R (no contended atomic, deterministic)
 #pragma unroll
@@ -253,7 +256,8 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     const float4* __restrict__ rec, const float* __restrict__ grad_acc, float* __restrict__ dmeans2D, float* __restrict__ dcolors,
     float* __restrict__ dopac, float* __restrict__ dmeans3D, float* __restrict__ dcov3D, float* __restrict__ dsh,
     float* __restrict__ dscales, float* __restrict__ drots,
-    float* __restrict__ stat_grad_accum, float* __restrict__ stat_denom, float* __restrict__ stat_max_radii) {
+    float* __restrict__ stat_grad_accum, float* __restrict__ stat_denom, float* __restrict__ stat_max_radii,
+    const uint32_t* __restrict__ skip_flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const bool vis = radii[i] > 0;
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     }
     acc[0] = gmx * (0.5f * (float)W); acc[1] = gmy * (0.5f * (float)H);
     dmeans2D[3 * i] = acc[0]; dmeans2D[3 * i + 1] = acc[1]; dmeans2D[3 * i + 2] = 0.f;
-    if (stat_grad_accum && vis) {
+    if (stat_grad_accum && vis && !(skip_flag && *skip_flag)) {       // (skip_flag: this frame overflowed its instance capacity)
         // the trainer's per-iteration densification statistics, where their inputs are produced
         // (/root/reference/scene/gaussian_model.py:735-737 add_densification_stats, trainers/train_static.py:125 max_radii2D)
         stat_grad_accum[i] += sqrtf(acc[0] * acc[0] + acc[1] * acc[1]);
@@ -932,12 +936,12 @@ hipError_t egs_launch_zero_f4(float4* p, size_t n4, hipStream_t s) {
 hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
                                  const float* opac, const float* scales, float mod, const float* rots, int act,
                                  const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, uint32_t* zero_words, size_t zero_n,
-                                 hipStream_t s) {
+                                 const int32_t* active_count, hipStream_t s) {
     if (P == 0) return hipSuccess;
     if (!zero_words) zero_n = 0;
     hipLaunchKernelGGL(k_preprocess, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, colors, opac, scales,
                        mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.tanfovx, cam.tanfovy, radii,
-                       g.rec, g.rect, g.offsets, g.clamped, g.visible, g.scan_scratch, zero_words, zero_n);
+                       g.rec, g.rect, g.offsets, g.clamped, g.visible, g.scan_scratch, zero_words, zero_n, active_count);
     return hipGetLastError();
 }
 
@@ -946,13 +950,14 @@ hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* mean
                                           EgsCamera cam, const int32_t* radii, EgsGeomPtrs g, const float* grad_acc,
                                           int colors_given, float* dmeans2D, float* dcolors, float* dopac,
                                           float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,
-                                          float* stat_grad_accum, float* stat_denom, float* stat_max_radii, hipStream_t s) {
+                                          float* stat_grad_accum, float* stat_denom, float* stat_max_radii, const uint32_t* skip_flag,
+                                          hipStream_t s) {
     if (P == 0) return hipSuccess;
     hipLaunchKernelGGL(k_preprocess_backward, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D,
                        colors_given ? nullptr : shs, scales, mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W,
                        cam.H, cam.tanfovx, cam.tanfovy, radii, g.clamped, g.rec, grad_acc, dmeans2D, dcolors, dopac, dmeans3D,
                        dcov3D, colors_given ? nullptr : dsh, cov3D ? nullptr : dscales, cov3D ? nullptr : drots,
-                       stat_grad_accum, stat_denom, stat_max_radii);
+                       stat_grad_accum, stat_denom, stat_max_radii, skip_flag);
     return hipGetLastError();
 }
 

@@ -34,14 +34,17 @@ __global__ __launch_bounds__(256) void k_render_forward(
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ quad_work) {
+    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ quad_work, uint32_t* __restrict__ quad_pairs) {
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
     const int tile = egs_tile_of_block(blockIdx.x, n_tiles);
     if (tile < 0) return;
     const unsigned lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     float4* my = lds[q];
     const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
-    if (qx0 >= W || qy0 >= H) { if (lane == 0) quad_work[tile * 4 + q] = 0; return; }   // quadrant entirely outside the image
+    if (qx0 >= W || qy0 >= H) {                                    // quadrant entirely outside the image
+        if (lane == 0) { quad_work[tile * 4 + q] = 0; quad_pairs[tile * 4 + q] = 0; quad_pairs[(n_tiles + tile) * 4 + q] = 0; }
+        return;
+    }
     const int px = qx0 + (int)(lane & 7), py = qy0 + (int)(lane >> 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
@@ -56,6 +59,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
     float Tl = inside ? 1.f : 0.f, Tf = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f, Aacc = 0.f;
     uint32_t last = 0;
     uint32_t visits = 0;                                            // wave-uniform: splats blended by this quadrant
+    uint32_t pairs = 0;                                             // wave-uniform: (pixel, splat) pairs that contributed (scalar unit only)
 #ifdef EGS_MEASURE           // instrumentation builds only (tools/lane_use.py): 1 = (wave, splat) visits, 2 = kept lanes, 3 = timeline
     uint32_t meas = 0;
     const uint64_t t_start = wall_clock64();
@@ -94,7 +98,9 @@ __global__ __launch_bounds__(256) void k_render_forward(
             Dacc = fmaf(s2.y, w, Dacc); Aacc += w;
             Tf = cont ? test : Tf;
             Tl = cont ? test : 0.f;
-            last = w > 0.f ? base + (uint32_t)j + 1u : last;
+            const bool used = w > 0.f;
+            last = used ? base + (uint32_t)j + 1u : last;
+            pairs += (uint32_t)__popcll(__ballot(used));
             alive = __ballot(cont) != 0ull;                       // whole quadrant saturated -> leave
 #ifdef EGS_MEASURE
             meas += EGS_MEASURE != 2 ? 1u : (uint32_t)__popcll(__ballot(w > 0.f));
@@ -109,7 +115,10 @@ __global__ __launch_bounds__(256) void k_render_forward(
         uint32_t wmax = last;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
-        if (lane == 0) quad_work[tile * 4 + q] = 10u * visits + 18u * ((wmax + 63u) / 64u);
+        if (lane == 0) {
+            quad_work[tile * 4 + q] = 10u * visits + 18u * ((wmax + 63u) / 64u);
+            quad_pairs[tile * 4 + q] = pairs; quad_pairs[(n_tiles + tile) * 4 + q] = visits;     // measurement only (bench.py: Q, visits)
+        }
 #ifdef EGS_MEASURE
         if (lane == 0) quad_work[tile * 4 + q] = meas;
 #endif
@@ -145,6 +154,6 @@ hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs 
     const int n_tiles = gx * gy;
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_render_forward, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
-                       im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, im.quad_work);
+                       im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, im.quad_work, im.quad_pairs);
     return hipGetLastError();
 }

@@ -107,6 +107,47 @@ class _Plan:
         return out.to(orig_dtype)
 
 
+def _apply_in_place(gaussians, plan, reset_stats, z=None, curr_gen=None):
+    """Capacity-sized model (capacity.CapacityGaussians): the new model is gathered from the live prefix into temporaries and
+    copied back INTO the same arrays; tensors, Parameter objects and optimizer state entries keep their identity and address.
+    Returns False (nothing changed) when the new count does not fit the capacity -- the caller grows the model first."""
+    L = _lib.load()
+    n_old, n_new = gaussians.n_active, plan.n_new
+    if n_new > gaussians.capacity:
+        return False
+    live = lambda t: t.detach()[:n_old]
+    old = {k: live(getattr(gaussians, _ATTR[k])) for k in GROUPS}
+    new = {k: plan.rows(old[k]) for k in GROUPS}
+    if plan.n_split:
+        with torch.cuda.device(plan.dev):
+            _lib.check(L.egs_split_children(plan.n_new, _p(plan.src), _p(plan.kind), _p(plan.split_rank), plan.n_split, _p(z),
+                                            _p(old["xyz"].float().contiguous()), _p(old["scaling"].float().contiguous()),
+                                            _p(old["rotation"].float().contiguous()), _p(new["xyz"]), _p(new["scaling"]), _stream()))
+    opt = getattr(gaussians, "optimizer", None)
+    with torch.no_grad():
+        if opt is not None:
+            for group in opt.param_groups:
+                name = group.get("name")
+                if name not in new:
+                    continue
+                stored = opt.state.get(group["params"][0], None)
+                if stored is not None and "exp_avg" in stored:
+                    for key in ("exp_avg", "exp_avg_sq"):
+                        stored[key][:n_new].copy_(plan.rows(stored[key][:n_old], zero_new=True))
+        for k in GROUPS:
+            getattr(gaussians, _ATTR[k]).detach()[:n_new].copy_(new[k])
+        gaussians._generation[:n_new].copy_(plan.ints(gaussians._generation[:n_old], clone_value=curr_gen))
+        gaussians._is_object[:n_new].copy_(plan.ints(gaussians._is_object[:n_old]))
+        for name in ("xyz_gradient_accum", "denom", "max_radii2D"):
+            t = getattr(gaussians, name)
+            if reset_stats:
+                t.zero_()
+            else:
+                t[:n_new].copy_(plan.rows(t[:n_old]))
+    gaussians.set_active(n_new)
+    return True
+
+
 def _apply(gaussians, plan, reset_stats, z=None, curr_gen=None, during_training=True):
     L = _lib.load()
     old = {k: getattr(gaussians, _ATTR[k]) for k in GROUPS}
@@ -161,11 +202,12 @@ def densify_and_prune(gaussians, max_grad, min_opacity, extent, max_screen_size,
         raise ValueError("prune_prev_gen=False needs curr_gen")
     L = _lib.load()
     xyz = _hip(gaussians._xyz, "_xyz")
-    P, dev = xyz.shape[0], xyz.device
+    in_place = getattr(gaussians, "capacity", None) is not None      # capacity.CapacityGaussians: plan on the live prefix, write back in place
+    P, dev = (gaussians.n_active if in_place else xyz.shape[0]), xyz.device
     if P == 0:
         return 0, 0
-    f = lambda t: t.detach().float().contiguous()
-    i32 = lambda t: t.detach().to(torch.int32).contiguous()
+    f = lambda t: t.detach()[:P].float().contiguous()
+    i32 = lambda t: t.detach()[:P].to(torch.int32).contiguous()
     plan = _Plan(P, dev)
     mss = 0.0 if not max_screen_size else float(max_screen_size)
     with torch.cuda.device(dev):
@@ -183,6 +225,11 @@ def densify_and_prune(gaussians, max_grad, min_opacity, extent, max_screen_size,
         z = _hip(z, "z").float().contiguous()
         if tuple(z.shape) != (2 * plan.n_split, 3):
             raise ValueError(f"z must be [{2 * plan.n_split}, 3] (two children per split Gaussian), got {tuple(z.shape)}")
+    if in_place:
+        if not _apply_in_place(gaussians, plan, reset_stats=bool(clone or split), z=z, curr_gen=curr_gen):
+            gaussians.grow(max(int(plan.n_new * 1.5), plan.n_new + 1024))        # new arrays: a captured step must be captured again
+            assert _apply_in_place(gaussians, plan, reset_stats=bool(clone or split), z=z, curr_gen=curr_gen)
+        return P, plan.n_new
     _apply(gaussians, plan, reset_stats=bool(clone or split), z=z, curr_gen=curr_gen)
     return P, plan.n_new
 
@@ -191,14 +238,18 @@ def prune_points(gaussians, mask, during_training=True):
     """GaussianModel.prune_points (:536): drop the Gaussians where `mask` is True, carrying the optimizer moments along."""
     L = _lib.load()
     xyz = _hip(gaussians._xyz, "_xyz")
-    P, dev = xyz.shape[0], xyz.device
+    in_place = getattr(gaussians, "capacity", None) is not None and during_training
+    P, dev = (gaussians.n_active if in_place else xyz.shape[0]), xyz.device
     if P == 0:
         return 0, 0
-    m = (mask if mask.dtype in (torch.bool, torch.uint8) else mask != 0).contiguous().view(torch.uint8)
+    m = (mask if mask.dtype in (torch.bool, torch.uint8) else mask != 0)[:P].contiguous().view(torch.uint8)
     plan = _Plan(P, dev)
     with torch.cuda.device(dev):
         _lib.check(L.egs_prune_plan(P, _p(m), _p(plan.scratch), _p(plan.src), _p(plan.kind), _p(plan.split_rank), _p(plan.totals), _stream()))
     plan.finish()
+    if in_place:
+        _apply_in_place(gaussians, plan, reset_stats=False)
+        return P, plan.n_new
     _apply(gaussians, plan, reset_stats=False, during_training=during_training)
     return P, plan.n_new
 
@@ -208,6 +259,13 @@ def reset_opacity(gaussians):
     o = torch.minimum(torch.sigmoid(gaussians._opacity.detach()), torch.full_like(gaussians._opacity, 0.01))
     new = torch.log(o / (1 - o))
     opt = gaussians.optimizer
+    if getattr(gaussians, "capacity", None) is not None:            # capacity-sized model: same tensors, new contents
+        with torch.no_grad():
+            gaussians._opacity.copy_(new)
+            stored = opt.state.get(gaussians._opacity, None) if opt is not None else None
+            if stored is not None and "exp_avg" in stored:
+                stored["exp_avg"].zero_(); stored["exp_avg_sq"].zero_()
+        return
     for group in opt.param_groups:
         if group.get("name") == "opacity":
             stored = opt.state.get(group["params"][0], None)

@@ -95,30 +95,39 @@ def covariance_and_opacity(log_scaling, scaling_modifier, rotation, opacity_raw)
     return _Cov3D.apply(log_scaling, rotation, None, None, scaling_modifier, 1.0, True, opacity_raw)
 
 
+def object_selection(is_object, which_object, n):
+    """(selected uint8[N] or None, row-0 gradient multiplier: python float or float32[1] device tensor) for the rows the reference's
+    build_covariance_from_scaling_rotation_w_rot rotates -- including its [N,1]-index quirk (covariance.py): Gaussian 0 is rotated
+    too whenever any Gaussian is selected, and its gradient is multiplied by (count + [0 selected]).  Evaluated on the device, no
+    host read.  The result depends only on (is_object, which_object): callers may keep it across steps."""
+    sel, mult = None, 1.0
+    if which_object is not None and is_object is not None:
+        sel = (is_object.reshape(-1) == which_object)
+        if is_object.dim() == 2 and n > 0:
+            cnt = sel.sum()
+            mult = (cnt + sel[0]).to(torch.float32).reshape(1)
+            first = torch.logical_or(sel[0:1], (cnt > 0).reshape(1))
+            sel = sel.clone(); sel[0:1] = first
+        sel = sel.to(torch.uint8).contiguous()
+    elif is_object is not None and is_object.dim() == 2 and n > 0:
+        mult = float(n + 1)
+    return sel, mult
+
+
 def rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation, accum_R, is_object=None, which_object=None,
-                                             rot_matrix=None, scaling_is_log=False):
+                                             rot_matrix=None, scaling_is_log=False, selection=None, opacity_raw=None):
     """`rot_matrix` (3x3, may require grad) is the trainable object rotation applied on top of accum_R during training
-    (trainable_object_move.rot_L in the reference).  Keeps the reference's [N,1]-index quirk, see covariance.py."""
+    (trainable_object_move.rot_L in the reference).  Keeps the reference's [N,1]-index quirk, see covariance.py.
+    selection: a cached object_selection(is_object, which_object, N); opacity_raw: also return sigmoid(opacity_raw) from the
+    same launch -> (cov3D, opacity)."""
     dev = scaling.device
     if accum_R is None:
         accum_R = torch.eye(3, device=dev)
     M = accum_R.to(dev).float()
     if rot_matrix is not None:
         M = rot_matrix @ M
-    n = scaling.shape[0]
-    sel, mult = None, 1.0
-    if which_object is not None and is_object is not None:
-        sel = (is_object.reshape(-1) == which_object)
-        if is_object.dim() == 2 and n > 0:
-            # the reference's index quirk (covariance.py): Gaussian 0 is rotated too whenever any Gaussian is selected, and its
-            # gradient is multiplied by (count + [0 selected]).  Both are evaluated on the device -- no host read per step.
-            cnt = sel.sum()
-            mult = (cnt + sel[0]).to(torch.float32).reshape(1)
-            first = torch.logical_or(sel[0:1], (cnt > 0).reshape(1))
-            sel = sel.clone(); sel[0:1] = first
-    elif is_object is not None and is_object.dim() == 2 and n > 0:
-        mult = float(n + 1)
-    return _Cov3D.apply(scaling, rotation, M, sel, scaling_modifier, mult, scaling_is_log)
+    sel, mult = selection if selection is not None else object_selection(is_object, which_object, scaling.shape[0])
+    return _Cov3D.apply(scaling, rotation, M, sel, scaling_modifier, mult, scaling_is_log, opacity_raw)
 
 
 class _L1SSIM(torch.autograd.Function):

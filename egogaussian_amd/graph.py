@@ -4,19 +4,23 @@ Once the kernels are fast the iteration of /root/reference/trainers/train_static
 kernel launches, three Python autograd Functions and the optimizer cost ~0.75 ms of CPU per step against ~0.55 ms of GPU
 work at 500k Gaussians.  The step has static shapes (the data-dependent instance count is handled by the capacity-bounded
 `egs_forward_enqueue`, the optimizer by `FusedAdam(capturable=True)`), so it is captured ONCE -- covariance, render
-forward, loss, backward, Adam -- and replayed with one launch per iteration; per-iteration inputs (camera matrices and
-ground-truth image) are copied into static device tensors first.
+forward, loss, backward, Adam -- and replayed with one launch per iteration; per-iteration inputs (camera matrices,
+ground-truth image and, for the `fine_all` call shape, the object's accumulated rotation and the hand-mask gate) are
+copied into static device tensors first, as ONE copy when the caller keeps them packed (`pack_frame`).
 
-Validity: a replayed frame whose instance count exceeded the captured capacity is clipped, hence wrong.  The graph
-tracks the running maximum of R on the device (`max_instances()`); callers check it at their next synchronisation point
-(the reference synchronises every iteration anyway through `loss.item()`, trainers/train_static.py:112) and re-capture
-with a larger capacity if needed (`recapture()`).
+Overflow safety.  A replayed frame whose instance count exceeds the captured capacity is clipped, hence wrong.  The
+forward chain writes an overflow word on the device (`_C.StepGuard`); the backward's fused densification statistics and
+the Adam launch read it and do NOTHING for such a frame -- parameters, moments, step counts and statistics stay bit for
+bit what they were, so every optimizer step follows a complete render, as in the reference (train_static.py:110-138).
+The frame is merely lost.  `ok()` (one host read of the running maximum) tells whether that ever happened; with
+`check_every=K` the object looks itself every K calls and re-captures with a larger capacity.
 
-What is baked into the captured launches and therefore needs `recapture()` when it changes: the tensors themselves (densification
-and pruning replace them), the number of Gaussians, the image size, `pc.active_sh_degree` (the reference raises it every 1000
-iterations, scene/gaussian_model.py:176-178), the background tensor's address, `lambda_dssim`.  What does not: camera and
-ground-truth contents (copied in per call) and the learning rates (device scalars; `__call__` pushes host-side edits of
-`param_groups[i]["lr"]` -- the reference's per-iteration `update_learning_rate` -- before each replay).
+What is baked into the captured launches and therefore needs `recapture()` when it changes: the tensors themselves
+(densification and pruning of a plain model replace them; a capacity.CapacityGaussians model keeps them, and its live row
+count is a device word the kernels read), the image size, `pc.active_sh_degree` (the reference raises it every 1000
+iterations, scene/gaussian_model.py:176-178), the background tensor's address, `lambda_dssim`.  What does not: camera,
+ground truth, accum_R and gate contents (copied in per call) and the learning rates (device scalars; `__call__` pushes
+host-side edits of `param_groups[i]["lr"]` -- the reference's per-iteration `update_learning_rate` -- before each replay).
 """
 import torch
 
@@ -31,17 +35,39 @@ def pack_camera(cam):
     return torch.cat([cam.world_view_transform.reshape(-1), cam.full_proj_transform.reshape(-1), cam.camera_center.reshape(-1)]).float()
 
 
-def pack_frame(cam, gt):
-    """One resident tensor per training frame: the ground-truth image followed by the camera block.  GraphedTrainStep(frame) then
-    refreshes both static inputs of the captured step with ONE device copy."""
-    return torch.cat([gt.reshape(-1).float(), pack_camera(cam).to(gt.device)])
+def frame_layout(n_img, n_pix, dynamic=False, gated=False):
+    """Float offsets of the segments of a packed frame (each starts on a 16-byte boundary): -> ({name: (begin, end)}, size)."""
+    up4 = lambda x: (x + 3) & ~3
+    off = {"gt": (0, n_img)}
+    end = up4(n_img)
+    off["cam"] = (end, end + 35); end = up4(end + 35)
+    if dynamic:
+        off["accum_R"] = (end, end + 9); end = up4(end + 9)
+    if gated:
+        off["gate"] = (end, end + n_pix); end = up4(end + n_pix)
+    return off, end
+
+
+def pack_frame(cam, gt, accum_R=None, gate=None):
+    """One resident tensor per training frame: the ground-truth image, the camera block and -- for a step captured with
+    dynamic=True / gated=True -- the object's accumulated rotation (3x3) and the per-pixel gradient gate (1 - hand mask, [H,W]).
+    GraphedTrainStep(frame) then refreshes every static input of the captured step with ONE device copy."""
+    off, size = frame_layout(gt.numel(), gt.shape[-2] * gt.shape[-1], accum_R is not None, gate is not None)
+    f = torch.zeros(size, device=gt.device, dtype=torch.float32)
+    f[off["gt"][0]:off["gt"][1]] = gt.reshape(-1)
+    f[off["cam"][0]:off["cam"][1]] = pack_camera(cam).to(gt.device)
+    if accum_R is not None:
+        f[off["accum_R"][0]:off["accum_R"][1]] = accum_R.reshape(-1).to(gt.device)
+    if gate is not None:
+        f[off["gate"][0]:off["gate"][1]] = gate.reshape(-1).to(gt.device)
+    return f
 
 
 class _StaticCamera:
     """Camera whose tensors are fixed device buffers; `load(cam)` copies another camera of the same intrinsics in."""
 
     def __init__(self, cam, storage=None):
-        """storage: an existing float32[35] device view to live in (the tail of a packed frame), else its own block."""
+        """storage: an existing float32[35] device view to live in (part of a packed frame), else its own block."""
         self.image_height, self.image_width, self.FoVx, self.FoVy = cam.image_height, cam.image_width, cam.FoVx, cam.FoVy
         packed = pack_camera(cam)
         if storage is None:
@@ -66,106 +92,165 @@ class _StaticCamera:
 
 
 class GraphedTrainStep:
-    def __init__(self, pc, optimizer, bg, lambda_dssim=0.2, pipe=Pipe, render_kwargs=None, densify_stats=False):
+    def __init__(self, pc, optimizer, bg, lambda_dssim=0.2, pipe=Pipe, render_kwargs=None, densify_stats=False, dynamic=False,
+                 which_object=1, gated=False, check_every=0):
         """densify_stats: the captured step also keeps the per-iteration densification statistics (trainers/train_static.py:125-127:
-        max_radii2D, xyz_gradient_accum, denom) -- updated by the rasterizer's backward itself, no launch of their own."""
+                       max_radii2D, xyz_gradient_accum, denom) -- updated by the rasterizer's backward itself, no launch of their own.
+        dynamic:       the `fine_all` call shape (/root/reference/trainers/fine_all.py:88-93): render(..., rot_cov=True,
+                       accum_R=<static 3x3, refreshed per call>, which_object=which_object, during_training=False).
+        gated:         the image gradient is multiplied by a per-pixel gate refreshed per call -- the reference's
+                       `render_image.register_hook(lambda grad: grad * (1 - hand_mask))` (train_static.py:91, fine_all.py:94).
+        check_every:   K > 0: every K calls read the overflow maximum (one host synchronisation) and re-capture with a larger
+                       instance capacity if a frame was clipped (its update was skipped, see the module docstring)."""
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True)")
         self.pc, self.opt, self.bg, self.lam, self.pipe = pc, optimizer, bg, lambda_dssim, pipe
         self.densify_stats = densify_stats
-        self.render_kwargs = render_kwargs or {}
+        self.dynamic, self.which_object, self.gated = bool(dynamic), which_object, bool(gated)
+        self.render_kwargs = dict(render_kwargs or {})
+        self.check_every = int(check_every)
         self.graph = None
-        self._max_r = None
+        self.guard = None
         self.loss_sum = None
+        self.recaptures = 0               # re-captures this object did on its own (overflow)
+        self.skipped_frames_seen = 0      # overflow events noticed by check()
+        self._calls = 0
 
     def _body(self):
-        out = render(self.cam, self.pc, self.pipe, self.bg, fused_densify_stats=self.densify_stats, **self.render_kwargs)
+        kw = dict(self.render_kwargs)
+        if self.dynamic:
+            kw.update(rot_cov=True, accum_R=self.accum_R, which_object=self.which_object, during_training=False)
+        out = render(self.cam, self.pc, self.pipe, self.bg, fused_densify_stats=self.densify_stats, guard=self.guard, **kw)
         # the loss value and the running sum are produced by the loss BACKWARD kernel (nothing reads them before): two launches less
-        loss = l1_ssim_loss(out["render"], self.gt, self.lam, running_sum=self.loss_sum, defer_value=True)
+        loss = l1_ssim_loss(out["render"], self.gt, self.lam, grad_gate=self.gate if self.gated else None, running_sum=self.loss_sum,
+                            defer_value=True)
         loss.backward(gradient=self._one)                            # a resident 1.0: no fill kernel per iteration
         self.opt.step()
         return loss.detach(), out
 
-    def capture(self, cam, gt, warmup=3, capacity_margin=1.25):
+    def _frame_layout(self, gt):
+        return frame_layout(gt.numel(), gt.shape[-2] * gt.shape[-1], self.dynamic, self.gated)
+
+    def capture(self, cam, gt, warmup=3, capacity_margin=1.25, accum_R=None, gate=None, capacity_cams=None, capacity=None):
         """Runs `warmup` eager iterations on (cam, gt) -- they are real training steps -- then records (without executing) one
-        more into the graph."""
+        more into the graph.  capacity_cams: further cameras whose instance counts size the captured capacity (a forward-only
+        render each); without them the capacity is `capacity_margin` x the count of `cam` alone, and R varies across views.
+        capacity: the instance capacity to capture with, as is (overrides the margin rule; tests use it to provoke an overflow)."""
         dev = gt.device
         if isinstance(cam, _StaticCamera):                           # recapture: keep the static buffers
             if gt is not self.gt:
                 self.gt.copy_(gt)
         else:
-            self._frame = torch.empty(gt.numel() + 35, device=dev, dtype=torch.float32)      # image, then camera: one copy target
-            self.gt = self._frame[:gt.numel()].view(gt.shape)
+            off, size = self._frame_layout(gt)
+            self._frame = torch.empty(size, device=dev, dtype=torch.float32)      # image, camera[, accum_R][, gate]: one copy target
+            self.gt = self._frame[off["gt"][0]:off["gt"][1]].view(gt.shape)
             self.gt.copy_(gt)
-            self.cam = _StaticCamera(cam, storage=self._frame[gt.numel():])
+            self.cam = _StaticCamera(cam, storage=self._frame[off["cam"][0]:off["cam"][1]])
+            self.accum_R = self.gate = None
+            if self.dynamic:
+                self.accum_R = self._frame[off["accum_R"][0]:off["accum_R"][1]].view(3, 3)
+                self.accum_R.copy_(torch.eye(3, device=dev) if accum_R is None else accum_R)
+            if self.gated:
+                self.gate = self._frame[off["gate"][0]:off["gate"][1]].view(gt.shape[-2], gt.shape[-1])
+                self.gate.copy_(torch.ones(gt.shape[-2:], device=dev) if gate is None else gate)
         self._one = torch.ones((), device=dev)
         if getattr(self, "loss_sum", None) is None:
             self.loss_sum = torch.zeros((), device=dev)                  # sum of the losses of every iteration run through this object
-        P = self.pc.get_xyz.shape[0]
+        self.guard = _C.StepGuard(dev)
+        self.opt.guard = self.guard                                  # the Adam launch of an overflowed frame does nothing
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
+            r_seen = 0
+            if capacity_cams:
+                kw = dict(self.render_kwargs)
+                if self.dynamic:
+                    kw.update(rot_cov=True, accum_R=self.accum_R, which_object=self.which_object, during_training=False)
+                with torch.no_grad():
+                    for c in capacity_cams:
+                        render(c, self.pc, self.pipe, self.bg, **kw)
+                        r_seen = max(r_seen, _C.stats["num_rendered"])
             for _ in range(max(1, warmup)):                          # eager: sets the capacity hint, allocator pools, lazy state
                 self.opt.zero_grad(set_to_none=True)
                 self._body()
+                r_seen = max(r_seen, _C.stats["num_rendered"])
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.capacity = max(int(_C.stats["num_rendered"] * capacity_margin), _C.stats["capacity"])
+        self.capacity = max(int(r_seen * capacity_margin), _C.stats["capacity"], getattr(self, "_min_capacity", 0))
+        if capacity is not None:
+            self.capacity = max(int(capacity), 1)
         _C.set_capacity_hint(self.capacity, dev)
-        self.P = P
-        self._max_r = torch.zeros(1, dtype=torch.int64, device=dev)      # raised by every replayed forward (library side)
+        self.P = self.pc.get_xyz.shape[0]
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        _C.set_running_max(dev, self._max_r)
         # capture_begin/capture_end directly: the torch.cuda.graph context manager also runs gc.collect() and
         # torch.cuda.empty_cache() (3 ms at this size), which a trainer that re-captures after every densification pays each time
         side.wait_stream(torch.cuda.current_stream(dev))
-        try:
-            with torch.cuda.stream(side):
-                # thread_local: calls other threads make meanwhile (e.g. the RCCL watchdog polling its events) must not abort the capture
-                self.graph.capture_begin(capture_error_mode="thread_local")
-                try:
-                    self.loss, out = self._body()
-                    self.image = out["render"].detach()
-                    self.radii = out["radii"]
-                    self.viewspace_grad = out["viewspace_points"].grad
-                    self._total = _C.stats["total_view"]
-                finally:
-                    self.graph.capture_end()
-        finally:
-            _C.set_running_max(dev, None)
+        with torch.cuda.stream(side):
+            # thread_local: calls other threads make meanwhile (e.g. the RCCL watchdog polling its events) must not abort the capture
+            self.graph.capture_begin(capture_error_mode="thread_local")
+            try:
+                self.loss, out = self._body()
+                self.image = out["render"].detach()
+                self.radii = out["radii"]
+                self.visibility_filter = out["visibility_filter"]      # follows every replay (a view of the rasterizer's saved state)
+                self.viewspace_grad = out["viewspace_points"].grad
+            finally:
+                self.graph.capture_end()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        self.guard.running_max.zero_(); self.guard.overflow.zero_()
         return self
 
-    def recapture(self, cam=None, gt=None, warmup=1, capacity_margin=1.25):
+    def recapture(self, cam=None, gt=None, warmup=1, capacity_margin=1.25, capacity_cams=None):
         """Capture again with the model as it is now -- after densification / pruning replaced the parameters, or after ok()
         reported a frame that outgrew the capacity.  Like capture(), the `warmup` eager iterations are real training steps."""
         cam = self.cam if cam is None else cam
         gt = self.gt if gt is None else gt
         self.graph = None                                            # drop the old graph and its private memory pool first
-        return self.capture(cam, gt, warmup=warmup, capacity_margin=capacity_margin)
+        return self.capture(cam, gt, warmup=warmup, capacity_margin=capacity_margin, capacity_cams=capacity_cams)
 
-    def __call__(self, cam, gt=None):
+    def __call__(self, cam, gt=None, accum_R=None, gate=None):
         """One training iteration: copy inputs in, replay.  Returns the (device, static) loss tensor.
-        Either (camera, ground-truth image) or one packed frame from pack_frame() (a single copy)."""
+        Either (camera, ground-truth image[, accum_R][, gate]) or one packed frame from pack_frame() (a single copy)."""
         if gt is None:
             self._frame.copy_(cam, non_blocking=True)
         else:
             self.cam.load(cam)
             self.gt.copy_(gt, non_blocking=True)
+            if self.dynamic and accum_R is not None:
+                self.accum_R.copy_(accum_R, non_blocking=True)
+            if self.gated and gate is not None:
+                self.gate.copy_(gate, non_blocking=True)
         self.opt.sync_lr()                                           # a fill per group whose learning rate was edited since the last call
         self.graph.replay()
+        self._calls += 1
+        if self.check_every > 0 and self._calls % self.check_every == 0:
+            self.check()
         return self.loss
+
+    def check(self, capacity_margin=1.25):
+        """Reads the running maximum of the instance count (synchronises).  If a replayed frame was clipped -- its parameter
+        update was skipped on the device -- re-captures with room for it and returns False; True otherwise."""
+        if self.ok():
+            return True
+        self.skipped_frames_seen += 1
+        self._min_capacity = int(self.max_instances() * capacity_margin) + 65536
+        self.recaptures += 1
+        self.recapture(warmup=1, capacity_margin=capacity_margin)
+        return False
 
     def last_instance_count(self):
         """Instances the most recent replay bucketed; call after synchronising.  More than `capacity` means that frame was
-        clipped."""
-        return int(self._total.item())
+        clipped (and its update skipped)."""
+        return int(self.guard.overflow[1].item()) & 0xffffffff
+
+    def last_frame_overflowed(self):
+        return bool(int(self.guard.overflow[0].item()))
 
     def max_instances(self):
-        """Largest R over every replay so far (reads a device scalar: synchronises)."""
-        return int(self._max_r.item())
+        """Largest R over every replay since the capture (reads a device scalar: synchronises)."""
+        return int(self.guard.running_max.item())
 
     def ok(self):
         """True if no replayed frame exceeded the captured capacity (i.e. every one of them was rendered completely)."""

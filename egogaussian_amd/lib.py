@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EGS_RASTER_LIB", os.path.join(_HERE, "libegs_raster.so"))      # override for A/B builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 RETRY_LARGER = -100
 
 vp, f32, i32, i64 = C.c_void_p, C.c_float, C.c_int, C.c_int64
@@ -24,7 +24,7 @@ class BinningLayout(C.Structure):
 
 
 class ImageLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("ranges", "final_T", "n_contrib", "quad_work", "tile_order")]
+    _fields_ = [(n, C.c_size_t) for n in ("ranges", "final_T", "n_contrib", "quad_work", "tile_order", "quad_pairs")]
 
 
 # name -> (restype, argtypes); every symbol include/egs_raster.h declares
@@ -40,15 +40,15 @@ SIGNATURES = {
     "egs_get_binning_layout": (C.c_int, [i32, i64, i32, i32, C.POINTER(BinningLayout)]),
     "egs_get_image_layout": (C.c_int, [i32, i32, C.POINTER(ImageLayout)]),
     "egs_forward_geometry": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
-                                       i32, vp, vp, C.POINTER(i64), vp, i32]),
+                                       i32, vp, vp, C.POINTER(i64), vp, vp, i32]),
     "egs_forward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, i64,
-                               vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp, i32]),
+                               vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp, vp, i32]),
     "egs_forward_enqueue": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp,
-                                       i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+                                       i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "egs_sum_counts": (C.c_int64, [i32, vp]),
     "egs_forward_render": (C.c_int, [i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
-                               vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
+                               vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "egs_cov3d_forward": (C.c_int, [i32, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_cov3d_dm_scratch_floats": (C.c_size_t, [i32]),
@@ -58,7 +58,7 @@ SIGNATURES = {
     "egs_l1_ssim_backward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "egs_adam_step": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
     "egs_adam_workgroups": (C.c_int64, [i64]),
-    "egs_adam_step_capturable": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
+    "egs_adam_step_capturable": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp]),
     "egs_densify_stats": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_densify_plan_scratch_bytes": (C.c_size_t, [i32]),
     "egs_densify_plan": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp,
@@ -90,6 +90,23 @@ def profile_end():
     return {L.egs_profile_stage_name(k).decode(): (float(ms[k]), int(n[k])) for k in range(N_STAGES)}
 
 _lib = None
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the library's sources -- csrc/*.hip, csrc/*.h, include/egs_raster.h, the Makefile -- in
+    name order.  Counter files under profiles/ carry the hash they were collected at; bench.py reports their numbers only
+    while it still equals this one (a profile of other kernels describes other kernels)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(csrc, "Makefile")])
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "egs_raster.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def library_path():

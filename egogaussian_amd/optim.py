@@ -8,6 +8,7 @@ densification code, which rewrites optimizer.state entries directly (gaussian_mo
 import ctypes as C
 
 import torch
+from torch.utils.weak import WeakIdKeyDictionary
 
 from . import lib as _lib
 
@@ -21,18 +22,36 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.capturable = capturable
-        self._lr_dev = {}
-        self._counter = {}                # (group index, index in group) -> (int32[workgroups] device counters, workgroups, numel); see k_adam
+        # capturable variant, per PARAMETER OBJECT (entries die with the parameter, e.g. when densification replaces it):
+        #   "lr": float32[1] device copy of the group's learning rate; "counter": (int32[workgroups] device step counters of k_adam,
+        #   workgroups, numel)
+        self._aux = WeakIdKeyDictionary()
+        self.guard = None                 # _C.StepGuard of a captured step: its overflow word makes step() a no-op for a clipped frame
+        self.active_rows = None           # (int32[1] device tensor, capacity rows): only the live rows of a capacity-sized model are stepped
+
+    def load_state_dict(self, state_dict):
+        """The device-side step counters and learning rates are derived state: dropped here and re-seeded from the loaded
+        state["step"] / param_groups at the next step()."""
+        super().load_state_dict(state_dict)
+        self._aux = WeakIdKeyDictionary()
+
+    def _aux_of(self, p):
+        a = self._aux.get(p)
+        if a is None:
+            a = self._aux[p] = {}
+        return a
 
     def sync_lr(self):
-        for gi, group in enumerate(self.param_groups):
+        for group in self.param_groups:
+            lr = float(group["lr"])
             for p in group["params"]:
-                t = self._lr_dev.get((gi, id(p)))
+                a = self._aux_of(p)
+                t = a.get("lr")
                 if t is None:
-                    self._lr_dev[(gi, id(p))] = torch.full((1,), float(group["lr"]), device=p.device)
-                elif float(group["lr"]) != getattr(t, "_host_value", None):
-                    t.fill_(float(group["lr"]))
-                self._lr_dev[(gi, id(p))]._host_value = float(group["lr"])
+                    a["lr"] = torch.full((1,), lr, device=p.device)
+                elif lr != a.get("lr_host"):
+                    t.fill_(lr)
+                a["lr_host"] = lr
 
     @torch.no_grad()
     def _step_capturable(self):
@@ -50,28 +69,35 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 if not (torch.is_tensor(st.get("step")) and st["step"].is_cuda):
                     st["step"] = torch.full((1,), float(st.get("step", 0)), device=p.device)
-                lr_t = self._lr_dev.get((gi, id(p)))
+                aux = self._aux_of(p)
+                lr_t = aux.get("lr")
                 if lr_t is None:
-                    lr_t = self._lr_dev[(gi, id(p))] = torch.full((1,), float(group["lr"]), device=p.device)
-                    lr_t._host_value = float(group["lr"])
+                    lr_t = aux["lr"] = torch.full((1,), float(group["lr"]), device=p.device)
+                    aux["lr_host"] = float(group["lr"])
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 # the kernel keeps the step number in one word per workgroup of this tensor and advances them itself;
-                # (re)seeded here from state["step"] when the tensor is new or its size changed (densification)
-                key, G = (gi, group["params"].index(p) if len(group["params"]) > 1 else 0), int(L.egs_adam_workgroups(p.numel()))
-                ent = self._counter.get(key)
+                # (re)seeded here from state["step"] when the tensor is new (densification replaced it, or a state dict was loaded)
+                G = int(L.egs_adam_workgroups(p.numel()))
+                ent = aux.get("counter")
                 if ent is None or ent[1] != G or ent[2] != p.numel() or ent[0].device != p.device:
                     if torch.cuda.is_current_stream_capturing():
                         raise RuntimeError("FusedAdam(capturable=True): take one eager step() before capturing (device counters are created then)")
-                    ent = (torch.full((max(G, 1),), int(round(float(st["step"]))), dtype=torch.int32, device=p.device), G, p.numel())
-                    self._counter[key] = ent
-                by_cfg.setdefault((p.device, group["betas"], group["eps"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"], st["step"], lr_t, ent[0]))
+                    ent = aux["counter"] = (torch.full((max(G, 1),), int(round(float(st["step"]))), dtype=torch.int32, device=p.device), G, p.numel())
+                rf = 0
+                if self.active_rows is not None and p.dim() >= 1 and p.shape[0] == self.active_rows[1] and p.shape[0] > 0:
+                    rf = p.numel() // p.shape[0]                  # a per-Gaussian array of the capacity-sized model
+                by_cfg.setdefault((p.device, group["betas"], group["eps"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"], st["step"], lr_t, ent[0], rf))
         for (dev, betas, eps), items in by_cfg.items():
             n = len(items)
             arr = lambda k: (C.c_void_p * n)(*[t[k].data_ptr() for t in items])
             NN = (C.c_int64 * n)(*[t[0].numel() for t in items])
+            RF = (C.c_int32 * n)(*[t[7] for t in items])
+            skip = None if self.guard is None else C.c_void_p(self.guard.overflow.data_ptr())
+            rows = None if self.active_rows is None else C.c_void_p(self.active_rows[0].data_ptr())
             with torch.cuda.device(dev):                             # the kernel itself advances the counters and writes st["step"]
                 _lib.check(L.egs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), NN, arr(4), arr(5), arr(6), float(betas[0]),
-                                                      float(betas[1]), float(eps), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                                      float(betas[1]), float(eps), skip, rows, RF if rows is not None else None,
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     @torch.no_grad()
     def step(self, closure=None):

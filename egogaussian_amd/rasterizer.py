@@ -39,26 +39,30 @@ class GaussianRasterizationSettings(NamedTuple):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                activation_flags=0, sh_rest=None, densify_stats=None):
+                activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None):
         rs = raster_settings
         if sh_rest is None:
             sh_rest = torch.empty(0, device=means3D.device, dtype=torch.float32)
         num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
-            rs.campos, rs.prefiltered, rs.debug, activation_flags, sh_rest)
+            rs.campos, rs.prefiltered, rs.debug, activation_flags, sh_rest, active_count, guard)
+        ctx.guard = guard
         ctx.raster_settings = rs
         ctx.activation_flags = int(activation_flags)
         ctx.densify_stats = densify_stats           # (tensors updated in place by the backward; not autograd inputs)
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img,
                               alpha, sh_rest)
-        ctx.mark_non_differentiable(radii)
+        # radii > 0, straight from the preprocess kernel (a bool view of the geometry buffer: read-only for the caller).  Returned
+        # as a fifth output instead of through any module-level state, so concurrent renders cannot see each other's mask.
+        visible = _C.visible_view(geom, means3D.shape[0])
+        ctx.mark_non_differentiable(radii, visible)
         ctx.set_materialize_grads(False)        # unused depth/alpha outputs arrive as None in backward, not as zero images
-        return color, radii, depth, alpha
+        return color, radii, depth, alpha, visible
 
     @staticmethod
-    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha, grad_visible=None):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, alpha, sh_rest = ctx.saved_tensors
         H, W = int(rs.image_height), int(rs.image_width)
@@ -73,25 +77,28 @@ class _RasterizeGaussians(torch.autograd.Function):
         grads = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos, geom,
-            ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags, sh_rest if split else None, ctx.densify_stats)
+            ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags, sh_rest if split else None, ctx.densify_stats, ctx.guard)
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = grads[:8]
         none_if_absent = lambda g, x: g if x.numel() != 0 else None
         return (g_means3D, g_means2D, none_if_absent(g_sh, sh), none_if_absent(g_colors, colors_precomp),
                 g_opac, none_if_absent(g_scales, scales),
                 none_if_absent(g_rots, rotations), none_if_absent(g_cov3D, cov3Ds_precomp), None, None,
-                grads[8] if split else None, None)
+                grads[8] if split else None, None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, activation_flags=0, sh_rest=None, densify_stats=None):
+                        raster_settings, activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None):
+    """-> (color, radii, depth, alpha, visible); upstream's function returns the first four, `visible` (bool[P] = radii > 0) is an
+    extension GaussianRasterizer keeps for render()."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, activation_flags, sh_rest, densify_stats)
+                                     cov3Ds_precomp, raster_settings, activation_flags, sh_rest, densify_stats, active_count, guard)
 
 
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
         self.raster_settings = raster_settings
+        self.visible = None             # bool[P] = radii > 0 of this module's most recent forward (an extension; see forward)
 
     def markVisible(self, positions):
         with torch.no_grad():
@@ -99,7 +106,7 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, raw_parameters=False, densify_stats=None):
+                cov3D_precomp=None, raw_parameters=False, densify_stats=None, active_count=None, guard=None):
         """Same call as upstream's.  raw_parameters=True (an extension): `scales`, `rotations` and `opacities` are the model's RAW
         parameters (log-scales, unnormalised quaternions, opacity logits); the activations run inside the preprocess kernel and
         the gradients come back w.r.t. the raw tensors (include/egs_raster.h, EGS_ACT_*).
@@ -107,6 +114,9 @@ class GaussianRasterizer(nn.Module):
         (/root/reference/scene/gaussian_model.py:157-160) -- which spares the torch.cat of get_features and the split of its gradient."""
         # densify_stats (an extension): (xyz_gradient_accum, denom, max_radii2D or None) -- the backward updates the trainer's
         # densification statistics in place, in the kernel that produces the screen-space gradient (include/egs_raster.h)
+        # active_count (an extension): int32[1] device tensor = live rows of a capacity-sized model; guard: a _C.StepGuard
+        # After the call `self.visible` holds radii > 0 as a bool view the preprocess kernel wrote (no compare launch); it aliases
+        # state saved for the backward and, under hipGraph replay, follows every replay -- clone it to keep or edit it.
         shs_rest = None
         if isinstance(shs, (tuple, list)):
             shs, shs_rest = shs
@@ -125,5 +135,7 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         if raw_parameters and cov3D_precomp.numel() != 0:
             raise Exception("GaussianRasterizer: raw_parameters needs `scales` and `rotations`, not `cov3D_precomp`")
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   self.raster_settings, _C.ACT_RAW_PARAMETERS if raw_parameters else 0, shs_rest, densify_stats)
+        color, radii, depth, alpha, self.visible = rasterize_gaussians(
+            means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, self.raster_settings,
+            _C.ACT_RAW_PARAMETERS if raw_parameters else 0, shs_rest, densify_stats, active_count, guard)
+        return color, radii, depth, alpha

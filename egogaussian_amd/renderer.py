@@ -37,9 +37,14 @@ def _screenspace_leaf(xyz):
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, rot_cov=False,
-           accum_R=None, which_object=None, during_training=False, fused_densify_stats=False):
-    """fused_densify_stats (an extension, default off): the backward of this render also updates pc.xyz_gradient_accum, pc.denom and
-    pc.max_radii2D in place (the trainer then skips add_densification_stats / the max_radii2D update for this iteration)."""
+           accum_R=None, which_object=None, during_training=False, fused_densify_stats=False, guard=None):
+    """Extensions (defaults = the reference's behaviour):
+    fused_densify_stats  the backward of this render also updates pc.xyz_gradient_accum, pc.denom and pc.max_radii2D in place
+                         (the trainer then skips add_densification_stats / the max_radii2D update for this iteration);
+    guard                a _C.StepGuard: device words a captured training step uses to void an overflowed frame (graph.py);
+    a model with an `active_count` attribute (int32[1] device tensor; capacity.CapacityGaussians) renders only its live rows.
+    `visibility_filter` is radii > 0 as written by the preprocess kernel: a fresh tensor in eager calls; while a hipGraph is being
+    captured it is a VIEW of the rasterizer's saved state that follows every replay (no launch) -- clone it to keep or edit it."""
     xyz = pc.get_xyz
     screenspace_points = _screenspace_leaf(xyz)
     rasterizer = GaussianRasterizer(raster_settings=get_raster_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
@@ -48,7 +53,11 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     raw = False
     if pipe.compute_cov3D_python:
         if rot_cov:
-            cov3D_precomp = pc.get_rotated_covariance(accum_R, which_object, during_training, scaling_modifier)
+            if getattr(pc, "get_rotated_covariance_and_opacity", None) is not None:
+                # optional fused producer: rotated covariance and activated opacity from the raw parameters in one launch
+                cov3D_precomp, opacity = pc.get_rotated_covariance_and_opacity(accum_R, which_object, during_training, scaling_modifier)
+            else:
+                cov3D_precomp = pc.get_rotated_covariance(accum_R, which_object, during_training, scaling_modifier)
         elif getattr(pc, "get_raw_parameters", None) is not None and pc.get_raw_parameters() is not None:
             # optional hook: hand the RAW parameters to the rasterizer, which applies exp / normalize / sigmoid itself and builds
             # the covariance in its preprocess kernel -- no activation or covariance launches at all (rasterizer.py)
@@ -80,11 +89,14 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     image, radii, depth, alpha = rasterizer(means3D=xyz, means2D=screenspace_points, shs=shs,
                                             colors_precomp=colors_precomp, opacities=pc.get_opacity if opacity is None else opacity, scales=scales,
                                             rotations=rotations, cov3D_precomp=cov3D_precomp, **({"raw_parameters": True} if raw else {}),
-                                            **({"densify_stats": (pc.xyz_gradient_accum, pc.denom, pc.max_radii2D)} if fused_densify_stats else {}))
-    from . import _C
-    visible = _C.stats.get("visible_view")                 # radii > 0, written by the preprocess kernel of the call above
-    if visible is None or visible.shape != radii.shape or visible.device != radii.device:
+                                            **({"densify_stats": (pc.xyz_gradient_accum, pc.denom, pc.max_radii2D)} if fused_densify_stats else {}),
+                                            **({"active_count": pc.active_count} if getattr(pc, "active_count", None) is not None else {}),
+                                            **({"guard": guard} if guard is not None else {}))
+    visible = rasterizer.visible                           # radii > 0 from the preprocess kernel of THIS call (returned, not shared state)
+    if visible is None:
         visible = radii > 0
+    elif not torch.cuda.is_current_stream_capturing():
+        visible = visible.clone()                          # eager: the caller owns it, as with the reference's `radii > 0`
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": visible, "radii": radii,
             "depth": depth, "alpha": alpha}
 

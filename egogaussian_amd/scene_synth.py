@@ -204,6 +204,27 @@ class SynthGaussians:
             return fused.covariance_and_opacity(self._scaling, scaling_modifier, self._rotation, self._opacity)
         return self.get_covariance(scaling_modifier), self.get_opacity
 
+    def _object_selection(self, which_object):
+        """fused.object_selection for this model, kept until `_is_object` is replaced or edited (it depends on nothing else)."""
+        from . import fused
+        key = (which_object, self._is_object.data_ptr(), self._is_object._version, tuple(self._is_object.shape))
+        if getattr(self, "_sel_key", None) != key:
+            self._sel_cache = fused.object_selection(self._is_object, which_object, self._xyz.shape[0])
+            self._sel_key = key
+        return self._sel_cache
+
+    def get_rotated_covariance_and_opacity(self, accum_R, which_object, during_training, scaling_modifier=1):
+        """Optional hook render(rot_cov=True) looks for: object-rotated covariance and activated opacity from the raw parameters in one
+        launch each way (HIP devices only; same values as get_rotated_covariance + get_opacity)."""
+        tom = self.trainable_object_move if during_training else None
+        if self.fused and self._xyz.is_cuda:
+            from . import fused
+            return fused.rotated_covariance_from_scaling_rotation(
+                self._scaling, scaling_modifier, self._rotation, accum_R, self._is_object, which_object,
+                None if tom is None else tom.rot_matrix(), scaling_is_log=True, selection=self._object_selection(which_object),
+                opacity_raw=self._opacity)
+        return self.get_rotated_covariance(accum_R, which_object, during_training, scaling_modifier), self.get_opacity
+
     def get_rotated_covariance(self, accum_R, which_object, during_training, scaling_modifier=1):
         tom = self.trainable_object_move if during_training else None
         if self.fused and self._xyz.is_cuda:

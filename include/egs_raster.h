@@ -24,8 +24,13 @@
  * Conventions
  *   - All pointers are DEVICE pointers unless marked HOST.  fp32, contiguous, row-major.
  *   - The library never allocates or frees device memory; every buffer is owned by the caller and must
- *     stay alive until the work enqueued on `stream` has completed.  The only process-wide state is the
- *     optional profiling pool (egs_profile_begin / egs_profile_end), off by default.
+ *     stay alive until the work enqueued on `stream` has completed.
+ *   - Process-wide state, all of it: (1) the optional profiling pool (egs_profile_begin / egs_profile_end), off by
+ *     default; (2) the two debug switches egs_debug_set_tile_culling / egs_debug_force_ballot_rank (plain ints read
+ *     by every subsequent forward of the process; neither changes an output value); (3) the result of the one-time
+ *     device check behind the tile sort's ranker (an atomic int); (4) one hipEvent per calling thread inside
+ *     egs_forward (thread_local).  Nothing else is kept between calls; concurrent calls on different streams /
+ *     threads are safe as long as they do not flip the debug switches meanwhile.
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it.  egs_forward_geometry is
  *     the only call that waits on the stream (one 8-byte device->host read of R).
  *   - Matrices use the reference's row-vector layout (/root/reference/scene/cameras.py:67-69):
@@ -46,7 +51,7 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 1
+#define EGS_ABI_VERSION 2
 #define EGS_TILE 16                 /* tile edge in pixels; part of the parity contract */
 #define EGS_MAX_SH_DEGREE 3
 
@@ -69,7 +74,9 @@ size_t egs_backward_scratch_bytes(int P);
 
 /* ---- buffer layouts, for tests and tools: byte offsets of the named sub-arrays ----------------- */
 typedef struct egs_geom_layout {
-    size_t rec;            /* float4[P][3]  packed splat record: (x, y, depth, opacity | conA, conB, conC, r | g, b, bbox_x, bbox_y) */
+    size_t rec;            /* float4[P][3]  packed splat record (csrc/egs_common.h): (x, y, qa, qb | qc, opacity, red, green |
+                              blue, depth, bits(bbox_x = x0 | x1<<16), bits(bbox_y = y0 | y1<<16)) with (qa, qb, qc) =
+                              (-conA/2, -conB, -conC/2) * log2(e), the conic pre-scaled for v_exp_f32 */
     size_t rect;           /* uint32[P][2]  tile rect: (x0 | x1<<16, y0 | y1<<16) */
     size_t offsets;        /* uint32[P]     tiles touched by each Gaussian (0 = culled) */
     size_t clamped;        /* uint8[P]      bit c set <=> colour channel c was clamped at 0 */
@@ -96,6 +103,9 @@ typedef struct egs_image_layout {
     size_t n_contrib;      /* uint32[H*W] */
     size_t quad_work;      /* uint32[tiles][4] estimated backward cost of every 8x8 quadrant (blended splats and list batches), written by the forward */
     size_t tile_order;     /* uint32[8*ceil(tiles/8)] tile handled by each workgroup of the backward blend */
+    size_t quad_pairs;     /* uint32[tiles][4] (pixel, splat) pairs every 8x8 quadrant blended (alpha >= 1/255, before saturation) and,
+                              in the upper array uint32[tiles][4] right after it, the (wave, splat) visits it made -- measurement only
+                              (bench.py: pair throughput Q/s) */
 } egs_image_layout;
 int egs_get_geom_layout(int P, egs_geom_layout* out);
 int egs_get_binning_layout(int P, int64_t R, int width, int height, egs_binning_layout* out);
@@ -125,6 +135,7 @@ int egs_forward_geometry(
     const float* viewmatrix /*[16]*/, const float* projmatrix /*[16]*/, const float* campos /*[3]*/,
     int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
     int32_t* radii /*[P] out*/, void* geom_buffer, int64_t* num_rendered /*HOST out: R*/,
+    const int32_t* active_count /*device int32[1] or NULL; see "capacity-sized models" below*/,
     void* stream, int debug);
 
 /* ---- forward, part 2: bucket instances by tile, sort each tile by (depth, index), blend
@@ -136,6 +147,18 @@ int egs_forward_render(
     const void* geom_buffer, void* binning_buffer, void* image_buffer,
     float* out_color /*[3,H,W]*/, float* out_depth /*[1,H,W]*/, float* out_alpha /*[1,H,W]*/,
     void* stream, int debug);
+
+/* Capacity-sized models (ABI 2).  A trainer that densifies / prunes every 100 iterations
+ * (/root/reference/scene/gaussian_model.py:565-586,678-709) can keep its arrays at a fixed CAPACITY of P rows and the number
+ * of live Gaussians in a device word: with active_count != NULL rows i >= *active_count are treated as culled (radii 0, no
+ * instances, zero gradients), whatever their contents.  P, every launch size and every buffer layout then stay fixed while
+ * the model grows and shrinks, so a hipGraph captured around the step survives densification.  NULL: all P rows are live.
+ *
+ * Overflow word (ABI 2).  egs_forward_enqueue cannot report a too-small `capacity` to the host; with overflow_flag != NULL
+ * (device uint32[2]) the chain WRITES [0] = 1 when this frame needed more than `capacity` instances (its image is then
+ * clipped and invalid), else 0, and [1] = the number of instances the frame bucketed.  Passed on as `skip_flag` to egs_backward and egs_adam_step_capturable it makes the
+ * rest of a captured training step a no-op for that frame: no densification statistics, no parameter, moment or step-count
+ * update -- every optimizer step follows a complete render, as in the reference (trainers/train_static.py:110-138). */
 
 /* ---- forward in ONE call, without a GPU bubble.  Same work as egs_forward_geometry + egs_forward_render, but the
  *      binning and blend kernels are enqueued against `capacity` (the caller's guess of R, e.g. 1.25 x the largest R seen
@@ -152,7 +175,7 @@ int egs_forward(
     int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
     int32_t* radii /*[P] out*/, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
     float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts /*HOST, page-locked*/,
-    int64_t* num_rendered /*HOST out*/, void* stream, int debug);
+    int64_t* num_rendered /*HOST out*/, const int32_t* active_count /*device int32[1] or NULL*/, void* stream, int debug);
 
 /* ---- the same chain with NO host wait, for hipGraph capture of a whole training step: everything is only enqueued
  *      (capacity must be > 0).  A frame that needs more than `capacity` instances is invalid (its kernels were clipped to
@@ -167,7 +190,8 @@ int egs_forward_enqueue(
     const float* viewmatrix, const float* projmatrix, const float* campos, const float* background,
     int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
     int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
-    float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max, void* stream);
+    float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
+    const int32_t* active_count /*device int32[1] or NULL*/, uint32_t* overflow_flag /*device uint32[2] out or NULL*/, void* stream);
 int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts /*HOST*/);
 
 /* ---- backward  (upstream: render backward + computeCov2D backward + preprocess backward) ------- */
@@ -190,6 +214,7 @@ int egs_backward(
      * (/root/reference/scene/gaussian_model.py:735-737) and max_radii[i] = max(max_radii[i], radii[i])
      * (/root/reference/trainers/train_static.py:125).  Same arithmetic as egs_densify_stats, one launch less per iteration. */
     float* stat_grad_accum /*[P] in/out or NULL*/, float* stat_denom /*[P] in/out or NULL*/, float* stat_max_radii /*[P] in/out or NULL*/,
+    const uint32_t* skip_flag /*device uint32[1] or NULL: non-zero = leave the three statistics untouched (overflowed frame)*/,
     void* scratch /* egs_backward_scratch_bytes(P) */, void* stream, int debug);
 
 /* ---- frustum test only  (upstream: markVisible) -------------------------------------------------- */
@@ -259,10 +284,15 @@ int egs_adam_step(int n_tensors, float* const* params, const float* const* grads
  * other kernel to keep count.  `step_dev[t]` (device float[1]) is WRITTEN with the number of the step
  * just taken (torch's state["step"]). */
 int64_t egs_adam_workgroups(int64_t numel);
+/* ABI 2: `skip_flag` (device uint32[1] or NULL) non-zero makes the launch a no-op (parameters, moments, counters and step_dev
+ * untouched) -- the overflow word of egs_forward_enqueue.  `active_rows` (device int32[1] or NULL) with `row_floats` (HOST
+ * int32[n_tensors], 0 = whole tensor) limits tensor t to its first *active_rows * row_floats[t] elements: the live rows of a
+ * capacity-sized model. */
 int egs_adam_step_capturable(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                              float* const* exp_avg_sq, const int64_t* numels, float* const* step_dev /*HOST array of device ptrs*/,
                              const float* const* lr_dev /*HOST array of device ptrs*/, uint32_t* const* counters /*HOST array of device ptrs*/,
-                             float beta1, float beta2, float eps, void* stream);
+                             float beta1, float beta2, float eps, const uint32_t* skip_flag, const int32_t* active_rows,
+                             const int32_t* row_floats /*HOST or NULL*/, void* stream);
 
 /* ---- f-4 (densify / prune part): the bookkeeping of /root/reference/scene/gaussian_model.py:506-709,735-740 on the device.
  *      egs_densify_stats         per-iteration statistics in one pass: for every visible Gaussian (visible[i] != 0, or

@@ -106,3 +106,32 @@ def check_culled_lists(st, ranges_hip, point_list_hip, H, W):
         worst = max(worst, float(alpha.max()) if alpha.size else 0.0)
     assert worst < (1.0 / 255.0) * (1 + 1e-5), f"a culled instance reaches alpha {worst} >= 1/255 somewhere in its tile"
     return int(kept.sum()), int((~kept).sum())
+
+
+class OracleRasterize(torch.autograd.Function):
+    """The C oracle (forward + analytic backward) as a CPU autograd op, so that an oracle-side TRAINING chain (torch covariance ->
+    oracle rasterizer -> torch loss -> torch Adam) can run for hundreds of steps in seconds.  Test infrastructure only.
+    Inputs: means3D [N,3], opacities [N,1], shs [N,M,3], cov3D [N,6] (float32 CPU tensors) + a dict of camera / image constants."""
+
+    @staticmethod
+    def forward(ctx, means3D, opacities, shs, cov3D, const):
+        from oracle.oracle import Oracle
+        o = Oracle(np.float32, nthreads=const.get("nthreads", 8))
+        st = o.forward(means3D=means3D, opacities=opacities, shs=shs, cov3D_precomp=cov3D, viewmatrix=const["viewmatrix"],
+                       projmatrix=const["projmatrix"], campos=const["campos"], bg=const["bg"], image_height=const["H"], image_width=const["W"],
+                       tanfovx=const["tanfovx"], tanfovy=const["tanfovy"], sh_degree=const.get("sh_degree", 0))
+        ctx.o, ctx.st, ctx.shapes = o, st, (means3D.shape, opacities.shape, shs.shape, cov3D.shape)
+        return torch.from_numpy(np.ascontiguousarray(st["color"], dtype=np.float32))
+
+    @staticmethod
+    def backward(ctx, g_color):
+        gb = ctx.o.backward(ctx.st, g_color.contiguous(), None, None)
+        t = lambda a, s: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).reshape(s)
+        return (t(gb["dL_dmeans3D"], ctx.shapes[0]), t(gb["dL_dopacity"], ctx.shapes[1]), t(gb["dL_dsh"], ctx.shapes[2]),
+                t(gb["dL_dcov3D"], ctx.shapes[3]), None)
+
+
+def quantize_8bit(img):
+    """What a rendered image goes through before the reference's metrics read it back: torchvision.utils.save_image to PNG
+    (/root/reference/trainers/eval_metric.py:113-120) = round(255 x) clamped to [0, 255], then / 255 on load."""
+    return torch.floor(img * 255.0 + 0.5).clamp(0, 255) / 255.0

@@ -4,7 +4,8 @@ splat size, camera) draws -- lists bit-exact with tile culling off, an ordered s
 within the test tolerances (a handful of entries may sit on the other side of an alpha threshold: the two implementations
 round alpha differently in the last place).  Complements tests/test_gpu_parity.py (fixed cases); run it for as long as you like:
     python tests/fuzz_parity.py [seconds] [seed]
-(lives under tests/ because it uses the oracle, which is test infrastructure; pytest does not collect it)"""
+(lives under tests/ because it uses the oracle, which is test infrastructure; tests/test_gpu_sweep.py runs a fixed-seed slice
+of it -- 320 draws -- under pytest -m gpu)"""
 import os, sys, time
 import numpy as np
 import torch
@@ -14,67 +15,77 @@ from tests.common import make_inputs, seeded_grads, rel_err, outlier_fraction, t
 from tests.test_gpu_parity import hip_forward, hip_backward, oracle_forward, TOL                                     # noqa: E402
 from egogaussian_amd import _C                                                                                       # noqa: E402
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-dev = torch.device("cuda:0")
-t_end, n_cases, worst = time.time() + budget, 0, {}
-while time.time() < t_end:
-    N = int(rng.choice([1, 2, 63, 64, 65, 300, 1023, 1025, 2500, 7000, 20000, 70000]))
-    H, W = int(rng.integers(1, 300)), int(rng.integers(1, 420))
-    mode = str(rng.choice(["sh_cov", "sh_sr", "col_sr", "col_cov"]))
-    deg = int(rng.integers(0, 4)) if mode.startswith("sh") else 0
-    active = int(rng.integers(0, deg + 1))
-    smul = float(rng.choice([0.5, 1.0, 2.0, 4.0, 8.0]))
-    frame = int(rng.integers(0, 300))
-    cull = bool(rng.integers(0, 2))
-    split = bool(rng.integers(0, 2)) and deg > 0                      # hand the coefficients over as (dc, rest)
-    tag = f"N={N} {W}x{H} {mode} M={(deg + 1) ** 2} active={active} scale x{smul} frame {frame} culling {'on' if cull else 'off'}{' split-SH' if split else ''}"
-    d = make_inputs(N, H, W, int(rng.integers(0, 1000)), deg, mode, frame=frame, scale_mul=smul, opacity_shift=float(rng.choice([0.0, 2.0, -2.0])))
-    d["sh_degree"] = active
-    o, st = oracle_forward(d)
-    with tile_culling(cull):
-        if split:
-            g = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
-            e0 = torch.empty(0, device=dev)
-            dc, rest = g["shs"][:, :1].contiguous(), g["shs"][:, 1:].contiguous()
-            out = _C.rasterize_gaussians(g["bg"], g["means3D"], e0, g["opacities"], g.get("scales", e0), g.get("rotations", e0), 1.0,
-                                         g.get("cov3D_precomp", e0), g["viewmatrix"], g["projmatrix"], g["tanfovx"], g["tanfovy"], H, W, dc, active,
-                                         g["campos"], False, False, 0, rest)
-        else:
-            g, out = hip_forward(d, dev)
-        R, color, depth, alpha, radii, geom, binning, img = out
-        torch.cuda.synchronize()
-        assert R == st["R"], tag
-        assert np.array_equal(radii.cpu().numpy(), st["radii"]), tag
-        if R:
-            bv = _C.binning_views(binning, N, R, W, H, _C.stats["capacity"]); iv = _C.image_views(img, W, H)
-            pl = bv["point_list"].cpu().numpy().view(np.uint32); rngs = iv["ranges"].cpu().numpy().view(np.uint32)
-            if cull:
-                check_culled_lists(st, rngs, pl, H, W)
+
+def run_draws(seed=0, budget_s=None, n_draws=None, dev=None, verbose=False):
+    """Random draws until `n_draws` are done or `budget_s` seconds have passed.  -> (cases run, worst max-relative gradient errors)."""
+    rng = np.random.default_rng(int(seed))
+    dev = torch.device("cuda:0") if dev is None else dev
+    t_end, n_cases, worst = (time.time() + budget_s) if budget_s else None, 0, {}
+    while (n_draws is None or n_cases < n_draws) and (t_end is None or time.time() < t_end):
+        N = int(rng.choice([1, 2, 63, 64, 65, 300, 1023, 1025, 2500, 7000, 20000, 70000]))
+        H, W = int(rng.integers(1, 300)), int(rng.integers(1, 420))
+        mode = str(rng.choice(["sh_cov", "sh_sr", "col_sr", "col_cov"]))
+        deg = int(rng.integers(0, 4)) if mode.startswith("sh") else 0
+        active = int(rng.integers(0, deg + 1))
+        smul = float(rng.choice([0.5, 1.0, 2.0, 4.0, 8.0]))
+        frame = int(rng.integers(0, 300))
+        cull = bool(rng.integers(0, 2))
+        split = bool(rng.integers(0, 2)) and deg > 0                      # hand the coefficients over as (dc, rest)
+        tag = f"N={N} {W}x{H} {mode} M={(deg + 1) ** 2} active={active} scale x{smul} frame {frame} culling {'on' if cull else 'off'}{' split-SH' if split else ''}"
+        if verbose:
+            print(tag, flush=True)
+        d = make_inputs(N, H, W, int(rng.integers(0, 1000)), deg, mode, frame=frame, scale_mul=smul, opacity_shift=float(rng.choice([0.0, 2.0, -2.0])))
+        d["sh_degree"] = active
+        o, st = oracle_forward(d)
+        with tile_culling(cull):
+            if split:
+                g = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+                e0 = torch.empty(0, device=dev)
+                dc, rest = g["shs"][:, :1].contiguous(), g["shs"][:, 1:].contiguous()
+                out = _C.rasterize_gaussians(g["bg"], g["means3D"], e0, g["opacities"], g.get("scales", e0), g.get("rotations", e0), 1.0,
+                                             g.get("cov3D_precomp", e0), g["viewmatrix"], g["projmatrix"], g["tanfovx"], g["tanfovy"], H, W, dc, active,
+                                             g["campos"], False, False, 0, rest)
             else:
-                assert np.array_equal(pl, st["point_list"]) and np.array_equal(rngs, st["ranges"]), tag
-        for name, hip, ora in (("colour", color, st["color"]), ("depth", depth, st["depth"]), ("alpha", alpha, st["alpha"])):
-            f = outlier_fraction(hip.cpu().numpy(), ora, TOL)
-            assert f <= max(1e-3, 8.0 / hip.numel()), f"{tag}: {name} outliers {f}"
-        grads = seeded_grads(H, W, 7)
-        if split:
-            gc, gd, ga = [x.to(dev) for x in grads]
-            full = _C.rasterize_gaussians_backward(g["bg"], g["means3D"], radii, e0, g.get("scales", e0), g.get("rotations", e0), 1.0,
-                                                   g.get("cov3D_precomp", e0), g["viewmatrix"], g["projmatrix"], g["tanfovx"], g["tanfovy"], gc, gd, ga,
-                                                   dc, active, g["campos"], geom, R, binning, img, alpha, False, 0, rest)
-            hb = list(full[:8]); hb[5] = torch.cat((full[5], full[8]), dim=1)
-        else:
-            hb = hip_backward(g, out, grads, dev)
-        torch.cuda.synchronize()
-    gb = o.backward(st, *grads)
-    for name, h in zip(["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot"], hb):
-        ora = gb.get(name)
-        if ora is None or h.numel() == 0:
-            continue
-        hh = h.cpu().numpy().reshape(ora.shape)
-        assert np.isfinite(hh).all() == np.isfinite(ora).all(), f"{tag}: {name} finiteness"
-        f, e = outlier_fraction(hh, ora, TOL), rel_err(hh, ora)
-        worst[name] = max(worst.get(name, 0.0), e)
-        assert f <= max(1e-3, 8.0 / hh.size) and e < 2e-2, f"{tag}: {name} outliers {f} max rel {e}"
-    n_cases += 1
-print(f"{n_cases} random cases passed in {budget:.0f} s; worst max-relative gradient errors: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+                g, out = hip_forward(d, dev)
+            R, color, depth, alpha, radii, geom, binning, img = out
+            torch.cuda.synchronize()
+            assert R == st["R"], tag
+            assert np.array_equal(radii.cpu().numpy(), st["radii"]), tag
+            if R:
+                bv = _C.binning_views(binning, N, R, W, H, _C.stats["capacity"]); iv = _C.image_views(img, W, H)
+                pl = bv["point_list"].cpu().numpy().view(np.uint32); rngs = iv["ranges"].cpu().numpy().view(np.uint32)
+                if cull:
+                    check_culled_lists(st, rngs, pl, H, W)
+                else:
+                    assert np.array_equal(pl, st["point_list"]) and np.array_equal(rngs, st["ranges"]), tag
+            for name, hip, ora in (("colour", color, st["color"]), ("depth", depth, st["depth"]), ("alpha", alpha, st["alpha"])):
+                f = outlier_fraction(hip.cpu().numpy(), ora, TOL)
+                assert f <= max(1e-3, 8.0 / hip.numel()), f"{tag}: {name} outliers {f}"
+            grads = seeded_grads(H, W, 7)
+            if split:
+                gc, gd, ga = [x.to(dev) for x in grads]
+                full = _C.rasterize_gaussians_backward(g["bg"], g["means3D"], radii, e0, g.get("scales", e0), g.get("rotations", e0), 1.0,
+                                                       g.get("cov3D_precomp", e0), g["viewmatrix"], g["projmatrix"], g["tanfovx"], g["tanfovy"], gc, gd, ga,
+                                                       dc, active, g["campos"], geom, R, binning, img, alpha, False, 0, rest)
+                hb = list(full[:8]); hb[5] = torch.cat((full[5], full[8]), dim=1)
+            else:
+                hb = hip_backward(g, out, grads, dev)
+            torch.cuda.synchronize()
+        gb = o.backward(st, *grads)
+        for name, h in zip(["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot"], hb):
+            ora = gb.get(name)
+            if ora is None or h.numel() == 0:
+                continue
+            hh = h.cpu().numpy().reshape(ora.shape)
+            assert np.isfinite(hh).all() == np.isfinite(ora).all(), f"{tag}: {name} finiteness"
+            f, e = outlier_fraction(hh, ora, TOL), rel_err(hh, ora)
+            worst[name] = max(worst.get(name, 0.0), e)
+            assert f <= max(1e-3, 8.0 / hh.size) and e < 2e-2, f"{tag}: {name} outliers {f} max rel {e}"
+        n_cases += 1
+    return n_cases, worst
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    n_cases, worst = run_draws(int(sys.argv[2]) if len(sys.argv) > 2 else 0, budget_s=budget)
+    print(f"{n_cases} random cases passed in {budget:.0f} s; worst max-relative gradient errors: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))

@@ -43,3 +43,39 @@ def test_single_process_is_identity():
     assert d.env_world() == (0, 1, 0) and d.shard_frames(7, 0, 1) == list(range(7))
     assert d.reduce_scalars([1.5, 2.0]) == [1.5, 2.0]
     d.barrier()
+
+
+def test_bench_plain_launch_command():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run, one rank per GPU, rendezvous
+    on 127.0.0.1 (the container's hostname may not resolve)."""
+    import importlib.util, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    cmd = bench.spawn_command(4, ["--gpus", "4", "--steps", "5"], port=29517)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    assert cmd[-5:] == [os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "5"]
+    port = int(bench.spawn_command(2, [])[bench.spawn_command(2, []).index("--master-port") + 1])
+    assert 1024 < port < 65536
+
+
+def test_counter_files_are_tied_to_the_kernel_sources():
+    """bench.py reports profiles/*.json numbers only when they were collected on the present kernel sources."""
+    import importlib.util, json, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    from egogaussian_amd import lib
+    h = lib.kernel_source_hash()
+    assert len(h) == 16 and h == lib.kernel_source_hash()
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "c.json")
+        json.dump({"_source_hash": h, "500000@960x540": {"render_backward": {"hbm_bytes_per_launch": 5}}}, open(p, "w"))
+        ent, why = bench.stamped(p, "500000@960x540", h)
+        assert why is None and ent["render_backward"]["hbm_bytes_per_launch"] == 5
+        ent, why = bench.stamped(p, "500000@960x540", "0" * 16)
+        assert ent is None and "collected at kernel-source hash" in why
+        ent, why = bench.stamped(p, "1@1x1", h)
+        assert ent is None and "no entry" in why
+        assert bench.stamped(os.path.join(d, "absent.json"), "k", h) == (None, "absent.json absent")

@@ -1,0 +1,175 @@
+"""GPU: the BENCHED configuration itself against the oracle, PSNR parity at a meaningful size, and the multi-rank entry point.
+
+  * config C (500k Gaussians @ 960x540) in exactly the mode bench.py times -- raw parameters activated inside the preprocess
+    kernel, tile culling on, the step replayed from a captured hipGraph -- image, radii and the five parameter gradients
+    against the C oracle chained through the torch activations / covariance (north star: 1e-4 relative fp32);
+  * 300 seeded training steps at config A size (10k @ 64x64), GPU chain vs oracle chain: |dPSNR| <= 0.05 dB on float images
+    and after the 8-bit PNG round trip the reference's metrics go through (/root/reference/trainers/eval_metric.py:113-120,159-161);
+  * bench.py --gpus 2 launched with a bare `python`: two ranks (sharing the one GPU of the test box over gloo), real
+    graph-replayed steps, disjoint frame sets, equal replicas at the start, scalars reduced."""
+import json
+import math
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.common import rel_err, outlier_fraction, OracleRasterize, quantize_8bit
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-4
+
+
+def test_config_C_bench_mode_vs_oracle():
+    from egogaussian_amd import _C
+    from egogaussian_amd.covariance import covariance_from_scaling_rotation
+    from egogaussian_amd.graph import GraphedTrainStep, pack_frame
+    from egogaussian_amd.losses import training_loss
+    from egogaussian_amd.optim import FusedAdam
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
+    from oracle.oracle import Oracle
+    dev = torch.device("cuda:0")
+    N, H, W = 500_000, 540, 960
+    teacher = make_scene(N, H, W, seed=0)
+    bg = torch.zeros(3, device=dev)
+    cams = [make_camera(k, H, W, device=dev) for k in (0, 7)]
+    with torch.no_grad():
+        tpc = SynthGaussians(teacher, device=dev, requires_grad=False)
+        gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
+    pc = SynthGaussians(perturb_student(teacher), device=dev)
+    assert pc.get_raw_parameters() is not None and _C.set_tile_culling(True) in (True, False)      # the benched mode: raw parameters, culling on
+    opt = FusedAdam([{"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3}, {"params": [pc._opacity], "lr": 0.05},
+                     {"params": [pc._scaling], "lr": 5e-3}, {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15, capturable=True)
+    step = GraphedTrainStep(pc, opt, bg, 0.2).capture(cams[0], gts[0], warmup=2)
+    params = dict(xyz=pc._xyz, f_dc=pc._features_dc, opacity=pc._opacity, scaling=pc._scaling, rotation=pc._rotation)
+    before = {k: v.detach().cpu().clone() for k, v in params.items()}          # the model the replayed step renders
+    step(pack_frame(cams[1], gts[1]))                                          # ONE replay on another frame
+    torch.cuda.synchronize()
+    assert step.ok() and not step.last_frame_overflowed()
+    img_hip, radii_hip = step.image.cpu().numpy(), step.radii.cpu().numpy()
+    grads_hip = {k: v.grad.detach().cpu().numpy() for k, v in params.items()}
+    assert all(not torch.equal(v.detach().cpu(), before[k]) for k, v in params.items())       # Adam did step
+
+    # oracle side: torch activations + covariance (pinned by covariance.npz) -> C oracle -> torch loss (pinned by losses.npz)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in before.items()}
+    cov = covariance_from_scaling_rotation(torch.exp(leaf["scaling"]), 1.0, leaf["rotation"])
+    opac = torch.sigmoid(leaf["opacity"])
+    cam = cams[1]
+    o = Oracle(np.float32, nthreads=min(64, os.cpu_count() or 8))
+    st = o.forward(means3D=leaf["xyz"], opacities=opac, shs=leaf["f_dc"], cov3D_precomp=cov, viewmatrix=cam.world_view_transform.cpu(),
+                   projmatrix=cam.full_proj_transform.cpu(), campos=cam.camera_center.cpu(), bg=bg.cpu(), image_height=H, image_width=W,
+                   tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
+    assert np.array_equal(radii_hip, st["radii"]), "radii differ (raw-parameter activations vs torch's differ in the last ulp at a rounding boundary?)"
+    img_or = torch.tensor(st["color"], dtype=torch.float32, requires_grad=True)
+    training_loss(img_or, gts[1].cpu(), 0.2).backward()
+    gb = o.backward(st, img_or.grad)
+    t = lambda a, like: torch.tensor(np.asarray(a, dtype=np.float32)).reshape(like.shape)
+    torch.autograd.backward([cov, opac], [t(gb["dL_dcov3D"], cov), t(gb["dL_dopacity"], opac)])
+    grads_or = dict(xyz=gb["dL_dmeans3D"], f_dc=gb["dL_dsh"].reshape(N, 1, 3), opacity=leaf["opacity"].grad.numpy(),
+                    scaling=leaf["scaling"].grad.numpy(), rotation=leaf["rotation"].grad.numpy())
+    e_img, f_img = rel_err(img_hip, st["color"]), outlier_fraction(img_hip, st["color"], TOL)
+    flips = int((np.abs(img_hip - st["color"]) > TOL * np.abs(st["color"]).max()).any(0).sum())
+    print(f"\n  config C, benched mode: R = {st['R']}, image max rel err {e_img:.2e}, pixels off by more than {TOL:g}: {flips}")
+    assert f_img <= 1e-4 and e_img < 2e-2
+    for k in grads_or:
+        e, f = rel_err(grads_hip[k], grads_or[k]), outlier_fraction(grads_hip[k], grads_or[k], TOL)
+        print(f"    d/d{k}: max rel err {e:.2e}, entries off by more than {TOL:g}: {f:.1e}")
+        if flips == 0:
+            assert e < TOL, k
+        else:
+            assert f <= 2e-4 and e < 5e-3, k
+
+
+def test_training_psnr_parity_300_steps_float_and_8bit():
+    """config A size, 300 seeded steps, same camera order on both sides: the product chain on the GPU (raw-parameter rasterizer, fused
+    loss, FusedAdam) and the oracle chain on the CPU (torch activations + covariance, C oracle forward / analytic backward, torch
+    loss, torch Adam)."""
+    from egogaussian_amd.fused import l1_ssim_loss
+    from egogaussian_amd.losses import training_loss, psnr
+    from egogaussian_amd.optim import FusedAdam
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe, N_FRAMES
+    dev = torch.device("cuda:0")
+    N, H, W, K = 10_000, 64, 64, 300
+    teacher = make_scene(N, H, W, seed=4); teacher["log_scale"] += math.log(2.5)
+    # Student = teacher with xyz += N(0, 0.03^2), f_dc += N(0, 0.3^2): 23 dB at the start, 34 dB after the 300 steps and still climbing,
+    # i.e. the trajectory is driven by real gradients.  (With SURVEY 8d's smaller perturbation the same 300 steps reach 49 dB, where
+    # Adam at eps = 1e-15 turns last-bit differences of near-zero gradients into sign flips: two runs of the SAME GPU chain then end
+    # 0.06 dB apart -- float atomics order -- which says nothing about parity.  profiles/r2_psnr_probe.txt has both regimes.)
+    rng = np.random.default_rng(1001)
+    student = {k: v.copy() for k, v in teacher.items()}
+    student["xyz"] += rng.normal(0, 0.03, student["xyz"].shape).astype(np.float32)
+    student["features"][:, :1] += rng.normal(0, 0.3, student["features"][:, :1].shape).astype(np.float32)
+    train_frames, eval_frames = list(range(0, N_FRAMES, 25)), [12.5, 87.5, 162.5, 237.5]
+    lrs = [("_xyz", 1.6e-4), ("_features_dc", 2.5e-3), ("_opacity", 0.05), ("_scaling", 5e-3), ("_rotation", 1e-3)]
+
+    def const_of(cam):
+        return dict(viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, campos=cam.camera_center, bg=torch.zeros(3),
+                    H=H, W=W, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2), nthreads=8)
+
+    def cpu_render(cam, pc):
+        return OracleRasterize.apply(pc.get_xyz, pc.get_opacity, pc.get_features, pc.get_covariance(), const_of(cam))
+
+    res = {}
+    for side in ("gpu", "cpu"):
+        d = dev if side == "gpu" else "cpu"
+        bg = torch.zeros(3, device=d)
+        rend = (lambda c, p: render(c, p, Pipe, bg)["render"]) if side == "gpu" else cpu_render
+        cams = [make_camera(k, H, W, device=d) for k in train_frames]
+        ecams = [make_camera(k, H, W, device=d) for k in eval_frames]
+        with torch.no_grad():
+            tpc = SynthGaussians(teacher, device=d, requires_grad=False)
+            gts, egts = [rend(c, tpc).clone() for c in cams], [rend(c, tpc).clone() for c in ecams]
+        pc = SynthGaussians(student, device=d)
+        groups = [{"params": [getattr(pc, a)], "lr": lr} for a, lr in lrs]
+        opt = FusedAdam(groups, lr=0.0, eps=1e-15) if side == "gpu" else torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        rnd = random.Random(0)
+        for it in range(K):
+            k = rnd.randrange(len(cams))
+            img = rend(cams[k], pc)
+            loss = l1_ssim_loss(img, gts[k], 0.2) if side == "gpu" else training_loss(img, gts[k], 0.2)
+            loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            imgs = [rend(c, pc) for c in ecams]
+            pf = float(np.mean([psnr(i[None], g[None]).item() for i, g in zip(imgs, egts)]))
+            p8 = float(np.mean([psnr(quantize_8bit(i)[None], quantize_8bit(g)[None]).item() for i, g in zip(imgs, egts)]))
+            p0 = float(np.mean([psnr(rend(c, SynthGaussians(student, device=d, requires_grad=False))[None], g[None]).item() for c, g in zip(ecams, egts)]))
+        res[side] = (pf, p8, p0, egts[0].cpu())
+    print(f"\n  PSNR on 4 held-out views after {K} steps (start {res['gpu'][2]:.2f} dB): float gpu {res['gpu'][0]:.4f} / oracle chain {res['cpu'][0]:.4f} dB; "
+          f"8-bit gpu {res['gpu'][1]:.4f} / oracle chain {res['cpu'][1]:.4f} dB")
+    assert rel_err(res["gpu"][3].numpy(), res["cpu"][3].numpy()) < 1e-4            # same ground truth on both sides
+    assert res["gpu"][0] > res["gpu"][2] + 1.0, "training did not improve the held-out PSNR"
+    assert abs(res["gpu"][0] - res["cpu"][0]) <= 0.05 and abs(res["gpu"][1] - res["cpu"][1]) <= 0.05
+
+
+def test_bench_two_ranks_plain_launch():
+    """`python bench.py --gpus 2` with no launcher around it: the script re-executes itself as two ranks.  The test box has one
+    GPU, so both ranks share device 0 and talk over gloo (RCCL refuses two ranks on one device)."""
+    env = dict(os.environ, EGS_BENCH_SHARE_DEVICE0="1", EGS_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--gaussians", "60000", "--height", "270",
+           "--width", "480", "--no-cpu-baseline", "--no-sh3-leg", "--verify-ranks"]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = [l for l in run.stdout.strip().splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["scaling"] == "weak" and j["value"] > 0
+    r0, r1 = sorted(j["ranks"], key=lambda r: r["rank"])
+    assert (r0["rank"], r1["rank"]) == (0, 1)
+    assert r0["frames"] == list(range(0, 16, 2)) and r1["frames"] == list(range(1, 16, 2))       # 8 frames each (warmup + steps), disjoint
+    assert not set(r0["frames"]) & set(r1["frames"])
+    assert r0["param_checksum_start"] == r1["param_checksum_start"]                            # equal replicas at the start
+    assert r0["graph"] and r1["graph"] and r0["overflow"]["ok"] and r1["overflow"]["ok"]       # real graph-replayed steps on both ranks
+    assert r0["loss_sum"] > 0 and r1["loss_sum"] > 0 and r0["loss_sum"] != r1["loss_sum"]      # different frames -> different losses
+    assert abs(j["mean_loss"] - (r0["loss_sum"] + r1["loss_sum"]) / 12) < 1e-6                 # the reduced scalar
+    assert j["config"]["launch"] == "one hipGraph replay per step"
+    fa = j["fine_all_shape"]
+    assert fa["n_gpus"] == 2 and fa["value"] > 0 and fa["launch"].startswith("one hipGraph") and math.isfinite(fa["psnr_db"])
+    assert j["roofline"]["pairs_Q"] > 0 and j["roofline"]["visits"] > 0
