@@ -21,11 +21,12 @@ def attribute_names(n_dc, n_rest):
 
 
 def vertex_table(gaussians):
-    """-> (names, float32 [N, len(names)]) exactly as the reference assembles it."""
-    c = lambda t: t.detach().cpu().numpy().astype(np.float32)
+    """-> (names, float32 [N, len(names)]) exactly as the reference assembles it (the live rows of a capacity-sized model)."""
+    n = getattr(gaussians, "n_active", None)                      # capacity.CapacityGaussians: rows beyond it are not part of the model
+    c = lambda t: t.detach()[:n].cpu().numpy().astype(np.float32)
     xyz = c(gaussians._xyz)
-    f_dc = c(gaussians._features_dc.detach().transpose(1, 2).flatten(start_dim=1).contiguous())
-    f_rest = c(gaussians._features_rest.detach().transpose(1, 2).flatten(start_dim=1).contiguous())
+    f_dc = c(gaussians._features_dc.detach()[:n].transpose(1, 2).flatten(start_dim=1).contiguous())
+    f_rest = c(gaussians._features_rest.detach()[:n].transpose(1, 2).flatten(start_dim=1).contiguous())
     cols = [xyz, np.zeros_like(xyz), f_dc, f_rest, c(gaussians._opacity), c(gaussians._scaling), c(gaussians._rotation),
             c(gaussians._label), c(gaussians._generation), c(gaussians._is_object)]
     cols = [a.reshape(xyz.shape[0], -1) for a in cols]

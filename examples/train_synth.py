@@ -5,7 +5,13 @@ with the steady-state iterations replayed from a hipGraph and the point cloud wr
 
     python examples/train_synth.py --gaussians 20000 --height 270 --width 480 --iters 600 --out /tmp/synth.ply
 
-It shows the order of calls a trainer needs (and where a re-capture is required); it is not part of the measured path.
+The model is capacity-sized (egogaussian_amd/capacity.py): densification and pruning rewrite the same arrays in place and the
+number of live Gaussians is a device word, so the captured step is NOT re-captured when the model grows (`--plain` keeps the
+reference's behaviour -- new tensors per densification, one re-capture each).  The step voids frames that outgrow its instance
+capacity on the device and re-captures itself with more room (GraphedTrainStep(check_every=...)).
+
+It shows the order of calls a trainer needs; it is not part of the measured path.  `--log` appends a line per report interval
+(iteration, live Gaussians, it/s so far, held-out PSNR), which is how profiles/r2_train_synth_*.log were produced.
 """
 import argparse
 import math
@@ -17,6 +23,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egogaussian_amd import densify, ply                                          # noqa: E402
+from egogaussian_amd.capacity import CapacityGaussians                            # noqa: E402
 from egogaussian_amd.graph import GraphedTrainStep                                # noqa: E402
 from egogaussian_amd.losses import psnr                                           # noqa: E402
 from egogaussian_amd.renderer import render                                       # noqa: E402
@@ -39,6 +46,11 @@ def main(argv=None):
     ap.add_argument("--sh-up-interval", type=int, default=0,
                     help="start at active degree 0 and raise it every this many iterations (the reference: 1000, scene/gaussian_model.py:176-178)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--plain", action="store_true", help="plain model: densification replaces the tensors, the step is re-captured each time")
+    ap.add_argument("--capacity-factor", type=float, default=3.0, help="rows allocated = this x the initial number of Gaussians")
+    ap.add_argument("--report-every", type=int, default=0, help="print (and --log) progress every this many iterations")
+    ap.add_argument("--log", default="")
+    ap.add_argument("--min-opacity", type=float, default=0.005)
     a = ap.parse_args(argv)
     dev = torch.device("cuda", 0)
     H, W = a.height, a.width
@@ -50,18 +62,38 @@ def main(argv=None):
     with torch.no_grad():
         tpc = SynthGaussians(teacher, device=dev, sh_degree=a.sh_degree, requires_grad=False)
         gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
-    pc = SynthGaussians(perturb_student(teacher), device=dev, sh_degree=a.sh_degree)
+    if a.plain:
+        pc = SynthGaussians(perturb_student(teacher), device=dev, sh_degree=a.sh_degree)
+    else:
+        pc = CapacityGaussians(perturb_student(teacher), int(a.gaussians * a.capacity_factor), device=dev, sh_degree=a.sh_degree)
     pc.training_setup(capturable=True)
+    live = lambda: getattr(pc, "n_active", pc._xyz.shape[0])
+    held = [make_camera(k * (N_FRAMES // a.frames) + 0.5 * (N_FRAMES // a.frames), H, W, device=dev) for k in range(0, a.frames, max(1, a.frames // 6))]
+    with torch.no_grad():
+        tpc = SynthGaussians(teacher, device=dev, sh_degree=a.sh_degree, requires_grad=False)
+        held_gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in held]
+        del tpc
     if a.sh_up_interval > 0:
         pc.active_sh_degree = 0
     extent = 10.0
 
     def quality():
+        """mean PSNR over held-out views between the training cameras"""
         with torch.no_grad():
-            return float(sum(psnr(render(c, pc, Pipe, bg)["render"][None], g[None]) for c, g in zip(cams[:4], gts[:4])) / 4)
+            return float(sum(psnr(render(c, pc, Pipe, bg)["render"][None], g[None]) for c, g in zip(held, held_gts)) / len(held))
 
-    print(f"start: {pc._xyz.shape[0]} Gaussians, PSNR {quality():.2f} dB")
-    step = GraphedTrainStep(pc, pc.optimizer, bg, lambda_dssim=0.2, densify_stats=True).capture(cams[0], gts[0], warmup=2)
+    log = open(a.log, "a") if a.log else None
+
+    def report(msg):
+        print(msg, flush=True)
+        if log:
+            log.write(msg + "\n"); log.flush()
+
+    report(f"# {' '.join(sys.argv)}")
+    report(f"start: {live()} Gaussians, held-out PSNR {quality():.2f} dB, {'plain model' if a.plain else f'capacity {pc.capacity} rows'}")
+    step = GraphedTrainStep(pc, pc.optimizer, bg, lambda_dssim=0.2, densify_stats=True, check_every=50)
+    step.capture(cams[0], gts[0], warmup=2, capacity_margin=1.5, capacity_cams=cams[::max(1, a.frames // 6)])
+    manual_recaptures, t_eval, next_report = 0, 0.0, a.report_every
     t0, it = time.perf_counter(), 2
     while it < a.iters:
         k = it % a.frames
@@ -69,26 +101,38 @@ def main(argv=None):
         it += 1
         if a.sh_up_interval > 0 and it % a.sh_up_interval == 0 and pc.active_sh_degree < pc.max_sh_degree:
             pc.active_sh_degree += 1                                 # oneupSHdegree: a launch argument of the captured kernels -> re-capture
-            step.recapture(warmup=1)
+            step.recapture(warmup=1); manual_recaptures += 1
             it += 1
-            print(f"iter {it}: active SH degree {pc.active_sh_degree}")
+            report(f"iter {it}: active SH degree {pc.active_sh_degree}")
         if it <= a.densify_until and it > a.densify_from and it % a.densify_interval == 0:
-            assert step.ok(), "a replayed frame outgrew the captured capacity"      # (reads a device word: synchronises)
+            step.check()                                             # a frame that outgrew the capacity was voided on the device; make room now
             size_threshold = 20 if it > a.opacity_reset_interval else None
-            n0, n1 = densify.densify_and_prune(pc, a.grad_threshold, 0.005, extent, size_threshold)
+            ptr = pc._xyz.data_ptr()
+            n0, n1 = densify.densify_and_prune(pc, a.grad_threshold, a.min_opacity, extent, size_threshold)
             if it % a.opacity_reset_interval == 0:
                 densify.reset_opacity(pc)
-            step.recapture(warmup=1)                                 # new parameter tensors -> new graph (one eager iteration inside)
-            it += 1
-            print(f"iter {it}: densify {n0} -> {n1} Gaussians")
+            if a.plain or pc._xyz.data_ptr() != ptr:                 # new parameter tensors (plain model, or the capacity had to grow) -> new graph
+                step.recapture(warmup=1); manual_recaptures += 1
+                it += 1
+            if not a.report_every:
+                report(f"iter {it}: densify {n0} -> {n1} Gaussians")
+        if a.report_every and it >= next_report:
+            next_report += a.report_every
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            q = quality()
+            t_eval += time.perf_counter() - te
+            report(f"iter {it:6d}  live {live():8d}  {it / (time.perf_counter() - t0 - t_eval):8.1f} it/s so far  held-out PSNR {q:.3f} dB  "
+                   f"re-captures {manual_recaptures + step.recaptures} (overflow {step.recaptures})  instance capacity {step.capacity}")
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert step.ok()
-    print(f"end: {pc._xyz.shape[0]} Gaussians, PSNR {quality():.2f} dB, {a.iters / dt:.0f} it/s including densification and re-captures")
+    dt = time.perf_counter() - t0 - t_eval
+    step.check()
+    report(f"end: {live()} Gaussians, held-out PSNR {quality():.2f} dB, {a.iters / dt:.0f} it/s including densification, opacity resets and "
+           f"{manual_recaptures + step.recaptures} re-capture(s) ({step.recaptures} after an instance-capacity overflow, {step.skipped_frames_seen} overflow events)")
     if a.out:
         ply.save_ply(pc, a.out)
         back = ply.load_ply(SynthGaussians(teacher, device=dev, sh_degree=a.sh_degree), a.out, device=dev)
-        assert torch.equal(back._xyz.detach(), pc._xyz.detach())
+        assert torch.equal(back._xyz.detach(), pc._xyz.detach()[:live()])
         print(f"wrote {a.out} ({os.path.getsize(a.out) / 1e6:.1f} MB) and read it back")
     return pc
 
