@@ -37,7 +37,10 @@ __device__ __forceinline__ bool egs_ellipse_hits(float cx, float cy, float qa, f
     const float lx = (float)qx0 - cx, hx = (float)qx1 - cx, ly = (float)qy0 - cy, hy = (float)qy1 - cy;
     const float dxe = fminf(fmaxf(0.f, lx), hx), dye = fminf(fmaxf(0.f, ly), hy);      // nearest block point to the centre
     if (dxe == 0.f && dye == 0.f) return true;                                           // centre inside the block
-    if (!(qa < 0.f && qc < 0.f)) return true;                                            // not a proper ellipse: keep
+    // Only a proper ellipse (negative-definite form: qa, qc < 0 and qb^2 < 4 qa qc, with a margin) has its block maximum at the
+    // clamped edge optimum computed below.  The reference rejects det == 0 only, so an indefinite conic is reachable (a
+    // cov3D_precomp that is not positive semi-definite, extreme scales): such a splat is never culled.
+    if (!(qa < 0.f && qc < 0.f && qb * qb < 3.99f * qa * qc)) return true;
     const float dys = fminf(fmaxf(-0.5f * qb * dxe * __builtin_amdgcn_rcpf(qc), ly), hy);     // best dy on the line dx = dxe
     const float dxs = fminf(fmaxf(-0.5f * qb * dye * __builtin_amdgcn_rcpf(qa), lx), hx);     // best dx on the line dy = dye
     const float q1 = qa * dxe * dxe + qb * dxe * dys + qc * dys * dys;
@@ -58,7 +61,7 @@ __device__ __forceinline__ bool egs_ellipse_hits_prepped(const float4& e0 /*x, y
     const float lx = (float)qx0 - e0.x, hx = (float)qx1 - e0.x, ly = (float)qy0 - e0.y, hy = (float)qy1 - e0.y;
     const float dxe = fminf(fmaxf(0.f, lx), hx), dye = fminf(fmaxf(0.f, ly), hy);
     if (dxe == 0.f && dye == 0.f) return true;
-    if (!(qa < 0.f && qc < 0.f)) return true;
+    if (!(qa < 0.f && qc < 0.f && qb * qb < 3.99f * qa * qc)) return true;                // not a proper ellipse: keep (see egs_ellipse_hits)
     const float dys = fminf(fmaxf(e1.z * dxe, ly), hy);
     const float dxs = fminf(fmaxf(e1.w * dye, lx), hx);
     const float q1 = qa * dxe * dxe + qb * dxe * dys + qc * dys * dys;
@@ -81,6 +84,14 @@ __device__ __forceinline__ float egs_log2_falloff(float dx, float dy, float qa, 
     return __fmaf_rn(__fmul_rn(qc, dy), dy, __fmul_rn(t, dx));
 }
 
+__device__ __forceinline__ float egs_alpha_noexp(float dx, float dy, float qa, float qb, float qc, float o, float& G) {   // ablation builds only
+    const float p = egs_log2_falloff(dx, dy, qa, qb, qc);
+    G = p * 0.001f + 1.f;
+    float a = fminf(0.99f, __fmul_rn(o, G));
+    a = p > 0.f ? 0.f : a;
+    a = a < (1.0f / 255.0f) ? 0.f : a;
+    return a;
+}
 // alpha = min(0.99, o * G) with the published skip rules folded in: returns 0 when the pair is skipped
 // (power > 0 or alpha < 1/255), so "alpha > 0" means "kept".  G = exp(power) is returned for the backward.
 // Both predicates stay in VCC -> v_cndmask form (no scalar mask round trip).
@@ -91,4 +102,21 @@ __device__ __forceinline__ float egs_alpha(float dx, float dy, float qa, float q
     a = p > 0.f ? 0.f : a;
     a = a < (1.0f / 255.0f) ? 0.f : a;
     return a;
+}
+
+// ---- hand-placed LDS reads of one staged splat record (10 floats at `addr`, an LDS byte offset) and the waits that go with them.
+// The compiler does not see these reads as asynchronous, so every register set passes through a wait (tied to it by "+v") before
+// its first use, and egs_lds_wait_all stands before the registers can be reused for anything else.
+typedef float egs_f4 __attribute__((ext_vector_type(4)));
+typedef float egs_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void egs_lds_fetch(unsigned addr, egs_f4& r0, egs_f4& r1, egs_f2& r2) {
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b64 %2, %3 offset:32"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(addr) : "memory");
+}
+// everything but the newest fetch (three reads) has landed
+__device__ __forceinline__ void egs_lds_wait_older(egs_f4& r0, egs_f4& r1, egs_f2& r2) {
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r0), "+v"(r1), "+v"(r2) : : "memory");
+}
+__device__ __forceinline__ void egs_lds_wait_all(egs_f4& a0, egs_f4& a1, egs_f2& a2, egs_f4& b0, egs_f4& b1, egs_f2& b2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2) : : "memory");
 }

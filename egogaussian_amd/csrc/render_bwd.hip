@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ __attribute__((aligned(16))) float red[4][5 * 64];
     const int tile = (int)tile_order[blockIdx.x];                   // 0xffffffff = padding workgroup
     if (tile < 0) return;
-    const unsigned lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const unsigned lane = threadIdx.x & 63, q = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
     float4* my = lds[q];
     float* myred = red[q];
 #if defined(EGS_MEASURE) && EGS_MEASURE == 4      // instrumentation build (tools/lane_use.py): per-wave timeline of the backward
@@ -180,7 +180,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const float4* red_src = reinterpret_cast<const float4*>(myred + (rv < 10 ? (rv >> 1) * 64 + (rv & 1) * 32 + rg * 8 : 0));
     const int slot = (rg == 0 && rv < 10) ? (int)rv : -1;
 
-    float T = T_final, U = 0.f, last_u = 0.f, last_alpha = 0.f;
+    // S = the blended colour-gradient term of everything BEHIND the splat being processed (U of the header), kept "ready for the
+    // next contributor": after a splat with (a, u) it becomes a u + (1 - a) S -- one state word and one select instead of three
+    // (same values and roundings as U_next = fma(a_last, u_last - U, U); the select keeps a skipped splat's colour, NaN included,
+    // out of the pixel's chain).
+    float T = T_final, S = 0.f;
+#if defined(EGS_ABL) && EGS_ABL == 5
+    float abl_sink = 0.f;
+#endif
 
     const int nb = (int)((wmax + 63) / 64);
     int b = nb - 1;
@@ -230,10 +237,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const float w = a * Tn;
             const float u = HAS_DA ? fmaf(s1.z, g_r, fmaf(s1.w, g_g, fmaf(s2.x, g_b, fmaf(s2.y, g_d, g_a))))
                                    : fmaf(s1.z, g_r, fmaf(s1.w, g_g, s2.x * g_b));
-            const float Un = fmaf(last_alpha, last_u - U, U);
-            float dLda = fmaf(bg_term, rcp, (u - Un) * Tn);
+            float dLda = fmaf(bg_term, rcp, (u - S) * Tn);
             dLda = contrib ? dLda : 0.f;
-            T = Tn; U = contrib ? Un : U; last_u = contrib ? u : last_u; last_alpha = contrib ? a : last_alpha;
+            T = Tn; S = contrib ? fmaf(a, u - S, S) : S;
 
             // Per-splat sums published to the accumulator line are MOMENTS of gd = dL/dalpha * G over the pixels:
             //   v0 = sum gd dx, v1 = sum gd dy, v2 = sum gd dx^2, v3 = sum gd dx dy, v4 = sum gd dy^2,  v5 = sum gd
@@ -246,6 +252,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const float v6 = w * g_r, v7 = w * g_g, v8 = w * g_b, v9 = HAS_DA ? w * g_d : 0.f;
             (void)t; (void)m; (void)nn;
 
+#if defined(EGS_ABL) && EGS_ABL == 5          /* ablation build (timing only): no cross-lane reduction, no atomic -- what the pair arithmetic alone costs */
+            abl_sink += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)) + (v8 + v9);
+            continue;
+#endif
             // 64-lane sums of v0..v9 (see the header): swap-fold, LDS regroup, quad DPP
             myred[0 * 64 + lane] = fold32(v0, v1); myred[1 * 64 + lane] = fold32(v2, v3); myred[2 * 64 + lane] = fold32(v4, v5);
             myred[3 * 64 + lane] = fold32(v6, v7); myred[4 * 64 + lane] = fold32(v8, v9);
@@ -254,10 +264,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             out = dpp_add<0xB1>(out);       // quad_perm [1,0,3,2]
             out = dpp_add<0x4E>(out);       // quad_perm [2,3,0,1]
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)my_id, j);
-            if (slot >= 0) unsafeAtomicAdd(grad_acc + (size_t)gid * EGS_GRAD_STRIDE + slot, out);
+            if (slot >= 0) unsafeAtomicAdd(grad_acc + (gid * (uint32_t)EGS_GRAD_STRIDE + (uint32_t)slot), out);   // (48 P < 2^32 bytes: P < 89 M)
         }
         __builtin_amdgcn_wave_barrier();
     }
+#if defined(EGS_ABL) && EGS_ABL == 5
+    if (abl_sink == 12345.678f) grad_acc[lane] = abl_sink;
+#endif
 #if defined(EGS_MEASURE) && EGS_MEASURE == 4
     if (inside) {                                                    // n_contrib was consumed above: reuse it as the log
         uint32_t hw, xcc;

@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256) void k_render_forward(
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
     const int tile = egs_tile_of_block(blockIdx.x, n_tiles);
     if (tile < 0) return;
-    const unsigned lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const unsigned lane = threadIdx.x & 63, q = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
     float4* my = lds[q];
+    const unsigned my_addr = (unsigned)(uintptr_t)my;             // LDS byte offset of the wave's slice (low half of the generic address)
     const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
     if (qx0 >= W || qy0 >= H) {                                    // quadrant entirely outside the image
         if (lane == 0) { quad_work[tile * 4 + q] = 0; quad_pairs[tile * 4 + q] = 0; quad_pairs[(n_tiles + tile) * 4 + q] = 0; }
@@ -83,29 +84,81 @@ __global__ __launch_bounds__(256) void k_render_forward(
         if (mask == 0ull) continue;
         my[lane * 3 + 0] = c0; my[lane * 3 + 1] = c1; my[lane * 3 + 2] = c2;
         __builtin_amdgcn_wave_barrier();
-        do {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1ull;
-            visits++;
-            const float4 s0 = my[j * 3 + 0], s1 = my[j * 3 + 1];
-            const float2 s2 = *reinterpret_cast<const float2*>(&my[j * 3 + 2]);
-            float G;
-            const float a = egs_alpha(s0.x - pxf, s0.y - pyf, s0.z, s0.w, s1.x, s1.y, G);   // 0 = skipped
-            const float test = fmaf(-a, Tl, Tl);                  // T (1 - alpha); == Tl when skipped, 0 when stopped
-            const bool cont = test >= 0.0001f;                    // false: this splat stops the pixel (or already stopped)
-            const float w = cont ? a * Tl : 0.f;
-            C0 = fmaf(s1.z, w, C0); C1 = fmaf(s1.w, w, C1); C2 = fmaf(s2.x, w, C2);
-            Dacc = fmaf(s2.y, w, Dacc); Aacc += w;
-            Tf = cont ? test : Tf;
-            Tl = cont ? test : 0.f;
-            const bool used = w > 0.f;
-            last = used ? base + (uint32_t)j + 1u : last;
-            pairs += (uint32_t)__popcll(__ballot(used));
-            alive = __ballot(cont) != 0ull;                       // whole quadrant saturated -> leave
+        // The record of the NEXT splat of the work list is fetched from the LDS slice while the current one is blended (two register
+        // sets, the loop unrolled by two so that no copy sits between a fetch and its use): once most waves of a SIMD have left -- all
+        // start together and a quadrant takes 10-70 us -- a lone wave would otherwise sit through the LDS round trip at every splat,
+        // and the launch ends with exactly those waves.  The reads and their waits are written out (egs_lds_fetch / egs_lds_wait_*):
+        // left to the compiler the fetch is either sunk next to its use or followed by a full lgkmcnt(0).  A fetch is issued on every
+        // path (entry 0 again when the list is exhausted), so exactly one -- three reads -- is outstanding at each wait.
 #ifdef EGS_MEASURE
-            meas += EGS_MEASURE != 2 ? 1u : (uint32_t)__popcll(__ballot(w > 0.f));
+#define EGS_FWD_MEAS(W) meas += EGS_MEASURE != 2 ? 1u : (uint32_t)__popcll(__ballot((W) > 0.f));
+#else
+#define EGS_FWD_MEAS(W)
 #endif
-        } while (mask != 0ull && alive);
+#ifndef EGS_ABL
+#define EGS_ABL 0
+#endif
+#if EGS_ABL == 1 || EGS_ABL == 2      /* ablation builds (timing only, tools): drop the measurement counters / the last-contributor tracking */
+#define EGS_ABL_VISITS
+#define EGS_ABL_PAIRS
+#else
+#define EGS_ABL_VISITS visits++;
+#define EGS_ABL_PAIRS pairs += (uint32_t)__popcll(__ballot(used));
+#endif
+#if EGS_ABL == 2
+#define EGS_ABL_LAST(J) last = used ? 1u : last;
+#else
+#define EGS_ABL_LAST(J) last = used ? base + J + 1u : last;
+#endif
+#if EGS_ABL == 3
+#define EGS_ABL_ALPHA egs_alpha_noexp
+#else
+#define EGS_ABL_ALPHA egs_alpha
+#endif
+#define EGS_FWD_BLEND(J, S0, S1, S2) {                                                                                              \
+            EGS_ABL_VISITS                                                                                                          \
+            float G;                                                                                                                \
+            const float a = EGS_ABL_ALPHA(S0.x - pxf, S0.y - pyf, S0.z, S0.w, S1.x, S1.y, G);   /* 0 = skipped */                   \
+            const float test = fmaf(-a, Tl, Tl);                  /* T (1 - alpha); == Tl when skipped, 0 when stopped */            \
+            const bool cont = test >= 0.0001f;                    /* false: this splat stops the pixel (or already stopped) */       \
+            const float w = cont ? a * Tl : 0.f;                                                                                    \
+            C0 = fmaf(S1.z, w, C0); C1 = fmaf(S1.w, w, C1); C2 = fmaf(S2.x, w, C2);                                                  \
+            Dacc = fmaf(S2.y, w, Dacc); Aacc += w;                                                                                  \
+            Tf = cont ? test : Tf;                                                                                                  \
+            Tl = cont ? test : 0.f;                                                                                                 \
+            const bool used = w > 0.f;                                                                                              \
+            EGS_ABL_LAST(J)                                                                                                         \
+            EGS_ABL_PAIRS                                                                                                           \
+            alive = __ballot(cont) != 0ull;                       /* whole quadrant saturated -> leave */                           \
+            EGS_FWD_MEAS(w) }
+        unsigned ja, jb;
+        egs_f4 a0, a1, b0, b1;
+        egs_f2 a2, b2;
+        ja = (unsigned)__builtin_ctzll(mask); mask &= mask - 1ull;
+        egs_lds_fetch(my_addr + ja * 48u, a0, a1, a2);
+        for (;;) {
+            const bool more_b = mask != 0ull;                     // (wave-uniform)
+            jb = more_b ? (unsigned)__builtin_ctzll(mask) : 0u; mask &= mask - 1ull;
+#if EGS_ABL == 4
+            b0 = a0; b1 = a1; b2 = a2;
+#else
+            egs_lds_fetch(my_addr + jb * 48u, b0, b1, b2);
+            egs_lds_wait_older(a0, a1, a2);
+#endif
+            EGS_FWD_BLEND(ja, a0, a1, a2)
+            if (!more_b || !alive) break;
+            const bool more_a = mask != 0ull;
+            ja = more_a ? (unsigned)__builtin_ctzll(mask) : 0u; mask &= mask - 1ull;
+#if EGS_ABL != 4
+            egs_lds_fetch(my_addr + ja * 48u, a0, a1, a2);
+            egs_lds_wait_older(b0, b1, b2);
+#endif
+            EGS_FWD_BLEND(jb, b0, b1, b2)
+            if (!more_a || !alive) break;
+        }
+        egs_lds_wait_all(a0, a1, a2, b0, b1, b2);                  // nothing may still be landing in registers the code below reuses
+#undef EGS_FWD_BLEND
+#undef EGS_FWD_MEAS
         __builtin_amdgcn_wave_barrier();
     }
     const float T = Tf;

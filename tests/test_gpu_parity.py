@@ -637,3 +637,29 @@ def test_split_spherical_harmonics_match_the_concatenated_call(active, M):
     assert outlier_fraction(full, gb["dL_dsh"].reshape(full.shape), TOL) <= 2e-4
     assert outlier_fraction(ref[2].cpu().numpy(), gb["dL_dmeans3D"], TOL) <= 2e-4
     assert outlier_fraction(ref[0].cpu().numpy(), st["color"], TOL) <= 1e-4
+
+
+def test_indefinite_covariances_are_never_culled():
+    """A user-supplied cov3D_precomp that is not positive semi-definite gives an indefinite 2D conic (the reference only rejects
+    det == 0): its falloff has no maximum at the clamped edge optimum the ellipse-vs-block test computes, so such a splat must be
+    kept everywhere.  Tile culling on and off must still agree bit for bit, and both with the oracle."""
+    dev = _dev()
+    N, H, W = 3000, 96, 128
+    d = make_inputs(N, H, W, 17, 0, "col_cov", scale_mul=3.0)
+    cov = d["cov3D_precomp"]
+    cov[3::11, 1] = 4.0 * cov[3::11, 0]                # |xy| > sqrt(xx yy): det < 0, trace > 0 (the radius stays a number)
+    cov[::7, 4] = -3.0 * cov[::7, 3]                   # same in the yz block
+    o, st = oracle_forward(d)
+    res = {}
+    for cull in (False, True):
+        with tile_culling(cull):
+            g, out = hip_forward(d, dev)
+            hb = hip_backward(g, out, seeded_grads(H, W, 2), dev)
+        res[cull] = ([t.clone() for t in out[1:5]], [t.clone() for t in hb])
+    assert out[0] == st["R"] and np.array_equal(res[True][0][3].cpu().numpy(), st["radii"])
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b), "tile culling changed an output for an indefinite conic"
+    finite = np.isfinite(st["color"]).all(0)
+    assert finite.mean() > 0.5
+    hipc = res[True][0][0].cpu().numpy()
+    assert outlier_fraction(hipc[:, finite], st["color"][:, finite], TOL) <= 1e-3
