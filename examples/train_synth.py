@@ -51,6 +51,9 @@ def main(argv=None):
     ap.add_argument("--report-every", type=int, default=0, help="print (and --log) progress every this many iterations")
     ap.add_argument("--log", default="")
     ap.add_argument("--min-opacity", type=float, default=0.005)
+    ap.add_argument("--knn-init", action="store_true",
+                    help="initialise the student as GaussianModel.create_from_pcd does (/root/reference/scene/gaussian_model.py:301-318): isotropic scales "
+                         "from simple_knn.distCUDA2 of the (perturbed) teacher positions, identity rotations, opacity 0.1")
     a = ap.parse_args(argv)
     dev = torch.device("cuda", 0)
     H, W = a.height, a.width
@@ -62,10 +65,17 @@ def main(argv=None):
     with torch.no_grad():
         tpc = SynthGaussians(teacher, device=dev, sh_degree=a.sh_degree, requires_grad=False)
         gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
+    student = perturb_student(teacher)
+    if a.knn_init:
+        from simple_knn._C import distCUDA2                      # the drop-in module name (egs_knn3_mean_dist2, csrc/knn.hip)
+        dist2 = torch.clamp_min(distCUDA2(torch.from_numpy(student["xyz"]).float().to(dev)), 0.0000001)
+        student["log_scale"] = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3).cpu().numpy()
+        student["quat"][:] = 0.0; student["quat"][:, 0] = 1.0
+        student["opacity_logit"][:] = math.log(0.1 / 0.9)
     if a.plain:
-        pc = SynthGaussians(perturb_student(teacher), device=dev, sh_degree=a.sh_degree)
+        pc = SynthGaussians(student, device=dev, sh_degree=a.sh_degree)
     else:
-        pc = CapacityGaussians(perturb_student(teacher), int(a.gaussians * a.capacity_factor), device=dev, sh_degree=a.sh_degree)
+        pc = CapacityGaussians(student, int(a.gaussians * a.capacity_factor), device=dev, sh_degree=a.sh_degree)
     pc.training_setup(capturable=True)
     live = lambda: getattr(pc, "n_active", pc._xyz.shape[0])
     held = [make_camera(k * (N_FRAMES // a.frames) + 0.5 * (N_FRAMES // a.frames), H, W, device=dev) for k in range(0, a.frames, max(1, a.frames // 6))]
