@@ -68,6 +68,8 @@ SIGNATURES = {
     "egs_gather_i32": (C.c_int, [i64, vp, vp, i32, i32, vp, vp, vp]),
     "egs_split_children": (C.c_int, [i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_knn3_mean_dist2": (C.c_int, [i32, vp, vp, vp]),
+    "egs_knn3_grid_scratch_bytes": (C.c_size_t, [i32]),
+    "egs_knn3_grid": (C.c_int, [i32, vp, vp, vp, vp]),
     "egs_debug_force_ballot_rank": (C.c_int, [i32]),
     "egs_debug_set_tile_culling": (C.c_int, [i32]),
     "egs_profile_begin": (C.c_int, [i32]),

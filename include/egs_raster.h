@@ -336,6 +336,12 @@ int egs_split_children(int64_t rows, const int32_t* src_index, const uint8_t* ki
  *      Replaces simple_knn._C.distCUDA2 (un-vendored submodule, /root/reference/.gitmodules:4-6), imported at
  *      /root/reference/scene/gaussian_model.py:21 and called at :301.  Exact (all pairs). */
 int egs_knn3_mean_dist2(int N, const float* points /*[N,3]*/, float* mean_dist2 /*[N] out*/, void* stream);
+/* The same statistic, bit for bit, through a uniform-grid search (counting sort of the points by cell, then rings of cells around
+ * every query until the third neighbour is provably inside): O(N) for clouds of roughly even density instead of O(N^2) -- the
+ * all-pairs call takes 0.4 s at 1 M points.  Points with a NaN / inf coordinate are nobody's neighbour and get +inf, in both
+ * calls.  `scratch`: egs_knn3_grid_scratch_bytes(N) bytes of device memory. */
+size_t egs_knn3_grid_scratch_bytes(int N);
+int egs_knn3_grid(int N, const float* points /*[N,3]*/, float* mean_dist2 /*[N] out*/, void* scratch, void* stream);
 
 /* Test hook: the per-tile sort ranks keys with an LDS atomic whose lane-order behaviour is verified on the device once per
  * process; on != 0 forces the ballot-based fallback so that tests can cover it.  Returns the previous setting. */

@@ -184,6 +184,43 @@ def test_knn_mean_dist2_matches_kdtree(N):
     assert got[0] < want.mean() and np.isfinite(got).all()
 
 
+@pytest.mark.parametrize("shape", ["normal", "uniform", "plane", "clusters", "line+outlier"])
+def test_knn_grid_search_is_bit_identical_to_all_pairs(shape):
+    """The uniform-grid search (what distCUDA2 uses from 32k points up) against the all-pairs kernel: same bits, for even and very
+    uneven densities, degenerate extents, duplicates and non-finite points; and against scipy's k-d tree at 300k points."""
+    import time
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(7)
+    N = 60000
+    if shape == "normal":
+        pts = rng.normal(size=(N, 3))
+    elif shape == "uniform":
+        pts = rng.uniform(-3, 5, size=(N, 3))
+    elif shape == "plane":
+        pts = rng.uniform(-1, 1, size=(N, 3)); pts[:, 2] = 0.25                     # zero extent along z
+    elif shape == "clusters":
+        pts = rng.normal(size=(N, 3)) * 0.01 + rng.integers(0, 5, size=(N, 1)) * 10.0  # five dense blobs far apart
+    else:
+        pts = np.zeros((N, 3)); pts[:, 0] = np.linspace(0, 1, N); pts[-1] = (1e4, 1e4, 1e4)
+    pts = pts.astype(np.float32)
+    pts[100] = pts[200]                                                             # an exact duplicate
+    pts[300] = (np.nan, 0, 0); pts[301] = (np.inf, 1, 2)                            # nobody's neighbours; their own answer is inf
+    t = torch.tensor(pts, device=DEV)
+    a, b = distCUDA2(t, method="pairs"), distCUDA2(t, method="grid")
+    assert torch.equal(a, b), f"{int((a != b).sum())} of {N} differ"
+    assert torch.isinf(b[300]) and torch.isinf(b[301]) and torch.isfinite(b[:300]).all()
+    if shape == "uniform":
+        from scipy.spatial import cKDTree
+        big = rng.uniform(-3, 5, size=(300000, 3)).astype(np.float32)
+        tb = torch.tensor(big, device=DEV)
+        distCUDA2(tb); torch.cuda.synchronize()
+        t0 = time.perf_counter(); got = distCUDA2(tb); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        d, _ = cKDTree(big.astype(np.float64)).query(big.astype(np.float64), k=4, workers=-1)
+        want = (d[:, 1:] ** 2).mean(1)
+        assert np.abs(got.cpu().numpy() - want).max() <= 1e-5 * want.max() + 1e-7
+        print(f"\n  grid search, 300k points: {dt * 1e3:.2f} ms")
+
+
 def test_knn_fewer_than_four_points():
     from simple_knn._C import distCUDA2
     out = distCUDA2(torch.tensor([[0.0, 0, 0], [1.0, 0, 0]], device=DEV))
