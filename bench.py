@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every step from Python instead of replaying a captured hipGraph")
     ap.add_argument("--torch-host-ops", action="store_true",
                     help="build cov3D and the loss with PyTorch ops (as the reference does) instead of the fused HIP kernels")
+    ap.add_argument("--steps-per-replay", type=int, default=4,
+                    help="training steps captured into one hipGraph (each on its own frame); lowered to a divisor of --steps when needed; 1 = one launch per step")
     ap.add_argument("--verify-ranks", action="store_true", help="add per-rank frame lists, start-of-run parameter checksums and loss sums to the JSON line")
     args = ap.parse_args()
 
@@ -222,22 +224,31 @@ def main():
 
         psnr_start = eval_psnr()
         step, graphed = eager_step, None
+        spr = 1
         if use_graph:                                               # the whole iteration as one hipGraph (egogaussian_amd/graph.py)
+            spr = next(k for k in range(max(1, min(args.steps_per_replay, args.steps)), 0, -1) if args.steps % k == 0)
             try:
-                graphed = GraphedTrainStep(pc, opt, bg, 0.2, dynamic=dynamic, gated=dynamic)
+                graphed = GraphedTrainStep(pc, opt, bg, 0.2, dynamic=dynamic, gated=dynamic, steps_per_replay=spr)
                 graphed.capture(cams[0], gts[0], warmup=2, accum_R=rot[0] if dynamic else None, gate=gates[0] if dynamic else None,
                                 capacity_cams=cams[::max(1, n_used // 6)])
             except Exception as exc:                                # keep measuring, eagerly, rather than lose the run
                 print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); stepping eagerly", file=sys.stderr)
                 graphed, use_graph = None, False
             if graphed is not None:
-                # resident: image + camera block (+ object rotation + gate), one copy per replay
-                frames = [pack_frame(c, g_, rot[i] if dynamic else None, gates[i] if dynamic else None) for i, (c, g_) in enumerate(zip(cams, gts))]
+                # resident: image + camera block (+ object rotation + gate) of every frame in ONE tensor, frame order = step order (the
+                # first spr - 1 frames repeated at the end), so that the spr frames of a replay are one contiguous copy
+                fl = [pack_frame(c, g_, rot[i] if dynamic else None, gates[i] if dynamic else None) for i, (c, g_) in enumerate(zip(cams, gts))]
+                frames = torch.stack(fl + fl[:spr - 1])
+                del fl
 
-                def step(i):                                        # noqa: F811
-                    graphed(frames[i % n_used])                      # (the captured step adds its loss to graphed.loss_sum itself)
-                    r_sum[1] += 1
-        for i in range(args.warmup):
+                def step(i):                                        # noqa: F811   (i = index of the first of spr consecutive steps)
+                    k = i % n_used
+                    graphed(frames[k:k + spr])                       # (the captured steps add their losses to graphed.loss_sum themselves)
+                    r_sum[1] += spr
+            else:
+                spr = 1
+        n_warm = -(-args.warmup // spr) * spr                       # whole replays: at least --warmup untimed steps
+        for i in range(0, n_warm, spr):
             step(i)
         loss_acc.zero_(); r_sum[:] = [0, 0]
         if graphed is not None:
@@ -247,8 +258,8 @@ def main():
         egs_lib.profile_begin(max_records=min(200000, 16 * (args.steps + 8)))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
+        for i in range(0, args.steps, spr):                         # EXACTLY args.steps training steps (spr per launch)
+            step(n_warm + i)
         torch.cuda.synchronize()
         egs_dist.barrier()
         torch.cuda.synchronize()
@@ -287,7 +298,7 @@ def main():
         n_s = len(range(0, n_used, max(1, n_used // 4)))
         return dict(elapsed=elapsed, stages=stages, stage_timing=stage_timing, loss=loss_acc.item(), psnr_end=psnr_end, psnr_start=psnr_start,
                     R_mean=float(r_sum[0]) / max(r_sum[1], 1), kept_ratio=kept / max(rect, 1), pairs=pairs / n_s, visits=visits / n_s,
-                    use_graph=use_graph, checksum=checksum, overflow=overflow, pc=pc, cams=cams)
+                    use_graph=use_graph, checksum=checksum, overflow=overflow, pc=pc, cams=cams, spr=spr)
 
     def reduce_leg(r):
         """Scalars only (RCCL over xGMI): max-over-ranks time, sums of loss / PSNR / instance counts."""
@@ -407,7 +418,8 @@ def main():
                    "gaussians": N, "image": [H, W], "sh_degree": D, "instances_R": int(R_mean), "instances_after_tile_culling": int(R_kept),
                    "sort_passes_max": passes,
                    "parallelism": f"frames sharded over {world} GPU(s), scalar all-reduce only",
-                   "launch": "one hipGraph replay per step" if head["use_graph"] else "eager (one launch per kernel)"},
+                   "launch": (f"one hipGraph replay per {head['spr']} steps ({head['spr']} complete iterations, each on its own frame, captured back to back)"
+                              if head["spr"] > 1 else "one hipGraph replay per step") if head["use_graph"] else "eager (one launch per kernel)"},
         "psnr_db": round(red["psnr"], 3), "psnr_db_before": round(red["psnr_before"], 3),
         "psnr_views": "8 held-out views at half-frame phases across the orbit (never trained on)", "mean_loss": round(red["mean_loss"], 6),
         "rasterizer_ms_per_step": round(op_ms, 4),
@@ -420,7 +432,8 @@ def main():
             "steps": args.steps, "n_gpus": world, "psnr_db": round(dr["psnr"], 3), "psnr_db_before": round(dr["psnr_before"], 3),
             "mean_loss": round(dr["mean_loss"], 6), "instances_R": int(dr["R_mean"]),
             "stages_ms": {k: round(ms / n, 4) for k, (ms, n) in dl["stages"].items() if n},
-            "launch": "one hipGraph replay per step" if dl["use_graph"] else "eager", "step": step_text["dynamic"],
+            "launch": (f"one hipGraph replay per {dl['spr']} steps" if dl["spr"] > 1 else "one hipGraph replay per step") if dl["use_graph"] else "eager",
+            "step": step_text["dynamic"],
             "reference": "/root/reference/trainers/fine_all.py:74-101 (BASELINE.json config 4)"}
     if ranks_info is not None:
         out["ranks"] = ranks_info

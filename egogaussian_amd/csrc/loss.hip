@@ -21,7 +21,11 @@
 // waiting: 3 rounds of latency-bound workgroups, 30 us + 25 us at 3x540x960; this one is bound by VALU/LDS issue.
 #define HALO 5
 #define SW 54                 // useful columns per wave (64 lanes - 2 * HALO)
+#ifdef EGS_LOSS_SR
+#define SR EGS_LOSS_SR        // (tuning builds)
+#else
 #define SR 15                 // output rows per wave (3 x 540 x 960: 1944 waves, just under 2 per SIMD)
+#endif
 #define WPB 2                 // waves per workgroup (independent)
 
 namespace {

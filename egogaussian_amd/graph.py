@@ -93,7 +93,7 @@ class _StaticCamera:
 
 class GraphedTrainStep:
     def __init__(self, pc, optimizer, bg, lambda_dssim=0.2, pipe=Pipe, render_kwargs=None, densify_stats=False, dynamic=False,
-                 which_object=1, gated=False, check_every=0):
+                 which_object=1, gated=False, check_every=0, steps_per_replay=1):
         """densify_stats: the captured step also keeps the per-iteration densification statistics (trainers/train_static.py:125-127:
                        max_radii2D, xyz_gradient_accum, denom) -- updated by the rasterizer's backward itself, no launch of their own.
         dynamic:       the `fine_all` call shape (/root/reference/trainers/fine_all.py:88-93): render(..., rot_cov=True,
@@ -101,7 +101,10 @@ class GraphedTrainStep:
         gated:         the image gradient is multiplied by a per-pixel gate refreshed per call -- the reference's
                        `render_image.register_hook(lambda grad: grad * (1 - hand_mask))` (train_static.py:91, fine_all.py:94).
         check_every:   K > 0: every K calls read the overflow maximum (one host synchronisation) and re-capture with a larger
-                       instance capacity if a frame was clipped (its update was skipped, see the module docstring)."""
+                       instance capacity if a frame was clipped (its update was skipped, see the module docstring).
+        steps_per_replay: S > 1 captures S complete iterations back to back, each on its own static frame; one launch then runs
+                       S training steps on S frames (`__call__` takes the S packed frames as one [S, frame] tensor or a list).  A
+                       graph launch leaves the GPU idle for ~9 us before its first node; this divides that by S."""
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True)")
         self.pc, self.opt, self.bg, self.lam, self.pipe = pc, optimizer, bg, lambda_dssim, pipe
@@ -109,6 +112,7 @@ class GraphedTrainStep:
         self.dynamic, self.which_object, self.gated = bool(dynamic), which_object, bool(gated)
         self.render_kwargs = dict(render_kwargs or {})
         self.check_every = int(check_every)
+        self.steps_per_replay = max(1, int(steps_per_replay))
         self.graph = None
         self.guard = None
         self.loss_sum = None
@@ -116,13 +120,15 @@ class GraphedTrainStep:
         self.skipped_frames_seen = 0      # overflow events noticed by check()
         self._calls = 0
 
-    def _body(self):
+    def _body(self, k=0):
+        """One training iteration on static frame k."""
+        f = self._slots[k]
         kw = dict(self.render_kwargs)
         if self.dynamic:
-            kw.update(rot_cov=True, accum_R=self.accum_R, which_object=self.which_object, during_training=False)
-        out = render(self.cam, self.pc, self.pipe, self.bg, fused_densify_stats=self.densify_stats, guard=self.guard, **kw)
+            kw.update(rot_cov=True, accum_R=f["accum_R"], which_object=self.which_object, during_training=False)
+        out = render(f["cam"], self.pc, self.pipe, self.bg, fused_densify_stats=self.densify_stats, guard=self.guard, **kw)
         # the loss value and the running sum are produced by the loss BACKWARD kernel (nothing reads them before): two launches less
-        loss = l1_ssim_loss(out["render"], self.gt, self.lam, grad_gate=self.gate if self.gated else None, running_sum=self.loss_sum,
+        loss = l1_ssim_loss(out["render"], f["gt"], self.lam, grad_gate=f["gate"] if self.gated else None, running_sum=self.loss_sum,
                             defer_value=True)
         loss.backward(gradient=self._one)                            # a resident 1.0: no fill kernel per iteration
         self.opt.step()
@@ -142,17 +148,24 @@ class GraphedTrainStep:
                 self.gt.copy_(gt)
         else:
             off, size = self._frame_layout(gt)
-            self._frame = torch.empty(size, device=dev, dtype=torch.float32)      # image, camera[, accum_R][, gate]: one copy target
-            self.gt = self._frame[off["gt"][0]:off["gt"][1]].view(gt.shape)
-            self.gt.copy_(gt)
-            self.cam = _StaticCamera(cam, storage=self._frame[off["cam"][0]:off["cam"][1]])
-            self.accum_R = self.gate = None
-            if self.dynamic:
-                self.accum_R = self._frame[off["accum_R"][0]:off["accum_R"][1]].view(3, 3)
-                self.accum_R.copy_(torch.eye(3, device=dev) if accum_R is None else accum_R)
-            if self.gated:
-                self.gate = self._frame[off["gate"][0]:off["gate"][1]].view(gt.shape[-2], gt.shape[-1])
-                self.gate.copy_(torch.ones(gt.shape[-2:], device=dev) if gate is None else gate)
+            # per captured iteration: image, camera[, accum_R][, gate] -- ONE copy target for all of them
+            self._frames = torch.empty((self.steps_per_replay, size), device=dev, dtype=torch.float32)
+            self._slots = []
+            for k in range(self.steps_per_replay):
+                fr = self._frames[k]
+                slot = {"gt": fr[off["gt"][0]:off["gt"][1]].view(gt.shape), "accum_R": None, "gate": None}
+                slot["gt"].copy_(gt)
+                slot["cam"] = _StaticCamera(cam, storage=fr[off["cam"][0]:off["cam"][1]])
+                if self.dynamic:
+                    slot["accum_R"] = fr[off["accum_R"][0]:off["accum_R"][1]].view(3, 3)
+                    slot["accum_R"].copy_(torch.eye(3, device=dev) if accum_R is None else accum_R)
+                if self.gated:
+                    slot["gate"] = fr[off["gate"][0]:off["gate"][1]].view(gt.shape[-2], gt.shape[-1])
+                    slot["gate"].copy_(torch.ones(gt.shape[-2:], device=dev) if gate is None else gate)
+                self._slots.append(slot)
+            self._frame = self._frames[0]
+            first = self._slots[0]                                   # (the single-iteration names)
+            self.gt, self.cam, self.accum_R, self.gate = first["gt"], first["cam"], first["accum_R"], first["gate"]
         self._one = torch.ones((), device=dev)
         if getattr(self, "loss_sum", None) is None:
             self.loss_sum = torch.zeros((), device=dev)                  # sum of the losses of every iteration run through this object
@@ -190,7 +203,12 @@ class GraphedTrainStep:
             # thread_local: calls other threads make meanwhile (e.g. the RCCL watchdog polling its events) must not abort the capture
             self.graph.capture_begin(capture_error_mode="thread_local")
             try:
-                self.loss, out = self._body()
+                self.losses = []
+                for k in range(self.steps_per_replay):
+                    if k:
+                        self.opt.zero_grad(set_to_none=True)         # (the next backward writes fresh gradients instead of accumulating)
+                    self.loss, out = self._body(k)
+                    self.losses.append(self.loss)
                 self.image = out["render"].detach()
                 self.radii = out["radii"]
                 self.visibility_filter = out["visibility_filter"]      # follows every replay (a view of the rasterizer's saved state)
@@ -211,11 +229,18 @@ class GraphedTrainStep:
         return self.capture(cam, gt, warmup=warmup, capacity_margin=capacity_margin, capacity_cams=capacity_cams)
 
     def __call__(self, cam, gt=None, accum_R=None, gate=None):
-        """One training iteration: copy inputs in, replay.  Returns the (device, static) loss tensor.
-        Either (camera, ground-truth image[, accum_R][, gate]) or one packed frame from pack_frame() (a single copy)."""
+        """One training iteration (steps_per_replay of them): copy inputs in, replay.  Returns the (device, static) loss tensor of
+        the last iteration (`self.losses` has all).  Either (camera, ground-truth image[, accum_R][, gate]) or packed frames from
+        pack_frame(): one for a single-iteration step, a [S, frame] tensor (one copy) or a list of S for steps_per_replay = S."""
         if gt is None:
-            self._frame.copy_(cam, non_blocking=True)
+            if isinstance(cam, (list, tuple)):
+                for k, fr in enumerate(cam):
+                    self._frames[k].copy_(fr, non_blocking=True)
+            else:
+                self._frames.copy_(cam.view(self._frames.shape), non_blocking=True)
         else:
+            if self.steps_per_replay != 1:
+                raise ValueError("steps_per_replay > 1 takes packed frames")
             self.cam.load(cam)
             self.gt.copy_(gt, non_blocking=True)
             if self.dynamic and accum_R is not None:

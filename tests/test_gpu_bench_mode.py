@@ -169,7 +169,7 @@ def test_bench_two_ranks_plain_launch():
     assert r0["graph"] and r1["graph"] and r0["overflow"]["ok"] and r1["overflow"]["ok"]       # real graph-replayed steps on both ranks
     assert r0["loss_sum"] > 0 and r1["loss_sum"] > 0 and r0["loss_sum"] != r1["loss_sum"]      # different frames -> different losses
     assert abs(j["mean_loss"] - (r0["loss_sum"] + r1["loss_sum"]) / 12) < 1e-6                 # the reduced scalar
-    assert j["config"]["launch"] == "one hipGraph replay per step"
+    assert j["config"]["launch"].startswith("one hipGraph replay per")
     fa = j["fine_all_shape"]
     assert fa["n_gpus"] == 2 and fa["value"] > 0 and fa["launch"].startswith("one hipGraph") and math.isfinite(fa["psnr_db"])
     assert j["roofline"]["pairs_Q"] > 0 and j["roofline"]["visits"] > 0

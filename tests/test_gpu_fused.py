@@ -282,6 +282,49 @@ def test_graphed_train_step_matches_eager():
             assert float(diff.max()) < 0.02, "graph-replayed parameters drifted from the eager ones"
 
 
+def test_several_steps_per_replay_match_single_step_replays():
+    """GraphedTrainStep(steps_per_replay=3): one launch = three complete iterations on three frames; six such steps must leave the
+    parameters where six single-step replays leave them (up to the order of the float atomics), with every loss recorded."""
+    import math
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.optim import FusedAdam
+    from egogaussian_amd.graph import GraphedTrainStep, pack_frame
+    N, H, W = 20000, 96, 160
+    teacher = make_scene(N, H, W, 0); teacher["log_scale"] += math.log(2.0)
+    student = perturb_student(teacher)
+    cams = [make_camera(k, H, W, device=DEV) for k in (0, 30, 60, 90, 120, 150)]
+    bg = torch.zeros(3, device=DEV)
+    with torch.no_grad():
+        tpc = SynthGaussians(teacher, device=DEV, requires_grad=False)
+        gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
+    frames = [pack_frame(c, g) for c, g in zip(cams, gts)]
+    groups = lambda pc: [{"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3}, {"params": [pc._opacity], "lr": 0.05},
+                         {"params": [pc._scaling], "lr": 5e-3}, {"params": [pc._rotation], "lr": 1e-3}]
+    res = {}
+    for spr in (1, 3):
+        pc = SynthGaussians(student, device=DEV)
+        opt = FusedAdam(groups(pc), lr=0.0, eps=1e-15, capturable=True)
+        step = GraphedTrainStep(pc, opt, bg, steps_per_replay=spr).capture(cams[0], gts[0], warmup=2)
+        losses = []
+        if spr == 1:
+            for f in frames:
+                losses.append(float(step(f)))
+        else:
+            for lo in (0, 3):
+                step(torch.stack(frames[lo:lo + 3]) if lo == 0 else frames[lo:lo + 3])      # one stacked copy / a list of frames
+                losses += [float(l) for l in step.losses]
+        torch.cuda.synchronize()
+        assert step.ok() and len(losses) == 6
+        res[spr] = (losses, [p.detach().clone() for p in pc.parameters()], float(step.loss_sum), float(opt.state[pc._xyz]["step"]))
+    assert res[1][3] == res[3][3] == 8.0                                  # 2 eager + 6 replayed Adam steps on both sides
+    assert np.allclose(res[1][0], res[3][0], rtol=2e-4) and abs(res[1][2] - res[3][2]) < 1e-4 * abs(res[1][2])
+    for a, b in zip(res[1][1], res[3][1]):
+        if a.numel():
+            diff = (a - b).abs()
+            assert float((diff > 2e-5 * float(a.abs().max()) + 1e-6).float().mean()) < 2e-3 and float(diff.max()) < 0.02
+
+
 def test_l1_ssim_deferred_value_and_running_sum():
     """defer_value=True moves the assembly of the scalar into the backward kernel (one launch less in a replayed training step):
     same value, same gradient; running_sum receives the value exactly once per loss, in either mode."""
