@@ -57,6 +57,12 @@ if os.environ.get("TIMELINE"):
     np.add.at(busy, inv, dur); np.maximum.at(endt, inv, t1); np.add.at(cnt, inv, 1)
     print("SIMDs", len(ids), "waves/SIMD min/mean/max", cnt.min(), cnt.mean(), cnt.max())
     print("SIMD end time min/mean/max", endt.min(), endt.mean(), endt.max(), " sum of wave durations per SIMD min/mean/max", busy.min(), busy.mean(), busy.max())
+    vis_simd = np.zeros(len(ids)); np.add.at(vis_simd, inv, a[:, 6])
+    cu = simd // 4
+    cids, cinv = np.unique(cu, return_inverse=True)
+    vis_cu = np.zeros(len(cids)); np.add.at(vis_cu, cinv, a[:, 6])
+    print("blended splats per SIMD min/mean/max", vis_simd.min(), vis_simd.mean(), vis_simd.max(), " per CU min/mean/max", vis_cu.min(), vis_cu.mean(), vis_cu.max(),
+          " corr(SIMD visits, SIMD end)", np.corrcoef(vis_simd, endt)[0, 1])
     print("corr(list length n, wave duration)", np.corrcoef(a[:, 3], dur)[0, 1])
     visits, depth = a[:, 6].astype(float), a[:, 7].astype(float)
     batches = np.ceil(np.minimum(depth + 64, a[:, 3]) / 64.0)
