@@ -454,6 +454,19 @@ def main():
                                           "steps 29.5 M parameters instead of 7 M"}
         except Exception as exc:                                   # the headline line must still come out
             out["sh_degree_3"] = {"error": f"{type(exc).__name__}: {exc}"}
+        # The step exactly as SURVEY.md section 8d words it -- get_covariance and the loss as PyTorch ops around the rasterizer, torch's
+        # own fused Adam, every kernel launched from Python (what a reference trainer gets by swapping the two import lines and nothing
+        # else): same workload, in a child process.
+        try:
+            leg = subprocess.run([sys.executable, os.path.abspath(__file__), "--torch-host-ops", "--steps", str(min(args.steps, 60)), "--warmup", "10",
+                                  "--no-cpu-baseline", "--gaussians", str(N), "--height", str(H), "--width", str(W)],
+                                 capture_output=True, text=True, timeout=600)
+            j = json.loads(leg.stdout.strip().splitlines()[-1])
+            out["reference_shaped_step"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                                            "rasterizer_ms_per_step": j["rasterizer_ms_per_step"], "psnr_db": j["psnr_db"], "step": j["config"]["workload"].split("step = ")[-1],
+                                            "launch": j["config"]["launch"]}
+        except Exception as exc:
+            out["reference_shaped_step"] = {"error": f"{type(exc).__name__}: {exc}"}
     print(json.dumps(out))
     egs_dist.shutdown()
 
