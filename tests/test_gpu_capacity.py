@@ -202,3 +202,36 @@ def test_overflowed_frame_leaves_parameters_moments_and_statistics_bit_unchanged
     torch.cuda.synchronize()
     assert not step.last_frame_overflowed() and step.ok()
     assert not torch.equal(pc._xyz.detach(), before[0])                # and training goes on
+
+
+def test_capacity_grows_when_densification_outruns_it():
+    """A model whose capacity is too small for the densified count grows (new arrays, optimizer state carried over); the plan is then
+    applied in place, and a captured step re-captured on the new tensors goes on training."""
+    from egogaussian_amd import densify
+    from egogaussian_amd.capacity import CapacityGaussians
+    from egogaussian_amd.graph import GraphedTrainStep
+    from egogaussian_amd.scene_synth import make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    H, W, n = 96, 160, 6000
+    teacher = _scene(n, H, W)
+    cam, bg = make_camera(0, H, W, device=DEV), torch.zeros(3, device=DEV)
+    with torch.no_grad():
+        gt = render(cam, SynthGaussians(teacher, device=DEV, requires_grad=False), Pipe, bg)["render"].clone()
+    pc = CapacityGaussians(perturb_student(teacher), n + 500, device=DEV)          # room for 500 more only
+    pc.training_setup(capturable=True)
+    step = GraphedTrainStep(pc, pc.optimizer, bg, 0.2, densify_stats=True).capture(cam, gt, warmup=2, capacity_margin=3.0)
+    for _ in range(20):
+        step(cam, gt)
+    torch.cuda.synchronize()
+    ptr, m_before = pc._xyz.data_ptr(), pc.optimizer.state[pc._xyz]["exp_avg"][:n].clone()
+    n0, n1 = densify.densify_and_prune(pc, 5e-5, 0.005, 10.0, None)
+    assert n1 > n + 500 and pc.capacity >= n1 and pc.n_active == n1 and int(pc.active_count.item()) == n1
+    assert pc._xyz.data_ptr() != ptr and pc._xyz.shape[0] == pc.capacity              # reallocated
+    assert pc.optimizer.param_groups[0]["params"][0] is pc._xyz and "exp_avg" in pc.optimizer.state[pc._xyz]
+    assert pc.optimizer.active_rows[1] == pc.capacity
+    assert pc.optimizer.state[pc._xyz]["exp_avg"].shape[0] == pc.capacity and float(m_before.abs().sum()) > 0
+    step.recapture(warmup=1)
+    l0 = float(step(cam, gt))
+    for _ in range(15):
+        step(cam, gt)
+    assert float(step(cam, gt)) < l0 and step.ok()
