@@ -247,15 +247,20 @@ def main():
                     r_sum[1] += spr
             else:
                 spr = 1
-        n_warm = -(-args.warmup // spr) * spr                       # whole replays: at least --warmup untimed steps
-        for i in range(0, n_warm, spr):
+        # EXACTLY --warmup untimed steps: whole replays, the remainder (warmup % spr) launched eagerly first
+        n_warm = args.warmup
+        for i in range(n_warm % spr if graphed is not None else 0):
+            eager_step(i)
+        for i in range(n_warm % spr if graphed is not None else 0, n_warm, spr):
             step(i)
         loss_acc.zero_(); r_sum[:] = [0, 0]
         if graphed is not None:
             graphed.loss_sum.zero_()
+        # (the event pool of the stage timer is set up BEFORE the last synchronisation: nothing but the barrier sits between the
+        # warm-up and the timed region, so the GPU does not idle into a lower power state right before it is timed)
+        egs_lib.profile_begin(max_records=min(200000, 16 * (args.steps + 8)))
         torch.cuda.synchronize()
         egs_dist.barrier()
-        egs_lib.profile_begin(max_records=min(200000, 16 * (args.steps + 8)))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(0, args.steps, spr):                         # EXACTLY args.steps training steps (spr per launch)
