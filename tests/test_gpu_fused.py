@@ -282,6 +282,64 @@ def test_graphed_train_step_matches_eager():
             assert float(diff.max()) < 0.02, "graph-replayed parameters drifted from the eager ones"
 
 
+def test_graphed_fine_all_step_matches_eager():
+    """The `fine_all` call shape captured into a graph -- render(rot_cov=True, accum_R=<static, refreshed per call>, which_object=1),
+    hand-mask gate as a static input -- replayed on changing (camera, image, accum_R, gate) leaves the parameters where the same steps
+    launched eagerly leave them (/root/reference/trainers/fine_all.py:88-101)."""
+    import math
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.fused import l1_ssim_loss
+    from egogaussian_amd.optim import FusedAdam
+    from egogaussian_amd.graph import GraphedTrainStep, pack_frame
+    N, H, W, K = 15000, 96, 160, 5
+    teacher = make_scene(N, H, W, 0); teacher["log_scale"] += math.log(2.0)
+    student = perturb_student(teacher)
+    gen = torch.Generator().manual_seed(9)
+    is_obj = (torch.rand(N, 1, generator=gen) < 0.3).float().to(DEV)
+    cams = [make_camera(k, H, W, device=DEV) for k in (0, 40, 80, 120)]
+    bg = torch.zeros(3, device=DEV)
+
+    def rot(a):
+        c, s_ = math.cos(a), math.sin(a)
+        return torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]], device=DEV)
+    Rs = [rot(0.2 * k) for k in range(4)]
+    gates = [(torch.rand(H, W, generator=gen) > 0.2).float().to(DEV) for _ in range(4)]
+    kw = lambda k: dict(rot_cov=True, accum_R=Rs[k], which_object=1, during_training=False)
+    with torch.no_grad():
+        tpc = SynthGaussians(teacher, device=DEV, requires_grad=False); tpc._is_object = is_obj
+        gts = [render(c, tpc, Pipe, bg, **kw(k))["render"].clone() for k, c in enumerate(cams)]
+    groups = lambda pc: [{"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3}, {"params": [pc._opacity], "lr": 0.05},
+                         {"params": [pc._scaling], "lr": 5e-3}, {"params": [pc._rotation], "lr": 1e-3}]
+    WARM = 2
+    pa = SynthGaussians(student, device=DEV); pa._is_object = is_obj
+    oa = FusedAdam(groups(pa), lr=0.0, eps=1e-15)
+    for k in [0] * WARM + [i % 4 for i in range(1, K + 1)]:
+        out = render(cams[k], pa, Pipe, bg, **kw(k))
+        l1_ssim_loss(out["render"], gts[k], 0.2, grad_gate=gates[k]).backward()
+        oa.step(); oa.zero_grad(set_to_none=True)
+    pb = SynthGaussians(student, device=DEV); pb._is_object = is_obj
+    ob = FusedAdam(groups(pb), lr=0.0, eps=1e-15, capturable=True)
+    step = GraphedTrainStep(pb, ob, bg, dynamic=True, gated=True).capture(cams[0], gts[0], warmup=WARM, accum_R=Rs[0], gate=gates[0])
+    for i in range(1, K + 1):
+        k = i % 4
+        if i % 2:
+            step(cams[k], gts[k], accum_R=Rs[k], gate=gates[k])                           # four separate copies
+        else:
+            step(pack_frame(cams[k], gts[k], Rs[k], gates[k]))                            # one packed copy
+    torch.cuda.synchronize()
+    assert step.ok()
+    for a, b in zip(pa.parameters(), pb.parameters()):
+        if a.numel():
+            diff = (a.detach() - b.detach()).abs()
+            assert float((diff > 2e-5 * float(a.detach().abs().max()) + 1e-6).float().mean()) < 2e-3 and float(diff.max()) < 0.02
+    # the gate really gates: a zero gate leaves no gradient at all
+    ob.zero_grad(set_to_none=True)                                       # (the replays left their gradients in .grad)
+    out = render(cams[1], pb, Pipe, bg, **kw(1))
+    l1_ssim_loss(out["render"], gts[1], 0.2, grad_gate=torch.zeros(H, W, device=DEV)).backward()
+    assert all(float(p.grad.abs().max()) == 0.0 for p in (pb._xyz, pb._features_dc, pb._opacity, pb._scaling, pb._rotation))
+
+
 def test_several_steps_per_replay_match_single_step_replays():
     """GraphedTrainStep(steps_per_replay=3): one launch = three complete iterations on three frames; six such steps must leave the
     parameters where six single-step replays leave them (up to the order of the float atomics), with every loss recorded."""
