@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every step from Python instead of replaying a captured hipGraph")
     ap.add_argument("--torch-host-ops", action="store_true",
                     help="build cov3D and the loss with PyTorch ops (as the reference does) instead of the fused HIP kernels")
-    ap.add_argument("--steps-per-replay", type=int, default=4,
+    ap.add_argument("--steps-per-replay", type=int, default=5,
                     help="training steps captured into one hipGraph (each on its own frame); lowered to a divisor of --steps when needed; 1 = one launch per step")
     ap.add_argument("--verify-ranks", action="store_true", help="add per-rank frame lists, start-of-run parameter checksums and loss sums to the JSON line")
     args = ap.parse_args()
