@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-    const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ tile_order, float* __restrict__ grad_acc) {
+    const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ tile_order, float* __restrict__ grad_acc,
+    const uint32_t* __restrict__ quad_visits) {
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
     __shared__ __attribute__((aligned(16))) float red[4][5 * 64];
     const int tile = (int)tile_order[blockIdx.x];                   // 0xffffffff = padding workgroup
@@ -189,6 +190,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     float abl_sink = 0.f;
 #endif
 
+    // Longest-remaining-work-first.  A SIMD issues its oldest wave first, and the tiles are dispatched most expensive first, so the
+    // light, late waves used to wait for the others and then run down alone -- the last quarter of the launch had fewer than three
+    // waves per SIMD (profiles/r2_blend_timelines.md).  The forward counted the splats every quadrant blends; this wave's issue
+    // priority (s_setprio, 4 levels) follows the number it still has to replay, so the waves of a SIMD reach the end together.
+    // Placement-like: it decides who issues first, never a result.  -DEGS_NO_LRPT builds without it.
+#ifndef EGS_NO_LRPT
+    int remaining = (int)quad_visits[tile * 4 + q];
+    int prio_now = -1;
+#endif
     const int nb = (int)((wmax + 63) / 64);
     int b = nb - 1;
     uint32_t id_next = (uint32_t)b * 64 + lane < wmax ? list[(uint32_t)b * 64 + lane] : 0u;
@@ -214,6 +224,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << j);
+#ifndef EGS_NO_LRPT
+            {
+                const int want = remaining >= 64 ? 3 : remaining >= 24 ? 2 : remaining >= 8 ? 1 : 0;       // (thresholds swept at config C)
+                if (want != prio_now) {
+                    prio_now = want;
+                    if (want == 3) __builtin_amdgcn_s_setprio(3); else if (want == 2) __builtin_amdgcn_s_setprio(2); else if (want == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                }
+                remaining--;
+            }
+#endif
             const float4 s0 = my[j * 3 + 0], s1 = my[j * 3 + 1];
             const float2 s2 = *reinterpret_cast<const float2*>(&my[j * 3 + 2]);
             const float dx = s0.x - pxf, dy = s0.y - pyf;
@@ -302,10 +322,10 @@ hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs
     if (dL_ddepth || dL_dalpha)
         hipLaunchKernelGGL(k_render_backward<true>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                            im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
-                           im.tile_order, grad_acc);
+                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles);
     else
         hipLaunchKernelGGL(k_render_backward<false>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                            im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
-                           im.tile_order, grad_acc);
+                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles);
     return hipGetLastError();
 }

@@ -30,6 +30,12 @@
 
 namespace {
 
+#ifndef EGS_FWD_LRPT1           // estimated splats left at which the forward's issue priority steps up (swept at config C)
+#define EGS_FWD_LRPT1 16
+#define EGS_FWD_LRPT2 48
+#define EGS_FWD_LRPT3 128
+#endif
+
 __global__ __launch_bounds__(256) void k_render_forward(
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
@@ -74,6 +80,26 @@ __global__ __launch_bounds__(256) void k_render_forward(
 
     bool alive = true;                                             // wave-uniform: some pixel still live
     for (uint32_t base = 0; alive && base < n; base += 64) {
+#ifndef EGS_NO_LRPT
+        // Longest-remaining-work-first, as in the backward (render_bwd.hip) -- but here the work left is not known, so it is estimated
+        // once per batch from the quadrant's own history: its least saturated pixel has come ln(Tmax) of the way to ln(1e-4) with the
+        // splats blended so far, so about visits * (ln(1e-4) - ln Tmax) / ln Tmax are left, and never more than the rest of the list
+        // would give at the same rate.  The wave's issue priority (4 levels) follows that estimate; it decides who issues first,
+        // never a result.
+        if (base) {
+            float tmax = Tl;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, d, 64));
+            const float lnT = __logf(fmaxf(tmax, 1e-30f));
+            const float by_decay = lnT < -1e-4f ? (9.2103404f + lnT) / -lnT : 1e9f;
+            const float by_list = (float)(n - base) / (float)base;
+            const int left = (int)__builtin_amdgcn_readfirstlane((int)fminf((float)visits * fminf(fmaxf(by_decay, 0.f), by_list), 1e6f));
+            const int want = left >= EGS_FWD_LRPT3 ? 3 : left >= EGS_FWD_LRPT2 ? 2 : left >= EGS_FWD_LRPT1 ? 1 : 0;
+            if (want == 3) __builtin_amdgcn_s_setprio(3); else if (want == 2) __builtin_amdgcn_s_setprio(2); else if (want == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        } else {
+            __builtin_amdgcn_s_setprio(3);
+        }
+#endif
         const float4 c0 = r0, c1 = r1, c2 = r2;
         const bool have = base + lane < n;
         // issue the next batch's gathers now
