@@ -66,6 +66,8 @@ __device__ __forceinline__ float row_sum(float v) {
 // captured into the hipGraph): the step got 3 % SLOWER -- the graph's cross-stream dependencies cost more than the 11 us hidden.
 #define ORDER_MAX_BAND 8192
 #define ORDER_LEVELS 1024
+#define ORDER_BALANCE_MAX 256               // band size up to which every workgroup of the launch is resident at once (8 per CU x 32 CUs)
+#define EGS_ORDER_HAS_PERM 0x01000000u      // tile_order word: bits 0-15 tile, 16-23 quadrant for the wave on SIMD 0..3 (two bits each), 24 = those are set
 __global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const uint32_t* __restrict__ quad_work,
                                                              uint32_t* __restrict__ tile_order, float4* __restrict__ acc4, size_t n4) {
     if (blockIdx.x >= EGS_XCDS) {
@@ -77,6 +79,8 @@ __global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const u
     // the order only decides which workgroup blends which tile, never a result.
     __shared__ uint32_t work[ORDER_MAX_BAND];
     __shared__ uint32_t level_base[ORDER_LEVELS], level_fill[ORDER_LEVELS], wsum[16], wmax_s;
+    __shared__ uint4 quad_cost[ORDER_BALANCE_MAX];                   // the four quadrant costs of every tile of a small band
+    __shared__ uint16_t sorted_tile[ORDER_BALANCE_MAX];
     const int per = egs_tiles_per_xcd(n_tiles), x = blockIdx.x;
     const int t0 = x * per, n = max(0, min(per, n_tiles - t0));
     const int slots = ((per + 31) / 32) * 32;
@@ -92,8 +96,10 @@ __global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const u
         const uint4 w4 = *reinterpret_cast<const uint4*>(quad_work + 4 * (size_t)(t0 + i));
         const uint32_t wsum_i = w4.x + w4.y + w4.z + w4.w;
         work[i] = wsum_i; mx = max(mx, wsum_i);
+        if (per <= ORDER_BALANCE_MAX) quad_cost[i] = w4;
     }
-    for (int sl = threadIdx.x; sl < per; sl += blockDim.x) tile_order[8 * sl + x] = 0xffffffffu;
+    if (per > ORDER_BALANCE_MAX)
+        for (int sl = threadIdx.x; sl < per; sl += blockDim.x) tile_order[8 * sl + x] = 0xffffffffu;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(&wmax_s, mx);
@@ -121,11 +127,63 @@ __global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const u
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const uint32_t lv = work[i];
         const int rank = (int)(level_base[lv] + atomicAdd(&level_fill[lv], 1u));
+        if (per <= ORDER_BALANCE_MAX) { sorted_tile[rank] = (uint16_t)i; continue; }      // band-local index, most expensive first
         const int round = rank / 32, pos = rank % 32;
         int slot = round * 32 + ((round & 1) ? 31 - pos : pos);
         if (slot >= per) slot = round * 32 + pos;                    // last, partial round: no room to mirror
         if (slot >= per) slot = per - 1 - (slots - 1 - slot);        // (cannot happen when per is a multiple of 32)
         tile_order[8 * slot + x] = (uint32_t)(t0 + i);
+    }
+    if (per > ORDER_BALANCE_MAX) return;
+    // Small band (every workgroup of the launch resident at once: the workgroup in slot 32 k + c of the band runs on CU c).  With the
+    // waves' issue priority following the work they have left (k_render_backward), a SIMD ends when its total work is done (measured
+    // correlation of blended splats per SIMD and SIMD end: 0.99), so what is left to balance is that total:
+    //   * CUs: dealt in sorted rounds -- in every round the CU that carries the least so far takes the round's most expensive tile;
+    //   * SIMDs: the four quadrant-waves of a workgroup land on the CU's four SIMDs, and which wave takes which quadrant is free, so
+    //     the tile's most expensive quadrant goes to the SIMD of that CU that carries the least.  The choice rides in bits 16-23 of
+    //     the tile_order word (two bits per SIMD = the quadrant its wave should take); the wave reads its SIMD from HW_ID.
+    // One wave does it (lane c = CU c), from the costs cached in LDS.
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int c = (int)threadIdx.x;
+    uint32_t load_cu = 0, ls0 = 0, ls1 = 0, ls2 = 0, ls3 = 0;
+    const int rounds = (per + 31) / 32;
+    for (int k = 0; k < rounds; k++) {
+        const bool has_slot = c < 32 && 32 * k + c < per;
+        const int m = min(32, n - 32 * k);                           // tiles of this round (uniform)
+        // position of this CU among the CUs with a slot, lightest first: 32 v_readlane + compare on unique keys (a loop of __shfl
+        // = ds_bpermute, each waited for, made this launch 13 us longer)
+        const uint32_t key = has_slot ? (min(load_cu, 0x03ffffffu) << 5) | (uint32_t)c : 0xffffffffu;
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 32; j++) rank += (uint32_t)__builtin_amdgcn_readlane((int)key, j) < key ? 1 : 0;
+        uint32_t word = 0xffffffffu;
+        if (has_slot && rank < m) {
+            const int i = (int)sorted_tile[32 * k + rank];
+            const uint4 w4 = quad_cost[i];
+            // two four-element sorting networks on (value << 2 | index) keys: registers only (indexing a local array by a run-time
+            // value would go through scratch memory, ~1 us per access)
+            uint32_t a0 = (min(w4.x, 0x3fffffffu) << 2) | 0u, a1 = (min(w4.y, 0x3fffffffu) << 2) | 1u,
+                     a2 = (min(w4.z, 0x3fffffffu) << 2) | 2u, a3 = (min(w4.w, 0x3fffffffu) << 2) | 3u;      // quadrants, to be sorted descending
+            uint32_t b0 = (min(ls0, 0x3fffffffu) << 2) | 0u, b1 = (min(ls1, 0x3fffffffu) << 2) | 1u,
+                     b2 = (min(ls2, 0x3fffffffu) << 2) | 2u, b3 = (min(ls3, 0x3fffffffu) << 2) | 3u;        // SIMDs, ascending
+#define EGS_CS(lo, hi) { const uint32_t t_ = min(lo, hi); hi = max(lo, hi); lo = t_; }
+            EGS_CS(a0, a1) EGS_CS(a2, a3) EGS_CS(a0, a2) EGS_CS(a1, a3) EGS_CS(a1, a2)          // a0 <= a1 <= a2 <= a3
+            EGS_CS(b0, b1) EGS_CS(b2, b3) EGS_CS(b0, b2) EGS_CS(b1, b3) EGS_CS(b1, b2)          // b0 <= b1 <= b2 <= b3
+#undef EGS_CS
+            // the most expensive quadrant (a3) goes to the least loaded SIMD (b0), and so on
+            const uint32_t qd[4] = { a3 & 3u, a2 & 3u, a1 & 3u, a0 & 3u }, cd[4] = { a3 >> 2, a2 >> 2, a1 >> 2, a0 >> 2 };
+            const uint32_t sd[4] = { b0 & 3u, b1 & 3u, b2 & 3u, b3 & 3u };
+            uint32_t perm = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {                            // (r is a compile-time index after unrolling)
+                perm |= qd[r] << (2u * sd[r]);
+                ls0 += sd[r] == 0u ? cd[r] : 0u; ls1 += sd[r] == 1u ? cd[r] : 0u; ls2 += sd[r] == 2u ? cd[r] : 0u; ls3 += sd[r] == 3u ? cd[r] : 0u;
+            }
+            load_cu += w4.x + w4.y + w4.z + w4.w;
+            word = (uint32_t)(t0 + i) | (perm << 16) | EGS_ORDER_HAS_PERM;
+        }
+        if (has_slot) tile_order[8 * (32 * k + c) + x] = word;
     }
 }
 
@@ -141,11 +199,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint32_t* __restrict__ quad_visits) {
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
     __shared__ __attribute__((aligned(16))) float red[4][5 * 64];
-    const int tile = (int)tile_order[blockIdx.x];                   // 0xffffffff = padding workgroup
-    if (tile < 0) return;
-    const unsigned lane = threadIdx.x & 63, q = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
-    float4* my = lds[q];
-    float* myred = red[q];
+    __shared__ uint32_t quad_claimed;
+    const uint32_t order_word = tile_order[blockIdx.x];              // 0xffffffff = padding workgroup
+    if (order_word == 0xffffffffu) return;
+    const int tile = (int)(order_word & ((order_word & EGS_ORDER_HAS_PERM) ? 0xffffu : 0xffffffffu));
+    const unsigned lane = threadIdx.x & 63, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
+    // Which quadrant this wave blends: the one the prologue chose for the SIMD it happens to run on (HW_ID bits 4-5), claimed
+    // through an LDS word so that the four waves take four different quadrants whatever the placement was (balance only -- any
+    // assignment gives the same sums).
+    unsigned q = wv;
+    if (order_word & EGS_ORDER_HAS_PERM) {
+        if (threadIdx.x == 0) quad_claimed = 0u;
+        __syncthreads();
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned want = (order_word >> (16 + 2 * ((hw >> 4) & 3u))) & 3u;
+        if (lane == 0) {
+            uint32_t before = atomicOr(&quad_claimed, 1u << want);
+            while (before & (1u << want)) {                          // taken (two waves of the workgroup on one SIMD): any free one
+                want = (unsigned)__builtin_ctz(~before & 0xfu);
+                before = atomicOr(&quad_claimed, 1u << want);
+            }
+        }
+        q = (unsigned)__builtin_amdgcn_readfirstlane((int)want);
+    }
+    float4* my = lds[wv];
+    float* myred = red[wv];
 #if defined(EGS_MEASURE) && EGS_MEASURE == 4      // instrumentation build (tools/lane_use.py): per-wave timeline of the backward
     const uint64_t t_start = wall_clock64();
     uint32_t meas = 0;
