@@ -190,12 +190,14 @@ def visible_view(geom, P):
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alpha,
-                                 debug, activation_flags=0, sh_rest=None, densify_stats=None, guard=None):
+                                 debug, activation_flags=0, sh_rest=None, densify_stats=None, guard=None, sink=None):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
            dL_dscales[P,3], dL_drotations[P,4]); with sh_rest, dL_dsh is [P,1,3] and a ninth element dL_dsh_rest[P,M-1,3] follows.
     densify_stats (extension): (xyz_gradient_accum[P,1], denom[P,1], max_radii2D[P] or None), float32, updated in place by the kernel
     that produces dL_dmeans2D (include/egs_raster.h) -- the caller then skips its add_densification_stats for this iteration.
-    guard (extension): the StepGuard of the forward; the statistics are left untouched when its overflow word is set."""
+    guard (extension): the StepGuard of the forward; the statistics are left untouched when its overflow word is set.
+    sink (extension): an optim.AdamSink -- the leaves it owns take their Adam step inside this backward (include/egs_raster.h,
+    egs_backward_adam); their gradients are not produced: those positions of the result are None."""
     L = _lib.load()
     means3D = _f32c(means3D, "means3D")
     dev = means3D.device
@@ -213,13 +215,31 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     with torch.cuda.device(dev):
         e = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
         own_cov = cov3D_precomp is None
-        dmeans2D, dcolors, dopacity, dmeans3D = e(P, 3), e(P, 3), e(P, 1), e(P, 3)
+        owned = set() if sink is None or P == 0 else sink.check(means3D=means3D, scales=scales, rotations=rotations, sh=sh, sh_rest=sh_rest,
+                                                                own_cov=own_cov, colors=colors)
+        keep = sink is not None and getattr(sink, "keep_grads", False)      # tests: the owned leaves' gradients are written as well
+        fused = lambda leaf: leaf in owned and not keep
+        dmeans2D = e(P, 3)
+        dcolors = None if (owned and not keep and sh is not None and sh_rest is None and M == 1) else e(P, 3)      # scratch nobody reads in that case
+        dopacity = None if fused(_lib.SINK_OPACITY) else e(P, 1)
+        dmeans3D = None if fused(_lib.SINK_MEANS3D) else e(P, 3)
         dcov3D = e(0, 6) if own_cov else e(P, 6)             # not produced when the library built the covariance itself
-        dsh = e(*sh.shape) if sh is not None else e(0, 0, 3)
+        dsh = None if fused(_lib.SINK_SH) else (e(*sh.shape) if sh is not None else e(0, 0, 3))
         dsh_rest = e(*sh_rest.shape) if sh_rest is not None else None
-        dscales = e(P, 3) if own_cov else e(0, 3)          # absent inputs get empty gradients (the autograd Function maps them to None)
-        drots = e(P, 4) if own_cov else e(0, 4)
-        if P != 0:
+        dscales = None if fused(_lib.SINK_SCALES) else (e(P, 3) if own_cov else e(0, 3))   # absent inputs get empty gradients (the autograd Function maps them to None)
+        drots = None if fused(_lib.SINK_ROTATIONS) else (e(P, 4) if own_cov else e(0, 4))
+        if P != 0 and owned:
+            scratch = torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
+            _lib.check(L.egs_backward_adam(
+                P, int(degree), M, int(R), _ptr(background), _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors), _ptr(scales),
+                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
+                _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
+                _ptr(imageBuffer), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(dmeans2D), _ptr(dcolors),
+                _ptr(dopacity), _ptr(dmeans3D), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
+                _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
+                C.byref(sink.struct), _ptr(scratch), _stream(), int(bool(debug))))
+            sink.mark_stepped()
+        elif P != 0:
             scratch = torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
             _lib.check(L.egs_backward(
                 P, int(degree), M, int(R), _ptr(background), _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors), _ptr(scales),

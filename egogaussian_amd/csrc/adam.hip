@@ -24,11 +24,7 @@ struct AdamArgs {
     int n; float b1, b2, eps;
 };
 
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps, float ss, float ib) {
-    m = fmaf(1.f - b1, g - m, m);
-    v = fmaf(1.f - b2, g * g, b2 * v);
-    p -= ss * (m / (sqrtf(v) * ib + eps));
-}
+__global__ void k_adam_tick(EgsAdamTick t) { egs_adam_tick(t, threadIdx.x); }
 
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     if (a.skip && *a.skip) return;                                   // the frame behind these gradients overflowed its instance capacity: no step at all
@@ -68,13 +64,13 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
         if (vec && i + 4 <= n) {
             float4 P = *reinterpret_cast<float4*>(p + i), M = *reinterpret_cast<float4*>(m + i), V = *reinterpret_cast<float4*>(v + i);
             const float4 G = *reinterpret_cast<const float4*>(g + i);
-            adam1(P.x, G.x, M.x, V.x, a.b1, a.b2, a.eps, ss, ib); adam1(P.y, G.y, M.y, V.y, a.b1, a.b2, a.eps, ss, ib);
-            adam1(P.z, G.z, M.z, V.z, a.b1, a.b2, a.eps, ss, ib); adam1(P.w, G.w, M.w, V.w, a.b1, a.b2, a.eps, ss, ib);
+            egs_adam1(P.x, G.x, M.x, V.x, a.b1, a.b2, a.eps, ss, ib); egs_adam1(P.y, G.y, M.y, V.y, a.b1, a.b2, a.eps, ss, ib);
+            egs_adam1(P.z, G.z, M.z, V.z, a.b1, a.b2, a.eps, ss, ib); egs_adam1(P.w, G.w, M.w, V.w, a.b1, a.b2, a.eps, ss, ib);
             *reinterpret_cast<float4*>(p + i) = P; *reinterpret_cast<float4*>(m + i) = M; *reinterpret_cast<float4*>(v + i) = V;
         } else {
             for (long long j = i; j < i + 4 && j < n; j++) {
                 float P = p[j], M = m[j], V = v[j];
-                adam1(P, g[j], M, V, a.b1, a.b2, a.eps, ss, ib);
+                egs_adam1(P, g[j], M, V, a.b1, a.b2, a.eps, ss, ib);
                 p[j] = P; m[j] = M; v[j] = V;
             }
         }
@@ -82,6 +78,11 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
 }
 
 }  // namespace
+
+hipError_t egs_launch_adam_tick(const EgsAdamTick& tick, hipStream_t s) {
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, s, tick);
+    return hipGetLastError();
+}
 
 static int adam_impl(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const int64_t* numels, const float* lrs, const int64_t* steps,

@@ -353,6 +353,89 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
     return 0;
 }
 
+static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const float* background, const float* means3D,
+                 const float* shs, const float* shs_rest, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, int width, int height, float tan_fovx, float tan_fovy, const int32_t* radii,
+                 const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                 const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
+                 float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
+                 float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
+                 const uint32_t* skip_flag, const egs_adam_sink* sink, void* scratch, void* stream, int debug) {
+    int rc = check_dims(P, width, height); if (rc) return rc;
+    if (P == 0) return 0;
+    if (R < 0 || R >= (1ll << 31)) return EGS_ERR_RANGE;
+    if (!background || !means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer ||
+        !dL_dout_color || !dL_dmeans2D || !scratch)
+        return EGS_ERR_ARG;
+    // leaves a fused optimizer owns: their gradient arrays are optional
+    const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);
+    bool own[EGS_SINK_LEAVES] = { false, false, false, false, false };
+    if (sink) {
+        if (!sink->coef) return EGS_ERR_ARG;
+        for (int l = 0; l < EGS_SINK_LEAVES; l++) {
+            const egs_adam_leaf& f = sink->leaf[l];
+            own[l] = f.param != nullptr;
+            if (own[l] && (!f.exp_avg || !f.exp_avg_sq || !f.lr || !f.step)) return EGS_ERR_ARG;
+        }
+        if ((own[EGS_SINK_SCALES] || own[EGS_SINK_ROTATIONS]) && cov3D_precomp) return EGS_ERR_MODE;
+        if (own[EGS_SINK_SH] && (!shs || sh_apart)) return EGS_ERR_MODE;
+        if (own[EGS_SINK_MEANS3D] && sh_apart) return EGS_ERR_MODE;
+        if ((own[EGS_SINK_MEANS3D] && sink->leaf[EGS_SINK_MEANS3D].param != means3D) || (own[EGS_SINK_SCALES] && sink->leaf[EGS_SINK_SCALES].param != scales) ||
+            (own[EGS_SINK_ROTATIONS] && sink->leaf[EGS_SINK_ROTATIONS].param != rotations) || (own[EGS_SINK_SH] && sink->leaf[EGS_SINK_SH].param != shs))
+            return EGS_ERR_ARG;
+    }
+    if ((!dL_dcolors && (colors_precomp || sh_apart)) || (!dL_dopacity && !own[EGS_SINK_OPACITY]) || (!dL_dmeans3D && !own[EGS_SINK_MEANS3D]))
+        return EGS_ERR_ARG;
+    if (R > 0 && !binning_buffer) return EGS_ERR_ARG;
+    rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp, activation_flags); if (rc) return rc;
+    if (shs && !dL_dsh && !own[EGS_SINK_SH]) return EGS_ERR_ARG;
+    if (shs_rest && (!shs || sh_coeffs < 2)) return EGS_ERR_MODE;
+    if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr)) return EGS_ERR_ARG;
+    if ((stat_grad_accum != nullptr) != (stat_denom != nullptr) || (stat_max_radii && !stat_grad_accum)) return EGS_ERR_ARG;
+    if (!cov3D_precomp && ((!dL_dscales && !own[EGS_SINK_SCALES]) || (!dL_drotations && !own[EGS_SINK_ROTATIONS]))) return EGS_ERR_ARG;
+    if (cov3D_precomp && !dL_dcov3D) return EGS_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
+    EgsBinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), P, R, width, height);
+    EgsImgPtrs im = img_ptrs(const_cast<void*>(image_buffer), width, height);
+    float* grad_acc = (float*)scratch;
+    EgsSink ks = {}; EgsAdamTick tick = {};
+    if (sink) {
+        for (int l = 0; l < EGS_SINK_LEAVES; l++) {
+            if (!own[l]) continue;
+            ks.leaf[l].p = sink->leaf[l].param; ks.leaf[l].m = sink->leaf[l].exp_avg; ks.leaf[l].v = sink->leaf[l].exp_avg_sq;
+            tick.step[l] = sink->leaf[l].step; tick.lr[l] = sink->leaf[l].lr;
+        }
+        ks.coef = sink->coef; ks.active_rows = sink->active_rows; ks.skip = skip_flag; ks.b1 = sink->beta1; ks.b2 = sink->beta2; ks.eps = sink->eps;
+        tick.coef = sink->coef; tick.skip = skip_flag; tick.b1 = sink->beta1; tick.b2 = sink->beta2;
+    }
+    // the accumulator is cleared by a kernel, not a memset node (see egs_launch_zero_f4): fused into the blend's prologue
+    if (R == 0) {
+        EGS_TRY(egs_launch_zero_f4((float4*)grad_acc, (size_t)P * EGS_GRAD_STRIDE / 4, s));
+        if (sink) EGS_TRY(egs_launch_adam_tick(tick, s));
+    }
+    if (R > 0) {
+        const uint32_t* point_list = b.point_list;
+        egs_prof_start(EGS_K_RENDER_BWD, s);
+        EGS_TRY(egs_launch_render_backward(width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth,
+                                           dL_dout_alpha, grad_acc, (size_t)P * EGS_GRAD_STRIDE, sink ? &tick : nullptr, s));
+        egs_prof_stop(EGS_K_RENDER_BWD, s);
+        EGS_SYNC_IF_DEBUG(s);
+    }
+    egs_prof_start(EGS_K_PREPROCESS_BWD, s);
+    EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
+    EGS_TRY(egs_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, scales, scale_modifier, rotations,
+                                           cov3D_precomp, activation_flags, cam, radii, g, grad_acc, colors_precomp != nullptr, dL_dmeans2D,
+                                           dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, sh_apart ? nullptr : dL_dsh, dL_dscales,
+                                           dL_drotations, stat_grad_accum, stat_denom, stat_max_radii, skip_flag, sink ? &ks : nullptr, s));
+    if (sh_apart) EGS_TRY(egs_launch_sh_backward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, radii, g, dL_dcolors, dL_dsh,
+                                                 dL_dsh_rest, dL_dmeans3D, s));
+    egs_prof_stop(EGS_K_PREPROCESS_BWD, s);
+    EGS_SYNC_IF_DEBUG(s);
+    return 0;
+}
+
 int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* background, const float* means3D,
                  const float* shs, const float* shs_rest, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix,
@@ -362,47 +445,28 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
                  float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
                  float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
                  const uint32_t* skip_flag, void* scratch, void* stream, int debug) {
-    int rc = check_dims(P, width, height); if (rc) return rc;
-    if (P == 0) return 0;
-    if (R < 0 || R >= (1ll << 31)) return EGS_ERR_RANGE;
-    if (!background || !means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer ||
-        !dL_dout_color || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !scratch)
-        return EGS_ERR_ARG;
-    if (R > 0 && !binning_buffer) return EGS_ERR_ARG;
-    rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp, activation_flags); if (rc) return rc;
-    if (shs && !dL_dsh) return EGS_ERR_ARG;
-    if (shs_rest && (!shs || sh_coeffs < 2)) return EGS_ERR_MODE;
-    if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr)) return EGS_ERR_ARG;
-    if ((stat_grad_accum != nullptr) != (stat_denom != nullptr) || (stat_max_radii && !stat_grad_accum)) return EGS_ERR_ARG;
-    if (!cov3D_precomp && (!dL_dscales || !dL_drotations)) return EGS_ERR_ARG;
-    if (cov3D_precomp && !dL_dcov3D) return EGS_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
-    EgsBinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), P, R, width, height);
-    EgsImgPtrs im = img_ptrs(const_cast<void*>(image_buffer), width, height);
-    float* grad_acc = (float*)scratch;
-    // the accumulator is cleared by a kernel, not a memset node (see egs_launch_zero_f4): fused into the blend's prologue
-    if (R == 0) EGS_TRY(egs_launch_zero_f4((float4*)grad_acc, (size_t)P * EGS_GRAD_STRIDE / 4, s));
-    if (R > 0) {
-        const uint32_t* point_list = b.point_list;
-        egs_prof_start(EGS_K_RENDER_BWD, s);
-        EGS_TRY(egs_launch_render_backward(width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth,
-                                           dL_dout_alpha, grad_acc, (size_t)P * EGS_GRAD_STRIDE, s));
-        egs_prof_stop(EGS_K_RENDER_BWD, s);
-        EGS_SYNC_IF_DEBUG(s);
-    }
-    egs_prof_start(EGS_K_PREPROCESS_BWD, s);
-    EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
-    const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);
-    EGS_TRY(egs_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, scales, scale_modifier, rotations,
-                                           cov3D_precomp, activation_flags, cam, radii, g, grad_acc, colors_precomp != nullptr, dL_dmeans2D,
-                                           dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, sh_apart ? nullptr : dL_dsh, dL_dscales,
-                                           dL_drotations, stat_grad_accum, stat_denom, stat_max_radii, skip_flag, s));
-    if (sh_apart) EGS_TRY(egs_launch_sh_backward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, radii, g, dL_dcolors, dL_dsh,
-                                                 dL_dsh_rest, dL_dmeans3D, s));
-    egs_prof_stop(EGS_K_PREPROCESS_BWD, s);
-    EGS_SYNC_IF_DEBUG(s);
-    return 0;
+    if (!dL_dcolors || !dL_dopacity || !dL_dmeans3D) return P == 0 ? 0 : EGS_ERR_ARG;
+    return backward_impl(P, sh_degree, sh_coeffs, R, background, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations,
+                         cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, geom_buffer,
+                         binning_buffer, image_buffer, dL_dout_color, dL_dout_depth, dL_dout_alpha, dL_dmeans2D, dL_dcolors, dL_dopacity,
+                         dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscales, dL_drotations, stat_grad_accum, stat_denom, stat_max_radii,
+                         skip_flag, nullptr, scratch, stream, debug);
+}
+
+int egs_backward_adam(int P, int sh_degree, int sh_coeffs, int64_t R, const float* background, const float* means3D,
+                      const float* shs, const float* shs_rest, const float* colors_precomp, const float* scales, float scale_modifier,
+                      const float* rotations, const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix,
+                      const float* campos, int width, int height, float tan_fovx, float tan_fovy, const int32_t* radii,
+                      const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                      const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
+                      float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
+                      float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
+                      const uint32_t* skip_flag, const egs_adam_sink* sink, void* scratch, void* stream, int debug) {
+    return backward_impl(P, sh_degree, sh_coeffs, R, background, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations,
+                         cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, geom_buffer,
+                         binning_buffer, image_buffer, dL_dout_color, dL_dout_depth, dL_dout_alpha, dL_dmeans2D, dL_dcolors, dL_dopacity,
+                         dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscales, dL_drotations, stat_grad_accum, stat_denom, stat_max_radii,
+                         skip_flag, sink, scratch, stream, debug);
 }
 
 int egs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

@@ -66,6 +66,43 @@ int egs_bin_gpb(int P);                                          // Gaussians pe
 int egs_key_bits_for_tiles(int n_tiles);
 size_t egs_scan_scratch_elems(size_t n);
 
+// ---- Adam, shared by the stand-alone optimizer launch (adam.hip) and the optimizer fused into the preprocess backward ----------
+// torch.optim.Adam with weight_decay = 0, amsgrad = False, maximize = False; ss = lr / (1 - b1^t), ib = 1 / sqrt(1 - b2^t)
+__device__ __forceinline__ void egs_adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps, float ss, float ib) {
+    m = fmaf(1.f - b1, g - m, m);
+    v = fmaf(1.f - b2, g * g, b2 * v);
+    p -= ss * (m / (sqrtf(v) * ib + eps));
+}
+// Leaves a fused optimizer can own (include/egs_raster.h: EGS_SINK_*), in the order their rows are staged: floats per row and
+// the float4 task at which each leaf's share of a 256-Gaussian workgroup starts (64 * row floats tasks each).
+#define EGS_SINK_LEAVES 5
+#define EGS_SINK_TASKS 896
+struct EgsSinkLeaf { float* p; float* m; float* v; };
+struct EgsSink {                       // kernel argument of k_preprocess_backward<true>
+    EgsSinkLeaf leaf[EGS_SINK_LEAVES]; const float* coef; const int32_t* active_rows; const uint32_t* skip; float b1, b2, eps;
+};
+struct EgsAdamTick {                   // one thread per backward: advances state["step"] and derives the two coefficients of every leaf
+    float* step[EGS_SINK_LEAVES]; const float* lr[EGS_SINK_LEAVES]; float* coef; const uint32_t* skip; float b1, b2;
+};
+// Called by threads 0 .. 2 * EGS_SINK_LEAVES - 1 of ONE workgroup: thread 2 l derives the step size of leaf l (and advances its
+// state["step"]), thread 2 l + 1 the second-moment correction -- the double-precision pow() calls run side by side (one thread doing
+// all ten made its launch 4 us longer).
+__device__ __forceinline__ void egs_adam_tick(const EgsAdamTick& t, unsigned lane) {
+    if (lane >= 2 * EGS_SINK_LEAVES) return;
+    if (t.skip && *t.skip) return;                                   // overflowed frame: no step is taken, none is counted
+#pragma unroll
+    for (int l = 0; l < EGS_SINK_LEAVES; l++) {
+        if ((lane >> 1) != (unsigned)l || !t.step[l]) continue;
+        // the same double-precision expressions as k_adam / the host use: fused and stand-alone steps are bit-identical
+        const double st = (double)t.step[l][0] + 1.0;                // (both threads of the pair read the step before either writes: see below)
+        const double bc = 1.0 - pow((double)((lane & 1) ? t.b2 : t.b1), st);
+        const float out = (lane & 1) ? (float)(1.0 / sqrt(bc)) : (float)((double)t.lr[l][0] / bc);
+        t.coef[2 * l + (lane & 1)] = out;
+        __builtin_amdgcn_wave_barrier();                             // the pair sits in one wave: its loads of step[l] precede this store in program order
+        if (!(lane & 1)) t.step[l][0] = (float)st;
+    }
+}
+
 // ---- launchers (host side, one per translation unit) -------------------------------------------
 struct EgsCamera {
     const float* view; const float* proj; const float* campos;
@@ -83,7 +120,7 @@ hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* mean
                                           int colors_given, float* dmeans2D, float* dcolors, float* dopac,
                                           float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,
                                           float* stat_grad_accum, float* stat_denom, float* stat_max_radii, const uint32_t* skip_flag,
-                                          hipStream_t s);
+                                          const EgsSink* sink /*NULL: gradients only*/, hipStream_t s);
 // Spherical harmonics as separate launches (M > 1 coefficients, or DC / rest given as two arrays: sh_rest != NULL).  The
 // preprocess launchers are then called with shs = NULL: the forward leaves the record's colour open, the backward leaves
 // dL/dSH and the view-direction part of dL/dmean3D to egs_launch_sh_backward (which must run after it).
@@ -104,9 +141,11 @@ hipError_t egs_launch_binning(int P, int64_t R, int W, int H, EgsGeomPtrs g, Egs
 hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                      EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha,
                                      hipStream_t s);
+// `tick` (may be NULL): the per-step bookkeeping of an optimizer fused into this backward, done by one thread of the prologue launch
 hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
-                                      const float* dL_dalpha, float* grad_acc, size_t acc_floats, hipStream_t s);
+                                      const float* dL_dalpha, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick, hipStream_t s);
+hipError_t egs_launch_adam_tick(const EgsAdamTick& tick, hipStream_t s);       // the same bookkeeping as a launch of its own (frames with no instance)
 
 // Zero-fill by a kernel.  hipMemsetAsync is avoided inside the per-step chain: captured into a hipGraph it becomes a memset
 // node, and on ROCm 7.2 replays of the training-step graph intermittently saw stale accumulator contents with it.

@@ -248,8 +248,15 @@ __global__ __launch_bounds__(256) void k_preprocess(
     if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-__global__ __launch_bounds__(256) void k_preprocess_backward(
-    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+// stage offsets (floats) of the leaves a fused optimizer owns: rows of the workgroup's 256 Gaussians, leaf after leaf
+#define ST_MEANS 0
+#define ST_OPAC 768
+#define ST_SCALES 1024
+#define ST_ROTS 1792
+#define ST_SH 2816
+template <bool SINK>
+__device__ __forceinline__ void pp_bwd_one(
+    const int i, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, float mod, const float* __restrict__ rots, const float* __restrict__ cov3D_in, int act,
     const float* __restrict__ V, const float* __restrict__ PM, const float* __restrict__ campos, int W, int H,
     float tanfovx, float tanfovy, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
@@ -257,9 +264,10 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     float* __restrict__ dopac, float* __restrict__ dmeans3D, float* __restrict__ dcov3D, float* __restrict__ dsh,
     float* __restrict__ dscales, float* __restrict__ drots,
     float* __restrict__ stat_grad_accum, float* __restrict__ stat_denom, float* __restrict__ stat_max_radii,
-    const uint32_t* __restrict__ skip_flag) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    const uint32_t* __restrict__ skip_flag, float* __restrict__ stage, const unsigned fused) {
+    // SINK: the gradients of the leaves in `fused` (bit = EGS_SINK_*) also go to `stage` (LDS), from where the workgroup applies
+    // Adam to its 256 rows; their dX arrays may then be NULL (nothing written)
+    const unsigned tid = threadIdx.x;
     const bool vis = radii[i] > 0;
     float acc[EGS_GRAD_STRIDE];
     {
@@ -291,20 +299,27 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
         stat_denom[i] += 1.f;
         if (stat_max_radii) stat_max_radii[i] = fmaxf(stat_max_radii[i], (float)radii[i]);
     }
-    dcolors[3 * i] = acc[6]; dcolors[3 * i + 1] = acc[7]; dcolors[3 * i + 2] = acc[8];
+    if (dcolors) { dcolors[3 * i] = acc[6]; dcolors[3 * i + 1] = acc[7]; dcolors[3 * i + 2] = acc[8]; }
     {   // logit opacities: chain through the sigmoid with the activated value the forward parked in the record
         const float o = rec[(size_t)i * EGS_SPLAT_REC_F4 + 1].y;
-        dopac[i] = (vis && (act & EGS_ACT_LOGIT_OPACITY)) ? acc[5] * (o * (1.f - o)) : acc[5];
+        const float go = (vis && (act & EGS_ACT_LOGIT_OPACITY)) ? acc[5] * (o * (1.f - o)) : acc[5];
+        if (dopac) dopac[i] = go;
+        if (SINK && (fused & (1u << EGS_SINK_OPACITY))) stage[ST_OPAC + tid] = go;
     }
     float gmean[3] = { 0.f, 0.f, 0.f }, g6[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     if (!vis) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) dmeans3D[3 * i + k] = 0.f;
+        for (int k = 0; k < 3; k++) if (dmeans3D) dmeans3D[3 * i + k] = 0.f;
 #pragma unroll
         for (int k = 0; k < 6; k++) if (dcov3D) dcov3D[6 * (size_t)i + k] = 0.f;
         if (dsh) for (int k = 0; k < M * 3; k++) dsh[(size_t)i * M * 3 + k] = 0.f;
         if (dscales) { dscales[3 * i] = 0.f; dscales[3 * i + 1] = 0.f; dscales[3 * i + 2] = 0.f; }
         if (drots) { drots[4 * i] = 0.f; drots[4 * i + 1] = 0.f; drots[4 * i + 2] = 0.f; drots[4 * i + 3] = 0.f; }
+        if (SINK) {                                                   // a culled Gaussian still takes its Adam step, with a zero gradient
+#pragma unroll
+            for (int k = 0; k < 3; k++) { stage[ST_MEANS + 3 * tid + k] = 0.f; stage[ST_SCALES + 3 * tid + k] = 0.f; stage[ST_SH + 3 * tid + k] = 0.f; }
+            *reinterpret_cast<float4*>(stage + ST_ROTS + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         return;
     }
     const float p[3] = { means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2] };
@@ -378,7 +393,8 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
         const float inv = 1.f / sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
         const float x = d0[0] * inv, y = d0[1] * inv, z = d0[2] * inv;
         const float* sh = shs + (size_t)i * M * 3;
-        float* gsh = dsh + (size_t)i * M * 3;
+        // (fused SH leaf: M == 1, checked by the caller; without a dsh array the three values go straight to the stage)
+        float* gsh = dsh ? dsh + (size_t)i * M * 3 : stage + ST_SH + 3 * tid;
         const uint32_t cl = clamped[i];
         float gdir[3] = { 0.f, 0.f, 0.f };
         for (int ch = 0; ch < 3; ch++) {
@@ -419,13 +435,15 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
 #undef GSH
             gdir[0] += dx_ * g; gdir[1] += dy_ * g; gdir[2] += dz_ * g;
         }
+        if (SINK && dsh && (fused & (1u << EGS_SINK_SH))) { stage[ST_SH + 3 * tid] = gsh[0]; stage[ST_SH + 3 * tid + 1] = gsh[1]; stage[ST_SH + 3 * tid + 2] = gsh[2]; }
         const float dot = x * gdir[0] + y * gdir[1] + z * gdir[2];
         gmean[0] += (gdir[0] - x * dot) * inv; gmean[1] += (gdir[1] - y * dot) * inv; gmean[2] += (gdir[2] - z * dot) * inv;
     }
-    dmeans3D[3 * i] = gmean[0]; dmeans3D[3 * i + 1] = gmean[1]; dmeans3D[3 * i + 2] = gmean[2];
+    if (dmeans3D) { dmeans3D[3 * i] = gmean[0]; dmeans3D[3 * i + 1] = gmean[1]; dmeans3D[3 * i + 2] = gmean[2]; }
+    if (SINK && (fused & (1u << EGS_SINK_MEANS3D))) { stage[ST_MEANS + 3 * tid] = gmean[0]; stage[ST_MEANS + 3 * tid + 1] = gmean[1]; stage[ST_MEANS + 3 * tid + 2] = gmean[2]; }
 
     // cov3D -> scale, quaternion (only when the forward built cov3D itself)
-    if (dscales && drots) {
+    if (!cov3D_in) {
         float Rm[9]; quat_to_rot(q, Rm);
         const float sc[3] = { mod * s[0], mod * s[1], mod * s[2] };
         const float Gs[9] = { g6[0], 0.5f * g6[1], 0.5f * g6[2], 0.5f * g6[1], g6[3], 0.5f * g6[4],
@@ -443,7 +461,9 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const float ds = mod * (gL[k] * Rm[k] + gL[3 + k] * Rm[3 + k] + gL[6 + k] * Rm[6 + k]);
-            dscales[3 * i + k] = (act & EGS_ACT_LOG_SCALES) ? ds * s[k] : ds;               // d/d log-scale = d/d scale * scale
+            const float dsk = (act & EGS_ACT_LOG_SCALES) ? ds * s[k] : ds;                  // d/d log-scale = d/d scale * scale
+            if (dscales) dscales[3 * i + k] = dsk;
+            if (SINK && (fused & (1u << EGS_SINK_SCALES))) stage[ST_SCALES + 3 * tid + k] = dsk;
 #pragma unroll
             for (int a = 0; a < 3; a++) gR[3 * a + k] = gL[3 * a + k] * sc[k];
         }
@@ -458,9 +478,90 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
 #pragma unroll
             for (int k = 0; k < 4; k++) gq[k] = (gq[k] - q[k] * dot) * qinv;
         }
-        drots[4 * i + 0] = gq[0]; drots[4 * i + 1] = gq[1]; drots[4 * i + 2] = gq[2]; drots[4 * i + 3] = gq[3];
+        if (drots) { drots[4 * i + 0] = gq[0]; drots[4 * i + 1] = gq[1]; drots[4 * i + 2] = gq[2]; drots[4 * i + 3] = gq[3]; }
+        if (SINK && (fused & (1u << EGS_SINK_ROTATIONS))) *reinterpret_cast<float4*>(stage + ST_ROTS + 4 * tid) = make_float4(gq[0], gq[1], gq[2], gq[3]);
     }
 }
+
+// One lane per Gaussian.  SINK (the optimizer fused into the backward, include/egs_raster.h egs_backward_adam): instead of (or besides)
+// writing the gradients of the leaves it owns, the workgroup parks them in LDS in array order and then takes the Adam step of ITS 256
+// rows of every such leaf with the stand-alone kernel's arithmetic (egs_adam1) and access pattern (float4, fully coalesced:
+// rows 256 b .. 256 b + 255 of a [P, k] array are one contiguous span).  The gradients never reach HBM and the parameters are not
+// read a second time by another launch: 16 B in + 12 B out per element become 12 + 12, and the step has one launch less.
+// 896 float4 tasks per workgroup (64 x (3 + 1 + 3 + 4 + 3)), task -> leaf boundaries fall on wave boundaries.
+template <bool SINK>
+__global__ __launch_bounds__(256) void k_preprocess_backward(
+    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ scales, float mod, const float* __restrict__ rots, const float* __restrict__ cov3D_in, int act,
+    const float* __restrict__ V, const float* __restrict__ PM, const float* __restrict__ campos, int W, int H,
+    float tanfovx, float tanfovy, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
+    const float4* __restrict__ rec, const float* __restrict__ grad_acc, float* __restrict__ dmeans2D, float* __restrict__ dcolors,
+    float* __restrict__ dopac, float* __restrict__ dmeans3D, float* __restrict__ dcov3D, float* __restrict__ dsh,
+    float* __restrict__ dscales, float* __restrict__ drots,
+    float* __restrict__ stat_grad_accum, float* __restrict__ stat_denom, float* __restrict__ stat_max_radii,
+    const uint32_t* __restrict__ skip_flag, EgsSink sink) {
+    __shared__ __attribute__((aligned(16))) float stage[SINK ? 4 * EGS_SINK_TASKS : 4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned fused = 0;
+    if (SINK) {
+#pragma unroll
+        for (int l = 0; l < EGS_SINK_LEAVES; l++) fused |= sink.leaf[l].p ? (1u << l) : 0u;
+    }
+    if (i < P)
+        pp_bwd_one<SINK>(i, D, M, means3D, shs, scales, mod, rots, cov3D_in, act, V, PM, campos, W, H, tanfovx, tanfovy, radii, clamped, rec,
+                         grad_acc, dmeans2D, dcolors, dopac, dmeans3D, dcov3D, dsh, dscales, drots, stat_grad_accum, stat_denom,
+                         stat_max_radii, skip_flag, stage, fused);
+    if (!SINK) return;
+    __syncthreads();
+    if (sink.skip && *sink.skip) return;                            // the frame overflowed its instance capacity: no step (and none was counted)
+    const int rows = sink.active_rows ? min(P, max(*sink.active_rows, 0)) : P;      // capacity-sized model: live rows only
+    const int row0 = blockIdx.x * 256;
+    const int live = min(256, rows - row0);                          // rows of this workgroup that take the step
+    if (live <= 0) return;
+    constexpr int RF[EGS_SINK_LEAVES] = { 3, 1, 3, 4, 3 };
+    constexpr int T0[EGS_SINK_LEAVES + 1] = { 0, 192, 256, 448, 704, 896 };
+    // all loads of the thread's (up to four) tasks first, then the arithmetic, then the stores
+    float4 Pq[4], Mq[4], Vq[4]; int cnt[4]; float* pp[4]; float* pm[4]; float* pv[4]; float ss[4], ib[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int task = (int)threadIdx.x + 256 * k;
+        cnt[k] = 0;
+#pragma unroll
+        for (int l = 0; l < EGS_SINK_LEAVES; l++) {
+            if (task < T0[l] || task >= T0[l + 1] || !sink.leaf[l].p) continue;
+            const int e = 4 * (task - T0[l]);                         // first element of the task inside the workgroup's span of leaf l
+            const size_t off = (size_t)row0 * RF[l] + e;
+            pp[k] = sink.leaf[l].p + off; pm[k] = sink.leaf[l].m + off; pv[k] = sink.leaf[l].v + off;
+            cnt[k] = max(0, min(4, live * RF[l] - e));
+            ss[k] = sink.coef[2 * l]; ib[k] = sink.coef[2 * l + 1];
+        }
+        if (cnt[k] == 4 && ((((size_t)pp[k]) | ((size_t)pm[k]) | ((size_t)pv[k])) & 15) == 0) {
+            Pq[k] = *reinterpret_cast<const float4*>(pp[k]); Mq[k] = *reinterpret_cast<const float4*>(pm[k]); Vq[k] = *reinterpret_cast<const float4*>(pv[k]);
+        } else if (cnt[k] > 0) {
+            float t[12];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const bool ok = j < cnt[k]; t[j] = ok ? pp[k][j] : 0.f; t[4 + j] = ok ? pm[k][j] : 0.f; t[8 + j] = ok ? pv[k][j] : 0.f; }
+            Pq[k] = make_float4(t[0], t[1], t[2], t[3]); Mq[k] = make_float4(t[4], t[5], t[6], t[7]); Vq[k] = make_float4(t[8], t[9], t[10], t[11]);
+            cnt[k] = -cnt[k];                                          // negative: element-wise stores
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (cnt[k] == 0) continue;
+        const float4 G = *reinterpret_cast<const float4*>(stage + 4 * ((int)threadIdx.x + 256 * k));
+        float4 Pn = Pq[k], Mn = Mq[k], Vn = Vq[k];
+        egs_adam1(Pn.x, G.x, Mn.x, Vn.x, sink.b1, sink.b2, sink.eps, ss[k], ib[k]); egs_adam1(Pn.y, G.y, Mn.y, Vn.y, sink.b1, sink.b2, sink.eps, ss[k], ib[k]);
+        egs_adam1(Pn.z, G.z, Mn.z, Vn.z, sink.b1, sink.b2, sink.eps, ss[k], ib[k]); egs_adam1(Pn.w, G.w, Mn.w, Vn.w, sink.b1, sink.b2, sink.eps, ss[k], ib[k]);
+        if (cnt[k] == 4) {
+            *reinterpret_cast<float4*>(pp[k]) = Pn; *reinterpret_cast<float4*>(pm[k]) = Mn; *reinterpret_cast<float4*>(pv[k]) = Vn;
+        } else {
+            const float a[4] = { Pn.x, Pn.y, Pn.z, Pn.w }, b_[4] = { Mn.x, Mn.y, Mn.z, Mn.w }, c_[4] = { Vn.x, Vn.y, Vn.z, Vn.w };
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (j < -cnt[k]) { pp[k][j] = a[j]; pm[k][j] = b_[j]; pv[k][j] = c_[j]; }
+        }
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Spherical harmonics with more than one coefficient (or given as separate DC / rest arrays).  A Gaussian's row is 12 M
@@ -951,13 +1052,16 @@ hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* mean
                                           int colors_given, float* dmeans2D, float* dcolors, float* dopac,
                                           float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,
                                           float* stat_grad_accum, float* stat_denom, float* stat_max_radii, const uint32_t* skip_flag,
-                                          hipStream_t s) {
+                                          const EgsSink* sink, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_preprocess_backward, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D,
-                       colors_given ? nullptr : shs, scales, mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W,
-                       cam.H, cam.tanfovx, cam.tanfovy, radii, g.clamped, g.rec, grad_acc, dmeans2D, dcolors, dopac, dmeans3D,
-                       dcov3D, colors_given ? nullptr : dsh, cov3D ? nullptr : dscales, cov3D ? nullptr : drots,
-                       stat_grad_accum, stat_denom, stat_max_radii, skip_flag);
+    EgsSink none = {};
+#define PPB_ARGS P, D, M, means3D, colors_given ? nullptr : shs, scales, mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W, \
+                 cam.H, cam.tanfovx, cam.tanfovy, radii, g.clamped, g.rec, grad_acc, dmeans2D, dcolors, dopac, dmeans3D, \
+                 dcov3D, colors_given ? nullptr : dsh, cov3D ? nullptr : dscales, cov3D ? nullptr : drots, \
+                 stat_grad_accum, stat_denom, stat_max_radii, skip_flag
+    if (sink) hipLaunchKernelGGL(k_preprocess_backward<true>, dim3((P + 255) / 256), dim3(256), 0, s, PPB_ARGS, *sink);
+    else hipLaunchKernelGGL(k_preprocess_backward<false>, dim3((P + 255) / 256), dim3(256), 0, s, PPB_ARGS, none);
+#undef PPB_ARGS
     return hipGetLastError();
 }
 

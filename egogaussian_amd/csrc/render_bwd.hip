@@ -69,10 +69,15 @@ __device__ __forceinline__ float row_sum(float v) {
 #define ORDER_BALANCE_MAX 256               // band size up to which every workgroup of the launch is resident at once (8 per CU x 32 CUs)
 #define EGS_ORDER_HAS_PERM 0x01000000u      // tile_order word: bits 0-15 tile, 16-23 quadrant for the wave on SIMD 0..3 (two bits each), 24 = those are set
 __global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const uint32_t* __restrict__ quad_work,
-                                                             uint32_t* __restrict__ tile_order, float4* __restrict__ acc4, size_t n4) {
+                                                             uint32_t* __restrict__ tile_order, float4* __restrict__ acc4, size_t n4,
+                                                             int has_tick, EgsAdamTick tick) {
     if (blockIdx.x >= EGS_XCDS) {
-        const size_t stride = (size_t)(gridDim.x - EGS_XCDS) * 1024;
-        for (size_t i = (size_t)(blockIdx.x - EGS_XCDS) * 1024 + threadIdx.x; i < n4; i += stride) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // an optimizer fused into this backward (egs_backward_adam): its once-per-step bookkeeping rides here, two launches ahead of
+        // its reader, in a workgroup of its own (the first after the ordering ones) so that no zeroing waits for the pow() calls
+        const unsigned first = EGS_XCDS + (has_tick ? 1u : 0u);
+        if (blockIdx.x < first) { if (threadIdx.x < 64) egs_adam_tick(tick, threadIdx.x); return; }
+        const size_t stride = (size_t)(gridDim.x - first) * 1024;
+        for (size_t i = (size_t)(blockIdx.x - first) * 1024 + threadIdx.x; i < n4; i += stride) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     // Order of one band: a counting sort on the cost quantised to ORDER_LEVELS levels (descending).  Ties land in arrival order --
@@ -390,14 +395,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
-                                      const float* dL_dalpha, float* grad_acc, size_t acc_floats, hipStream_t s) {
+                                      const float* dL_dalpha, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick, hipStream_t s) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
-    if (n_tiles == 0) return egs_launch_zero_f4((float4*)grad_acc, acc_floats / 4, s);
+    if (n_tiles == 0) {
+        if (tick) { hipError_t e = egs_launch_adam_tick(*tick, s); if (e != hipSuccess) return e; }
+        return egs_launch_zero_f4((float4*)grad_acc, acc_floats / 4, s);
+    }
     const size_t n4 = acc_floats / 4;
-    const unsigned zero_blocks = (unsigned)std::min<size_t>((n4 + 1023) / 1024, 1024);
-    hipLaunchKernelGGL(k_backward_prologue, dim3(EGS_XCDS + zero_blocks), dim3(1024), 0, s, n_tiles, im.quad_work, im.tile_order,
-                       (float4*)grad_acc, n4);
+    const unsigned zero_blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((n4 + 1023) / 1024, 1024));
+    EgsAdamTick no_tick = {};
+    hipLaunchKernelGGL(k_backward_prologue, dim3(EGS_XCDS + (tick ? 1 : 0) + zero_blocks), dim3(1024), 0, s, n_tiles, im.quad_work, im.tile_order,
+                       (float4*)grad_acc, n4, tick ? 1 : 0, tick ? *tick : no_tick);
     if (dL_ddepth || dL_dalpha)
         hipLaunchKernelGGL(k_render_backward<true>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                            im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,

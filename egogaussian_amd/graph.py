@@ -93,7 +93,7 @@ class _StaticCamera:
 
 class GraphedTrainStep:
     def __init__(self, pc, optimizer, bg, lambda_dssim=0.2, pipe=Pipe, render_kwargs=None, densify_stats=False, dynamic=False,
-                 which_object=1, gated=False, check_every=0, steps_per_replay=1):
+                 which_object=1, gated=False, check_every=0, steps_per_replay=1, fuse_optimizer=True):
         """densify_stats: the captured step also keeps the per-iteration densification statistics (trainers/train_static.py:125-127:
                        max_radii2D, xyz_gradient_accum, denom) -- updated by the rasterizer's backward itself, no launch of their own.
         dynamic:       the `fine_all` call shape (/root/reference/trainers/fine_all.py:88-93): render(..., rot_cov=True,
@@ -104,7 +104,12 @@ class GraphedTrainStep:
                        instance capacity if a frame was clipped (its update was skipped, see the module docstring).
         steps_per_replay: S > 1 captures S complete iterations back to back, each on its own static frame; one launch then runs
                        S training steps on S frames (`__call__` takes the S packed frames as one [S, frame] tensor or a list).  A
-                       graph launch leaves the GPU idle for ~9 us before its first node; this divides that by S."""
+                       graph launch leaves the GPU idle for ~9 us before its first node; this divides that by S.
+        fuse_optimizer: the parameters render() hands to the rasterizer as stored take their Adam step inside its backward
+                       (renderer.render, optimizer=): no gradient arrays, no optimizer launch for them; the step's loss must then
+                       depend on the model through that one render only -- which is the step this class captures.  Results are
+                       bit-identical either way."""
+        self.fuse_optimizer = bool(fuse_optimizer)
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True)")
         self.pc, self.opt, self.bg, self.lam, self.pipe = pc, optimizer, bg, lambda_dssim, pipe
@@ -126,12 +131,13 @@ class GraphedTrainStep:
         kw = dict(self.render_kwargs)
         if self.dynamic:
             kw.update(rot_cov=True, accum_R=f["accum_R"], which_object=self.which_object, during_training=False)
-        out = render(f["cam"], self.pc, self.pipe, self.bg, fused_densify_stats=self.densify_stats, guard=self.guard, **kw)
+        out = render(f["cam"], self.pc, self.pipe, self.bg, fused_densify_stats=self.densify_stats, guard=self.guard,
+                     optimizer=self.opt if self.fuse_optimizer else None, **kw)
         # the loss value and the running sum are produced by the loss BACKWARD kernel (nothing reads them before): two launches less
         loss = l1_ssim_loss(out["render"], f["gt"], self.lam, grad_gate=f["gate"] if self.gated else None, running_sum=self.loss_sum,
                             defer_value=True)
         loss.backward(gradient=self._one)                            # a resident 1.0: no fill kernel per iteration
-        self.opt.step()
+        self.opt.step()                                              # whatever the backward did not step itself (fuse_optimizer)
         return loss.detach(), out
 
     def _frame_layout(self, gt):

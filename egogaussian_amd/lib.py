@@ -27,6 +27,17 @@ class ImageLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("ranges", "final_T", "n_contrib", "quad_work", "tile_order", "quad_pairs")]
 
 
+class AdamLeaf(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("param", "exp_avg", "exp_avg_sq", "lr", "step")]
+
+
+class AdamSink(C.Structure):                     # egs_adam_sink
+    _fields_ = [("leaf", AdamLeaf * 5), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("coef", C.c_void_p),
+                ("active_rows", C.c_void_p)]
+
+
+SINK_MEANS3D, SINK_OPACITY, SINK_SCALES, SINK_ROTATIONS, SINK_SH = range(5)      # EGS_SINK_*
+
 # name -> (restype, argtypes); every symbol include/egs_raster.h declares
 SIGNATURES = {
     "egs_abi_version": (C.c_int, []),
@@ -49,6 +60,8 @@ SIGNATURES = {
     "egs_forward_render": (C.c_int, [i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
                                vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
+    "egs_backward_adam": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
+                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(AdamSink), vp, vp, i32]),
     "egs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "egs_cov3d_forward": (C.c_int, [i32, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_cov3d_dm_scratch_floats": (C.c_size_t, [i32]),

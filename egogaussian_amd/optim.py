@@ -13,6 +13,31 @@ from torch.utils.weak import WeakIdKeyDictionary
 from . import lib as _lib
 
 
+class AdamSink:
+    """The per-Gaussian leaves of a FusedAdam(capturable=True) that ONE rasterizer backward steps itself (include/egs_raster.h,
+    egs_backward_adam): built by FusedAdam.make_sink() for the tensors of one render call, consumed by that call's backward.
+    `owned` holds the EGS_SINK_* ids; `struct` is the egs_adam_sink handed to the library; `ptrs` the leaves' data pointers."""
+
+    def __init__(self, struct, owned, ptrs, keep, opt=None, params=()):
+        self.struct, self.owned, self.ptrs, self._keep = struct, owned, ptrs, keep
+        self._opt, self._params = opt, tuple(params)
+        self.keep_grads = False           # True: the backward also writes (and returns) the owned leaves' gradients -- inspection / tests
+
+    def mark_stepped(self):
+        """Called once the backward that carries this sink has been enqueued: the next optimizer.step() leaves the owned leaves
+        alone even if a gradient reached them (keep_grads)."""
+        if self._opt is not None:
+            self._opt._sunk.update(id(p) for p in self._params)
+
+    def check(self, means3D, scales, rotations, sh, sh_rest, own_cov, colors):
+        """Called by _C.rasterize_gaussians_backward with the arrays it is about to pass: the owned leaves must be those arrays."""
+        got = {_lib.SINK_MEANS3D: means3D, _lib.SINK_SCALES: scales, _lib.SINK_ROTATIONS: rotations, _lib.SINK_SH: sh}
+        for leaf, t in got.items():
+            if leaf in self.owned and (t is None or t.data_ptr() != self.ptrs[leaf]):
+                raise RuntimeError("AdamSink: the backward received a different array than the leaf the sink was built for")
+        return self.owned
+
+
 class FusedAdam(torch.optim.Optimizer):
     """capturable=True keeps the step count and every group's learning rate in device scalars that the kernel reads (and, for
     the count, advances), so
@@ -28,6 +53,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._aux = WeakIdKeyDictionary()
         self.guard = None                 # _C.StepGuard of a captured step: its overflow word makes step() a no-op for a clipped frame
         self.active_rows = None           # (int32[1] device tensor, capacity rows): only the live rows of a capacity-sized model are stepped
+        self._coef = {}                   # device -> float32[10] scratch of the fused path (make_sink)
+        self._sunk = set()                # id(p) of parameters a rasterizer backward stepped since the last step()
 
     def load_state_dict(self, state_dict):
         """The device-side step counters and learning rates are derived state: dropped here and re-seeded from the loaded
@@ -40,6 +67,75 @@ class FusedAdam(torch.optim.Optimizer):
         if a is None:
             a = self._aux[p] = {}
         return a
+
+    def _capturable_state(self, p, group):
+        """(exp_avg, exp_avg_sq, step float32[1] on the device, lr float32[1] on the device) of parameter p, created on first use."""
+        st = self.state[p]
+        if "exp_avg" not in st:
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if not (torch.is_tensor(st.get("step")) and st["step"].is_cuda):
+            st["step"] = torch.full((1,), float(st.get("step", 0)), device=p.device)
+        aux = self._aux_of(p)
+        lr_t = aux.get("lr")
+        if lr_t is None:
+            lr_t = aux["lr"] = torch.full((1,), float(group["lr"]), device=p.device)
+            aux["lr_host"] = float(group["lr"])
+        return st["exp_avg"], st["exp_avg_sq"], st["step"], lr_t
+
+    def make_sink(self, means3D=None, opacities=None, scales=None, rotations=None, sh=None, sh_rest=None, cov3D_given=False,
+                  colors_given=False):
+        """An AdamSink for the tensors ONE rasterizer call is about to receive, or None when none of them can be fused.  A tensor
+        is fused when it IS a parameter of this optimizer (the raw leaf, not an activation of it) that requires grad, and the
+        library's conditions hold (include/egs_raster.h).  The caller vouches that this rasterizer call is the ONLY consumer of
+        those leaves in the backward to come: their gradient is consumed in place, `p.grad` stays None and step() skips them.
+        All leaves of one sink share betas / eps (one param-group configuration), as the reference's optimizer does."""
+        if not self.capturable:
+            return None
+        by_ptr = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                by_ptr[p.data_ptr()] = (p, group)
+        P = None if means3D is None else means3D.shape[0]
+        sh_single = sh is not None and sh.numel() != 0 and sh.dim() == 3 and sh.shape[1] == 1 and (sh_rest is None or sh_rest.numel() == 0)
+        want = {_lib.SINK_MEANS3D: (means3D, 3, colors_given or sh_single), _lib.SINK_OPACITY: (opacities, 1, True),
+                _lib.SINK_SCALES: (scales, 3, not cov3D_given), _lib.SINK_ROTATIONS: (rotations, 4, not cov3D_given),
+                _lib.SINK_SH: (sh, 3, sh_single and not colors_given)}
+        struct, owned, ptrs, keep, cfg, params = _lib.AdamSink(), set(), {}, [], None, []
+        for leaf, (t, rf, allowed) in want.items():
+            if t is None or not allowed or t.numel() == 0 or not t.requires_grad:
+                continue
+            ent = by_ptr.get(t.data_ptr())
+            if ent is None:
+                continue
+            p, group = ent
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.shape[0] == P and p.numel() == P * rf):
+                continue
+            this_cfg = (tuple(group["betas"]), float(group["eps"]))
+            if cfg is None:
+                cfg = this_cfg
+            elif cfg != this_cfg:
+                continue                                              # another betas / eps: left to step()
+            m, v, step, lr_t = self._capturable_state(p, group)
+            if not (m.is_contiguous() and v.is_contiguous()):
+                continue
+            f = struct.leaf[leaf]
+            f.param, f.exp_avg, f.exp_avg_sq, f.lr, f.step = p.data_ptr(), m.data_ptr(), v.data_ptr(), lr_t.data_ptr(), step.data_ptr()
+            owned.add(leaf); ptrs[leaf] = p.data_ptr(); keep += [p, m, v, lr_t, step]; params.append(p)
+            self._aux_of(p)["counter_stale"] = True                   # k_adam's own step counters no longer follow state["step"]
+        if not owned:
+            return None
+        dev = means3D.device
+        coef = self._coef.get(dev)
+        if coef is None:
+            coef = self._coef[dev] = torch.zeros(10, device=dev)
+        struct.beta1, struct.beta2, struct.eps, struct.coef = float(cfg[0][0]), float(cfg[0][1]), float(cfg[1]), coef.data_ptr()
+        if self.active_rows is not None and P == self.active_rows[1]:
+            struct.active_rows = self.active_rows[0].data_ptr()
+            keep.append(self.active_rows[0])
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        return AdamSink(struct, owned, ptrs, keep + [coef], self, params)
 
     def sync_lr(self):
         for group in self.param_groups:
@@ -59,21 +155,15 @@ class FusedAdam(torch.optim.Optimizer):
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
         by_cfg = {}
+        sunk, self._sunk = self._sunk, set()
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or id(p) in sunk:                  # (sunk: a rasterizer backward took this step already, make_sink)
                     continue
+                self._capturable_state(p, group)
                 st = self.state[p]
-                if "exp_avg" not in st:
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if not (torch.is_tensor(st.get("step")) and st["step"].is_cuda):
-                    st["step"] = torch.full((1,), float(st.get("step", 0)), device=p.device)
                 aux = self._aux_of(p)
-                lr_t = aux.get("lr")
-                if lr_t is None:
-                    lr_t = aux["lr"] = torch.full((1,), float(group["lr"]), device=p.device)
-                    aux["lr_host"] = float(group["lr"])
+                lr_t = aux["lr"]
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 # the kernel keeps the step number in one word per workgroup of this tensor and advances them itself;
                 # (re)seeded here from state["step"] when the tensor is new (densification replaced it, or a state dict was loaded)
@@ -83,6 +173,11 @@ class FusedAdam(torch.optim.Optimizer):
                     if torch.cuda.is_current_stream_capturing():
                         raise RuntimeError("FusedAdam(capturable=True): take one eager step() before capturing (device counters are created then)")
                     ent = aux["counter"] = (torch.full((max(G, 1),), int(round(float(st["step"]))), dtype=torch.int32, device=p.device), G, p.numel())
+                    aux["counter_stale"] = False
+                if aux.get("counter_stale"):
+                    # steps taken inside a rasterizer backward (make_sink) advanced state["step"] only: re-seed the words on the device
+                    ent[0].copy_(st["step"].round().to(torch.int32).expand(ent[0].shape))
+                    aux["counter_stale"] = False
                 rf = 0
                 if self.active_rows is not None and p.dim() >= 1 and p.shape[0] == self.active_rows[1] and p.shape[0] > 0:
                     rf = p.numel() // p.shape[0]                  # a per-Gaussian array of the capacity-sized model

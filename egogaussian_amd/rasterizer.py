@@ -39,8 +39,12 @@ class GaussianRasterizationSettings(NamedTuple):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None):
+                activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None, optimizer=None):
         rs = raster_settings
+        # optimizer (extension): a FusedAdam(capturable=True) whose leaves among THIS call's inputs take their step inside the backward
+        ctx.sink = None if (optimizer is None or not any(ctx.needs_input_grad)) else optimizer.make_sink(
+            means3D=means3D, opacities=opacities, scales=scales, rotations=rotations, sh=sh, sh_rest=sh_rest,
+            cov3D_given=cov3Ds_precomp.numel() != 0, colors_given=colors_precomp.numel() != 0)
         if sh_rest is None:
             sh_rest = torch.empty(0, device=means3D.device, dtype=torch.float32)
         num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
@@ -77,21 +81,22 @@ class _RasterizeGaussians(torch.autograd.Function):
         grads = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos, geom,
-            ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags, sh_rest if split else None, ctx.densify_stats, ctx.guard)
+            ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags, sh_rest if split else None, ctx.densify_stats, ctx.guard,
+            ctx.sink)
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = grads[:8]
-        none_if_absent = lambda g, x: g if x.numel() != 0 else None
+        none_if_absent = lambda g, x: g if (g is not None and x.numel() != 0) else None
         return (g_means3D, g_means2D, none_if_absent(g_sh, sh), none_if_absent(g_colors, colors_precomp),
                 g_opac, none_if_absent(g_scales, scales),
                 none_if_absent(g_rots, rotations), none_if_absent(g_cov3D, cov3Ds_precomp), None, None,
-                grads[8] if split else None, None, None, None)
+                grads[8] if split else None, None, None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None):
+                        raster_settings, activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None, optimizer=None):
     """-> (color, radii, depth, alpha, visible); upstream's function returns the first four, `visible` (bool[P] = radii > 0) is an
     extension GaussianRasterizer keeps for render()."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, activation_flags, sh_rest, densify_stats, active_count, guard)
+                                     cov3Ds_precomp, raster_settings, activation_flags, sh_rest, densify_stats, active_count, guard, optimizer)
 
 
 class GaussianRasterizer(nn.Module):
@@ -106,7 +111,7 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, raw_parameters=False, densify_stats=None, active_count=None, guard=None):
+                cov3D_precomp=None, raw_parameters=False, densify_stats=None, active_count=None, guard=None, optimizer=None):
         """Same call as upstream's.  raw_parameters=True (an extension): `scales`, `rotations` and `opacities` are the model's RAW
         parameters (log-scales, unnormalised quaternions, opacity logits); the activations run inside the preprocess kernel and
         the gradients come back w.r.t. the raw tensors (include/egs_raster.h, EGS_ACT_*).
@@ -115,6 +120,9 @@ class GaussianRasterizer(nn.Module):
         # densify_stats (an extension): (xyz_gradient_accum, denom, max_radii2D or None) -- the backward updates the trainer's
         # densification statistics in place, in the kernel that produces the screen-space gradient (include/egs_raster.h)
         # active_count (an extension): int32[1] device tensor = live rows of a capacity-sized model; guard: a _C.StepGuard
+        # optimizer (an extension): a FusedAdam(capturable=True).  Every input of this call that IS one of its parameters takes its
+        # Adam step inside the backward (its .grad stays None and optimizer.step() skips it) -- only valid when this call is the
+        # sole consumer of those parameters in the backward pass (optim.FusedAdam.make_sink)
         # After the call `self.visible` holds radii > 0 as a bool view the preprocess kernel wrote (no compare launch); it aliases
         # state saved for the backward and, under hipGraph replay, follows every replay -- clone it to keep or edit it.
         shs_rest = None
@@ -137,5 +145,5 @@ class GaussianRasterizer(nn.Module):
             raise Exception("GaussianRasterizer: raw_parameters needs `scales` and `rotations`, not `cov3D_precomp`")
         color, radii, depth, alpha, self.visible = rasterize_gaussians(
             means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, self.raster_settings,
-            _C.ACT_RAW_PARAMETERS if raw_parameters else 0, shs_rest, densify_stats, active_count, guard)
+            _C.ACT_RAW_PARAMETERS if raw_parameters else 0, shs_rest, densify_stats, active_count, guard, optimizer)
         return color, radii, depth, alpha

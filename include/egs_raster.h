@@ -217,6 +217,51 @@ int egs_backward(
     const uint32_t* skip_flag /*device uint32[1] or NULL: non-zero = leave the three statistics untouched (overflowed frame)*/,
     void* scratch /* egs_backward_scratch_bytes(P) */, void* stream, int debug);
 
+/* ---- backward with the optimizer inside (ABI 2 addition; no upstream counterpart: upstream returns the gradients to autograd
+ *      and torch.optim.Adam reads them back, /root/reference/trainers/train_static.py:97,137).
+ * egs_backward_adam is egs_backward plus, for every LEAF the sink owns, the Adam step of that leaf taken by the kernel that
+ * produces its gradient: the gradient never reaches HBM, the parameter is not read again by an optimizer launch, and the training
+ * step has one launch less.  Arithmetic and results are those of egs_adam_step_capturable, bit for bit.
+ *   - A leaf is one of the five per-Gaussian inputs below; `param` must be the SAME device array the call receives as that input
+ *     (for EGS_SINK_OPACITY: the array the forward received as `opacities`; the backward itself reads the activated value from the
+ *     geometry buffer).  It is updated IN PLACE after its last read; exp_avg / exp_avg_sq have its shape, lr / step are device float[1]:
+ *     torch's state["step"], advanced by one per call.  param == NULL: that leaf is not fused.
+ *   - The dL_d* output of a fused leaf may be NULL (nothing written); if given, the gradient is written as well.
+ *   - Conditions (else EGS_ERR_MODE): EGS_SINK_SCALES / EGS_SINK_ROTATIONS need scales + rotations (not cov3D_precomp);
+ *     EGS_SINK_SH needs `shs` with sh_coeffs == 1 and no shs_rest; EGS_SINK_MEANS3D needs `colors_precomp` or such an `shs`
+ *     (with more coefficients the view-direction term reaches dL_dmeans3D in a later launch).
+ *   - skip_flag set: no step is taken and none is counted.  active_rows: rows >= *active_rows are left alone (capacity-sized
+ *     models), as in egs_adam_step_capturable.
+ *   - coef: device float[2 * EGS_SINK_LEAVES] scratch owned by the caller, written and read by this call only. */
+#define EGS_SINK_MEANS3D   0    /* [P,3] */
+#define EGS_SINK_OPACITY   1    /* [P,1] */
+#define EGS_SINK_SCALES    2    /* [P,3] */
+#define EGS_SINK_ROTATIONS 3    /* [P,4] */
+#define EGS_SINK_SH        4    /* [P,1,3] */
+typedef struct egs_adam_leaf {
+    float* param; float* exp_avg; float* exp_avg_sq;
+    const float* lr;     /* device float[1] */
+    float* step;         /* device float[1], in/out */
+} egs_adam_leaf;
+typedef struct egs_adam_sink {
+    egs_adam_leaf leaf[5];       /* indexed by EGS_SINK_* */
+    float beta1, beta2, eps;
+    float* coef;                 /* device float[10] scratch */
+    const int32_t* active_rows;  /* device int32[1] or NULL */
+} egs_adam_sink;
+int egs_backward_adam(
+    int P, int sh_degree, int sh_coeffs, int64_t R,
+    const float* background, const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    int width, int height, float tan_fovx, float tan_fovy,
+    const int32_t* radii, const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+    const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha,
+    float* dL_dmeans2D, float* dL_dcolors /*may be NULL with shs*/, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+    float* dL_dsh_rest, float* dL_dscales, float* dL_drotations,
+    float* stat_grad_accum, float* stat_denom, float* stat_max_radii, const uint32_t* skip_flag,
+    const egs_adam_sink* sink /*HOST; NULL = egs_backward*/, void* scratch, void* stream, int debug);
+
 /* ---- frustum test only  (upstream: markVisible) -------------------------------------------------- */
 int egs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present /*[P] out, 0/1*/, void* stream);

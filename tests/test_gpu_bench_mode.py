@@ -46,7 +46,17 @@ def test_config_C_bench_mode_vs_oracle():
     assert pc.get_raw_parameters() is not None and _C.set_tile_culling(True) in (True, False)      # the benched mode: raw parameters, culling on
     opt = FusedAdam([{"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3}, {"params": [pc._opacity], "lr": 0.05},
                      {"params": [pc._scaling], "lr": 5e-3}, {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15, capturable=True)
+    # the benched step takes the Adam step of all five parameters inside the rasterizer backward and writes no gradient arrays;
+    # here the same kernel writes them as well (AdamSink.keep_grads), so that they can be compared
+    make_sink = opt.make_sink
+
+    def keeping(**kw):
+        sink = make_sink(**kw)
+        sink.keep_grads = True
+        return sink
+    opt.make_sink = keeping
     step = GraphedTrainStep(pc, opt, bg, 0.2).capture(cams[0], gts[0], warmup=2)
+    assert step.fuse_optimizer
     params = dict(xyz=pc._xyz, f_dc=pc._features_dc, opacity=pc._opacity, scaling=pc._scaling, rotation=pc._rotation)
     before = {k: v.detach().cpu().clone() for k, v in params.items()}          # the model the replayed step renders
     step(pack_frame(cams[1], gts[1]))                                          # ONE replay on another frame

@@ -1,0 +1,219 @@
+"""GPU: the optimizer inside the rasterizer backward (include/egs_raster.h egs_backward_adam, optim.FusedAdam.make_sink).
+
+What it replaces in the reference: loss.backward() hands per-parameter gradients to autograd and optimizer.step() reads them back
+(/root/reference/trainers/train_static.py:97,137; torch.optim.Adam(l, lr=0.0, eps=1e-15), scene/gaussian_model.py:180-198).
+The fused path must take exactly the step the stand-alone kernel takes from the same gradients -- checked bit for bit, with the
+gradients of the owned leaves written as well (the C ABI allows both) so that the stand-alone step can be replayed on copies."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LEAVES = ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation")
+
+
+def _groups(pc):
+    return [{"params": [pc._xyz], "lr": 1.6e-4, "name": "xyz"}, {"params": [pc._features_dc], "lr": 2.5e-3, "name": "f_dc"},
+            {"params": [pc._opacity], "lr": 0.05, "name": "opacity"}, {"params": [pc._scaling], "lr": 5e-3, "name": "scaling"},
+            {"params": [pc._rotation], "lr": 1e-3, "name": "rotation"}]
+
+
+def _scene(N=12000, H=96, W=160, seed=0):
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    teacher = make_scene(N, H, W, seed); teacher["log_scale"] += math.log(2.0)
+    cams = [make_camera(k, H, W, device=DEV) for k in (0, 40, 80, 120)]
+    bg = torch.zeros(3, device=DEV)
+    with torch.no_grad():
+        tpc = SynthGaussians(teacher, device=DEV, requires_grad=False)
+        gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
+    return perturb_student(teacher), cams, gts, bg
+
+
+def test_fused_step_is_the_standalone_step_bit_for_bit():
+    """Four iterations; in each the backward steps the five leaves itself AND writes their gradients; a twin optimizer on copies of
+    (parameter, exp_avg, exp_avg_sq) taken before the backward steps with those gradients through the stand-alone kernel: parameters,
+    both moments and state["step"] must be equal bit for bit.  The fifth iteration goes the other way round -- the optimizer that was
+    fused so far takes a stand-alone step (its own step counters are re-seeded from state["step"]) -- and must again agree."""
+    from egogaussian_amd.scene_synth import SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.fused import l1_ssim_loss
+    from egogaussian_amd.optim import FusedAdam
+    import egogaussian_amd.optim as optim
+    student, cams, gts, bg = _scene()
+    pa = SynthGaussians(student, device=DEV)
+    oa = FusedAdam(_groups(pa), lr=0.0, eps=1e-15, capturable=True)
+    pb = SynthGaussians(student, device=DEV)
+    ob = FusedAdam(_groups(pb), lr=0.0, eps=1e-15, capturable=True)
+    real_make = oa.make_sink
+
+    def keeping(**kw):
+        sink = real_make(**kw)
+        sink.keep_grads = True
+        keeping.last = sink
+        return sink
+    oa.make_sink = keeping
+    for it in range(5):
+        k = it % 4
+        fused = it < 4
+        for a in LEAVES:                                            # the twin starts every iteration from the same bits
+            with torch.no_grad():
+                getattr(pb, a).copy_(getattr(pa, a))
+        out = render(cams[k], pa, Pipe, bg, optimizer=oa if fused else None)
+        loss = l1_ssim_loss(out["render"], gts[k], 0.2)
+        # capture the gradients the backward writes: hook on the rasterizer's Function is not needed -- with keep_grads the
+        # backward returns them to autograd as usual AND has already stepped the leaves
+        before = {a: getattr(pa, a).detach().clone() for a in LEAVES}
+        loss.backward()
+        if fused:
+            assert keeping.last.owned == {0, 1, 2, 3, 4}
+            for a in LEAVES:
+                g = getattr(pa, a).grad
+                assert g is not None and float(g.abs().max()) > 0            # (keep_grads) the gradient arrays were written too
+                assert not torch.equal(before[a], getattr(pa, a).detach()), f"{a}: the backward did not step it"
+                getattr(pb, a).grad = g.clone()
+            oa.step()                                                # the gradients are there (keep_grads), yet nothing may be stepped twice
+            oa.zero_grad(set_to_none=True)
+        else:
+            for a in LEAVES:
+                getattr(pb, a).grad = getattr(pa, a).grad.clone()
+            oa.step(); oa.zero_grad(set_to_none=True)
+        ob.step(); ob.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        for a in LEAVES:
+            x, y = getattr(pa, a), getattr(pb, a)
+            assert torch.equal(x.detach(), y.detach()), f"iteration {it}: {a} differs"
+            for key in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(oa.state[x][key], ob.state[y][key]), f"iteration {it}: {a} {key} differs"
+            assert float(oa.state[x]["step"]) == float(ob.state[y]["step"]) == it + 1
+
+
+def test_fused_leaves_have_no_gradient_arrays_and_step_once():
+    """Default use (no keep_grads): the owned leaves end the backward with .grad None, took exactly one step, and the screen-space
+    gradient (densification statistic input) is still delivered."""
+    from egogaussian_amd.scene_synth import SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.fused import l1_ssim_loss
+    from egogaussian_amd.optim import FusedAdam
+    student, cams, gts, bg = _scene(N=6000)
+    pc = SynthGaussians(student, device=DEV)
+    opt = FusedAdam(_groups(pc), lr=0.0, eps=1e-15, capturable=True)
+    before = {a: getattr(pc, a).detach().clone() for a in LEAVES}
+    out = render(cams[0], pc, Pipe, bg, optimizer=opt)
+    l1_ssim_loss(out["render"], gts[0], 0.2).backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert out["viewspace_points"].grad is not None and float(out["viewspace_points"].grad.abs().max()) > 0
+    for a in LEAVES:
+        p = getattr(pc, a)
+        assert p.grad is None and float(opt.state[p]["step"]) == 1.0
+        moved = (p.detach() != before[a]).any(dim=tuple(range(1, p.dim())))
+        assert bool(moved[out["visibility_filter"]].any())
+    # an evaluation render under no_grad builds no sink and steps nothing
+    snap = pc._xyz.detach().clone()
+    with torch.no_grad():
+        render(cams[1], pc, Pipe, bg, optimizer=opt)
+    torch.cuda.synchronize()
+    assert torch.equal(snap, pc._xyz.detach()) and float(opt.state[pc._xyz]["step"]) == 1.0
+
+
+def test_graph_step_with_and_without_fused_optimizer_agree():
+    """GraphedTrainStep(fuse_optimizer=True / False) on the same frames: same parameters up to the order of the backward's float
+    atomics (the tolerance the eager-vs-graph tests use), same step counts; the fused graph has no gradient arrays for the leaves."""
+    from egogaussian_amd.scene_synth import SynthGaussians
+    from egogaussian_amd.optim import FusedAdam
+    from egogaussian_amd.graph import GraphedTrainStep
+    student, cams, gts, bg = _scene(N=15000)
+    res = []
+    for fuse in (False, True):
+        pc = SynthGaussians(student, device=DEV)
+        opt = FusedAdam(_groups(pc), lr=0.0, eps=1e-15, capturable=True)
+        step = GraphedTrainStep(pc, opt, bg, 0.2, fuse_optimizer=fuse, densify_stats=False).capture(cams[0], gts[0], warmup=2)
+        for i in range(1, 9):
+            step(cams[i % 4], gts[i % 4])
+        torch.cuda.synchronize()
+        assert step.ok()
+        for a in LEAVES:
+            assert float(opt.state[getattr(pc, a)]["step"]) == 10.0
+            assert (getattr(pc, a).grad is None) == fuse
+        res.append(pc)
+    for a in LEAVES:
+        x, y = getattr(res[0], a).detach(), getattr(res[1], a).detach()
+        diff = (x - y).abs()
+        assert float((diff > 2e-5 * float(x.abs().max()) + 1e-6).float().mean()) < 2e-3 and float(diff.max()) < 0.02, a
+
+
+def test_partial_sinks_follow_the_library_conditions():
+    """cov3D_precomp given (the `fine_all` call shape): scaling / rotation / opacity reach the rasterizer as activations, so only xyz
+    and features_dc are owned and the other three are stepped by optimizer.step() from their gradient arrays; colours precomputed:
+    only xyz can be owned."""
+    from egogaussian_amd.scene_synth import SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.fused import l1_ssim_loss
+    from egogaussian_amd.optim import FusedAdam
+    import egogaussian_amd.lib as lib
+    student, cams, gts, bg = _scene(N=6000)
+    pc = SynthGaussians(student, device=DEV)
+    pc._is_object = (torch.rand(6000, 1, generator=torch.Generator().manual_seed(3)) < 0.3).float().to(DEV)
+    opt = FusedAdam(_groups(pc), lr=0.0, eps=1e-15, capturable=True)
+    seen = []
+    real = opt.make_sink
+    opt.make_sink = lambda **kw: seen.append(real(**kw)) or seen[-1]
+    out = render(cams[0], pc, Pipe, bg, rot_cov=True, accum_R=torch.eye(3, device=DEV), which_object=1, during_training=False, optimizer=opt)
+    l1_ssim_loss(out["render"], gts[0], 0.2).backward()
+    opt.step(); opt.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    assert seen[-1].owned == {lib.SINK_MEANS3D, lib.SINK_SH}
+    for a in LEAVES:
+        assert float(opt.state[getattr(pc, a)]["step"]) == 1.0, a
+    out = render(cams[1], pc, Pipe, bg, override_color=torch.rand(pc.get_xyz.shape[0], 3, device=DEV), optimizer=opt)
+    l1_ssim_loss(out["render"], gts[1], 0.2).backward()
+    opt.step(); opt.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    assert lib.SINK_SH not in seen[-1].owned and lib.SINK_MEANS3D in seen[-1].owned
+    assert float(opt.state[pc._xyz]["step"]) == 2.0 and float(opt.state[pc._features_dc]["step"]) == 1.0
+
+
+def test_c_abi_rejects_inconsistent_sinks():
+    """egs_backward_adam argument checking: a leaf whose `param` is not the array passed as that input, a scales leaf together with
+    cov3D_precomp, a missing moment array."""
+    import ctypes as C
+    import egogaussian_amd.lib as lib
+    L = lib.load()
+    P, H, W = 64, 32, 32
+    z = lambda *s: torch.zeros(s, device=DEV)
+    vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    means, sh, scales, rots, cov = z(P, 3), z(P, 1, 3), z(P, 3), z(P, 4), z(P, 6)
+    m, v, lr, st, coef = z(P, 3), z(P, 3), z(1), z(1), z(10)
+    radii = torch.zeros(P, dtype=torch.int32, device=DEV)
+    geom = torch.zeros(L.egs_geom_bytes(P), dtype=torch.uint8, device=DEV)
+    img = torch.zeros(L.egs_image_bytes(W, H), dtype=torch.uint8, device=DEV)
+    scratch = torch.zeros(L.egs_backward_scratch_bytes(P), dtype=torch.uint8, device=DEV)
+    cam = z(16); pos = z(3); bg = z(3); gcol = z(3, H, W)
+
+    def call(sink, use_cov=False, scales_in=scales):
+        return L.egs_backward_adam(P, 0, 1, 0, vp(bg), vp(means), vp(sh), None, None, None if use_cov else vp(scales_in), 1.0,
+                                   None if use_cov else vp(rots), vp(cov) if use_cov else None, 0, vp(cam), vp(cam), vp(pos), W, H, 1.0, 1.0,
+                                   vp(radii), vp(geom), None, vp(img), vp(gcol), None, None, vp(z(P, 3)), vp(z(P, 3)), vp(z(P, 1)), vp(z(P, 3)),
+                                   vp(z(P, 6)) if use_cov else None, vp(z(P, 1, 3)), None, None if use_cov else vp(z(P, 3)),
+                                   None if use_cov else vp(z(P, 4)), None, None, None, None, C.byref(sink), vp(scratch), None, 0)
+
+    def sink_for(leaf, param, moments=True):
+        s = lib.AdamSink()
+        f = s.leaf[leaf]
+        f.param, f.lr, f.step = param.data_ptr(), lr.data_ptr(), st.data_ptr()
+        if moments:
+            f.exp_avg, f.exp_avg_sq = m.data_ptr(), v.data_ptr()
+        s.beta1, s.beta2, s.eps, s.coef = 0.9, 0.999, 1e-15, coef.data_ptr()
+        return s
+    ERR_ARG, ERR_MODE = -1, -2
+    assert call(sink_for(lib.SINK_SCALES, scales)) == 0                              # R = 0: nothing rendered, a plain zero-gradient step
+    torch.cuda.synchronize()
+    assert float(st) == 1.0
+    assert call(sink_for(lib.SINK_SCALES, z(P, 3))) == ERR_ARG                       # not the array passed as `scales`
+    assert call(sink_for(lib.SINK_SCALES, scales), use_cov=True) == ERR_MODE
+    assert call(sink_for(lib.SINK_MEANS3D, means, moments=False)) == ERR_ARG
+    s = sink_for(lib.SINK_MEANS3D, means); s.coef = None
+    assert call(s) == ERR_ARG

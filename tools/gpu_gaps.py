@@ -1,20 +1,20 @@
 #!/usr/bin/env python
 """Idle gaps of the GPU between consecutive kernels, from a rocprofv3 --kernel-trace database: which kernel the GPU waited for,
-how long, per training step (a step = one k_adam launch).   python tools/gpu_gaps.py results.db"""
+how long, per training step (a step = one k_render_backward launch).   python tools/gpu_gaps.py results.db"""
 import collections, sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
 ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 rows = c.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
-adam = [k for k, r in enumerate(rows) if "k_adam" in r[0]]
+adam = [k for k, r in enumerate(rows) if "k_render_backward" in r[0]]
 rows = rows[adam[len(adam) // 4]:adam[3 * len(adam) // 4] + 1]       # the steady middle half of the training steps
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:44]
 gap_by, busy, steps = collections.defaultdict(float), 0.0, 0
 for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
     busy += (e0 - s0)
     gap_by[short(n1)] += max(0, s1 - e0)
-    steps += "k_adam" in n1
+    steps += "k_render_backward" in n1
 wall = rows[-1][2] - rows[0][1]
 print(f"{steps} steps; per step: wall {wall / steps / 1e3:.1f} us, kernels busy {busy / steps / 1e3:.1f} us, idle {(wall - busy) / steps / 1e3:.1f} us")
 for n, g in sorted(gap_by.items(), key=lambda kv: -kv[1])[:12]:
