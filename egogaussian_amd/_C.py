@@ -190,14 +190,17 @@ def visible_view(geom, P):
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alpha,
-                                 debug, activation_flags=0, sh_rest=None, densify_stats=None, guard=None, sink=None):
+                                 debug, activation_flags=0, sh_rest=None, densify_stats=None, guard=None, sink=None,
+                                 prologue_scratch=None):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
            dL_dscales[P,3], dL_drotations[P,4]); with sh_rest, dL_dsh is [P,1,3] and a ninth element dL_dsh_rest[P,M-1,3] follows.
     densify_stats (extension): (xyz_gradient_accum[P,1], denom[P,1], max_radii2D[P] or None), float32, updated in place by the kernel
     that produces dL_dmeans2D (include/egs_raster.h) -- the caller then skips its add_densification_stats for this iteration.
     guard (extension): the StepGuard of the forward; the statistics are left untouched when its overflow word is set.
     sink (extension): an optim.AdamSink -- the leaves it owns take their Adam step inside this backward (include/egs_raster.h,
-    egs_backward_adam); their gradients are not produced: those positions of the result are None."""
+    egs_backward_adam); their gradients are not produced: those positions of the result are None.
+    prologue_scratch (extension): the scratch buffer a preceding egs_l1_ssim_backward_ex prepared for THIS backward (tile order,
+    cleared accumulator, optimizer bookkeeping: fused.l1_ssim_loss(raster_prologue=True)); the backward then starts at its blend kernel."""
     L = _lib.load()
     means3D = _f32c(means3D, "means3D")
     dev = means3D.device
@@ -228,8 +231,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dsh_rest = e(*sh_rest.shape) if sh_rest is not None else None
         dscales = None if fused(_lib.SINK_SCALES) else (e(P, 3) if own_cov else e(0, 3))   # absent inputs get empty gradients (the autograd Function maps them to None)
         drots = None if fused(_lib.SINK_ROTATIONS) else (e(P, 4) if own_cov else e(0, 4))
-        if P != 0 and owned:
-            scratch = torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
+        if P != 0 and (owned or prologue_scratch is not None):
+            scratch = prologue_scratch if prologue_scratch is not None else torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
             _lib.check(L.egs_backward_adam(
                 P, int(degree), M, int(R), _ptr(background), _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors), _ptr(scales),
                 float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
@@ -237,8 +240,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(imageBuffer), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(dmeans2D), _ptr(dcolors),
                 _ptr(dopacity), _ptr(dmeans3D), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
                 _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
-                C.byref(sink.struct), _ptr(scratch), _stream(), int(bool(debug))))
-            sink.mark_stepped()
+                C.byref(sink.struct) if owned else None, 1 if prologue_scratch is not None else 0, _ptr(scratch), _stream(), int(bool(debug))))
+            if owned:
+                sink.mark_stepped()
         elif P != 0:
             scratch = torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
             _lib.check(L.egs_backward(

@@ -3,6 +3,7 @@
 // Replaces the pybind `_C` entry points of the upstream extension bound at
 // /root/reference/gaussian_renderer/__init__.py:14.
 #include "egs_common.h"
+#include "backward_prologue.h"
 #include <string.h>
 #include <vector>
 
@@ -353,6 +354,17 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
     return 0;
 }
 
+// egs_adam_sink (HOST struct of the C ABI) -> what the kernels take by value
+static void sink_to_kernel_args(const egs_adam_sink* sink, const uint32_t* skip_flag, EgsSink& ks, EgsAdamTick& tick) {
+    for (int l = 0; l < EGS_SINK_LEAVES; l++) {
+        if (!sink->leaf[l].param) continue;
+        ks.leaf[l].p = sink->leaf[l].param; ks.leaf[l].m = sink->leaf[l].exp_avg; ks.leaf[l].v = sink->leaf[l].exp_avg_sq;
+        tick.step[l] = sink->leaf[l].step; tick.lr[l] = sink->leaf[l].lr;
+    }
+    ks.coef = sink->coef; ks.active_rows = sink->active_rows; ks.skip = skip_flag; ks.b1 = sink->beta1; ks.b2 = sink->beta2; ks.eps = sink->eps;
+    tick.coef = sink->coef; tick.skip = skip_flag; tick.b1 = sink->beta1; tick.b2 = sink->beta2;
+}
+
 static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const float* background, const float* means3D,
                  const float* shs, const float* shs_rest, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix,
@@ -361,7 +373,7 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
                  const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
                  float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
                  float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
-                 const uint32_t* skip_flag, const egs_adam_sink* sink, void* scratch, void* stream, int debug) {
+                 const uint32_t* skip_flag, const egs_adam_sink* sink, int prologue_done, void* scratch, void* stream, int debug) {
     int rc = check_dims(P, width, height); if (rc) return rc;
     if (P == 0) return 0;
     if (R < 0 || R >= (1ll << 31)) return EGS_ERR_RANGE;
@@ -401,17 +413,9 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
     EgsImgPtrs im = img_ptrs(const_cast<void*>(image_buffer), width, height);
     float* grad_acc = (float*)scratch;
     EgsSink ks = {}; EgsAdamTick tick = {};
-    if (sink) {
-        for (int l = 0; l < EGS_SINK_LEAVES; l++) {
-            if (!own[l]) continue;
-            ks.leaf[l].p = sink->leaf[l].param; ks.leaf[l].m = sink->leaf[l].exp_avg; ks.leaf[l].v = sink->leaf[l].exp_avg_sq;
-            tick.step[l] = sink->leaf[l].step; tick.lr[l] = sink->leaf[l].lr;
-        }
-        ks.coef = sink->coef; ks.active_rows = sink->active_rows; ks.skip = skip_flag; ks.b1 = sink->beta1; ks.b2 = sink->beta2; ks.eps = sink->eps;
-        tick.coef = sink->coef; tick.skip = skip_flag; tick.b1 = sink->beta1; tick.b2 = sink->beta2;
-    }
+    if (sink) sink_to_kernel_args(sink, skip_flag, ks, tick);
     // the accumulator is cleared by a kernel, not a memset node (see egs_launch_zero_f4): fused into the blend's prologue
-    if (R == 0) {
+    if (R == 0 && !prologue_done) {
         EGS_TRY(egs_launch_zero_f4((float4*)grad_acc, (size_t)P * EGS_GRAD_STRIDE / 4, s));
         if (sink) EGS_TRY(egs_launch_adam_tick(tick, s));
     }
@@ -419,7 +423,7 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
         const uint32_t* point_list = b.point_list;
         egs_prof_start(EGS_K_RENDER_BWD, s);
         EGS_TRY(egs_launch_render_backward(width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth,
-                                           dL_dout_alpha, grad_acc, (size_t)P * EGS_GRAD_STRIDE, sink ? &tick : nullptr, s));
+                                           dL_dout_alpha, grad_acc, (size_t)P * EGS_GRAD_STRIDE, sink ? &tick : nullptr, prologue_done, s));
         egs_prof_stop(EGS_K_RENDER_BWD, s);
         EGS_SYNC_IF_DEBUG(s);
     }
@@ -450,7 +454,7 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
                          cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, geom_buffer,
                          binning_buffer, image_buffer, dL_dout_color, dL_dout_depth, dL_dout_alpha, dL_dmeans2D, dL_dcolors, dL_dopacity,
                          dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscales, dL_drotations, stat_grad_accum, stat_denom, stat_max_radii,
-                         skip_flag, nullptr, scratch, stream, debug);
+                         skip_flag, nullptr, 0, scratch, stream, debug);
 }
 
 int egs_backward_adam(int P, int sh_degree, int sh_coeffs, int64_t R, const float* background, const float* means3D,
@@ -461,12 +465,35 @@ int egs_backward_adam(int P, int sh_degree, int sh_coeffs, int64_t R, const floa
                       const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
                       float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
                       float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
-                      const uint32_t* skip_flag, const egs_adam_sink* sink, void* scratch, void* stream, int debug) {
+                      const uint32_t* skip_flag, const egs_adam_sink* sink, int prologue_done, void* scratch, void* stream, int debug) {
     return backward_impl(P, sh_degree, sh_coeffs, R, background, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations,
                          cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, geom_buffer,
                          binning_buffer, image_buffer, dL_dout_color, dL_dout_depth, dL_dout_alpha, dL_dmeans2D, dL_dcolors, dL_dopacity,
                          dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscales, dL_drotations, stat_grad_accum, stat_denom, stat_max_radii,
-                         skip_flag, sink, scratch, stream, debug);
+                         skip_flag, sink, prologue_done, scratch, stream, debug);
+}
+
+int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
+                            const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
+                            const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
+                            float* loss_running_sum, const egs_backward_prologue* side, void* stream) {
+    if (!side)
+        return egs_launch_l1_ssim_backward(channels, height, width, img, gt, lambda_dssim, upstream_grad, gate, dm_dmu1, dm_dexx, dm_dexy, dL_dimg,
+                                           deferred_partial_sums, deferred_loss, loss_running_sum, nullptr, (hipStream_t)stream);
+    int rc = check_dims(side->P, side->width, side->height); if (rc) return rc;
+    if (side->P <= 0 || !side->image_buffer || !side->scratch) return EGS_ERR_ARG;
+    EgsImgPtrs im = img_ptrs(side->image_buffer, side->width, side->height);
+    EgsPrologueArgs pa = {};
+    pa.n_tiles = ((side->width + EGS_TILE - 1) / EGS_TILE) * ((side->height + EGS_TILE - 1) / EGS_TILE);
+    pa.quad_work = im.quad_work; pa.tile_order = im.tile_order; pa.acc4 = (float4*)side->scratch; pa.n4 = (size_t)side->P * EGS_GRAD_STRIDE / 4;
+    if (side->sink) {
+        if (!side->sink->coef) return EGS_ERR_ARG;
+        EgsSink ks = {};
+        sink_to_kernel_args(side->sink, side->skip_flag, ks, pa.tick);
+        pa.has_tick = 1;
+    }
+    return egs_launch_l1_ssim_backward(channels, height, width, img, gt, lambda_dssim, upstream_grad, gate, dm_dmu1, dm_dexx, dm_dexy, dL_dimg,
+                                       deferred_partial_sums, deferred_loss, loss_running_sum, &pa, (hipStream_t)stream);
 }
 
 int egs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

@@ -144,7 +144,8 @@ hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs 
 // `tick` (may be NULL): the per-step bookkeeping of an optimizer fused into this backward, done by one thread of the prologue launch
 hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
-                                      const float* dL_dalpha, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick, hipStream_t s);
+                                      const float* dL_dalpha, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick,
+                                      int prologue_done /*the tile order, the cleared accumulator and the tick are in place already*/, hipStream_t s);
 hipError_t egs_launch_adam_tick(const EgsAdamTick& tick, hipStream_t s);       // the same bookkeeping as a launch of its own (frames with no instance)
 
 // Zero-fill by a kernel.  hipMemsetAsync is avoided inside the per-step chain: captured into a hipGraph it becomes a memset

@@ -10,6 +10,7 @@
 // and adds the L1 term and the optional per-pixel gradient gate.  8 B in + 12 B out per pixel-channel forward,
 // 20 B in + 4 B out backward (+ 10/SR halo rows and 10/54 halo columns re-read).
 #include "egs_common.h"
+#include "backward_prologue.h"
 
 // Mapping (wave64 streaming, no workgroup barriers): a wave owns a strip of SW = 54 output columns x SR output rows of
 // one channel.  Lane L is image column  strip_x0 - 5 + L  (5 halo columns each side) and walks DOWN the rows:
@@ -221,18 +222,31 @@ __device__ __forceinline__ void wave_finish_loss(size_t nblocks, const float* __
     }
 }
 
+// SIDE: the launch also carries the jobs that prepare the rasterizer's backward blend of the same frame (backward_prologue.h) in
+// its first `side_jobs` workgroups -- tile ordering on one CU per XCD, the fused optimizer's bookkeeping, clearing the gradient
+// accumulator.  They have nothing to do with the loss; they ride here because this launch sits between the two blends of a training
+// step and leaves most of the machine's issue slots and all of its HBM bandwidth unused, while a launch of their own costs 12 us.
+// grid: 1-D = side jobs, then per channel plane ceil(strips / WPB) strip workgroups (+ 1 for the deferred loss value)
+template <bool SIDE>
 __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_backward(int H, int W, int strips_x, int strips_y, const float* __restrict__ img,
                                                                 const float* __restrict__ gt, float w_l1, float w_ssim,
                                                                 const float* __restrict__ upstream, const float* __restrict__ gate,
                                                                 const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dexx,
                                                                 const float* __restrict__ dm_dexy, float* __restrict__ dimg,
                                                                 const float* __restrict__ fin_partial, size_t fin_n, float fin_lambda,
-                                                                float* __restrict__ fin_loss, float* __restrict__ fin_running) {
+                                                                float* __restrict__ fin_loss, float* __restrict__ fin_running,
+                                                                unsigned per_plane, unsigned side_jobs, EgsPrologueArgs side) {
     __shared__ float lds[WPB][3 * 80];
+    if (SIDE) {
+        __shared__ EgsOrderLds order_lds;
+        if (blockIdx.x < side_jobs) { egs_prologue_job<64 * WPB>(side, blockIdx.x, side_jobs, order_lds); return; }
+    }
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int strip = blockIdx.x * WPB + (int)wv;
-    if (fin_partial && blockIdx.x == gridDim.x - 1) {                  // deferred loss value: one extra workgroup per channel plane, no strip
-        if (blockIdx.z == 0 && wv == 0) wave_finish_loss(fin_n, fin_partial, w_l1, w_ssim, fin_lambda, fin_loss, fin_running, lane);
+    const unsigned rel = blockIdx.x - (SIDE ? side_jobs : 0u);
+    const unsigned plane_z = rel / per_plane, bx = rel - plane_z * per_plane;
+    const int strip = (int)bx * WPB + (int)wv;
+    if (fin_partial && bx == per_plane - 1) {                          // deferred loss value: one extra workgroup per channel plane, no strip
+        if (plane_z == 0 && wv == 0) wave_finish_loss(fin_n, fin_partial, w_l1, w_ssim, fin_lambda, fin_loss, fin_running, lane);
         return;                                                        // (every resident wave ends with the kernel: a wave with a strip has no slack)
     }
     if (strip >= strips_x * strips_y) return;
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_backward(int H, int W, int
     __builtin_amdgcn_wave_barrier();
     BwdCtx c;
     c.H = H; c.W = W; c.lane = lane; c.img = img; c.gt = gt; c.m0 = dm_dmu1; c.m1 = dm_dexx; c.m2 = dm_dexy; c.gate = gate; c.dimg = dimg;
-    c.rows = lds[wv]; c.plane = (size_t)blockIdx.z * H * W; c.w_l1 = w_l1; c.w_ssim = w_ssim; c.up = upstream[0];
+    c.rows = lds[wv]; c.plane = (size_t)plane_z * H * W; c.w_l1 = w_l1; c.w_ssim = w_ssim; c.up = upstream[0];
     const int sx = strip % strips_x, sy = strip / strips_x;
     c.gx = sx * SW - HALO + (int)lane;
     c.col_ok = c.gx >= 0 && c.gx < W;
@@ -297,6 +311,26 @@ __global__ __launch_bounds__(1024) void k_l1_ssim_finish(size_t nblocks, const f
 
 }  // namespace
 
+int egs_launch_l1_ssim_backward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
+                                const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
+                                const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
+                                float* loss_running_sum, const EgsPrologueArgs* side, hipStream_t stream) {
+    if (channels <= 0 || height <= 0 || width <= 0 || !img || !gt || !upstream_grad || !dm_dmu1 || !dm_dexx || !dm_dexy || !dL_dimg)
+        return EGS_ERR_ARG;
+    const float n = (float)channels * (float)height * (float)width;
+    const int strips_x = (width + SW - 1) / SW, strips_y = (height + SR - 1) / SR;
+    const unsigned per_plane = (unsigned)((strips_x * strips_y + WPB - 1) / WPB + (deferred_partial_sums ? 1 : 0));
+    const unsigned side_jobs = side ? egs_prologue_jobs(side->n4, side->has_tick, 64 * WPB) : 0u;
+    EgsPrologueArgs none = {};
+#define LB_ARGS height, width, strips_x, strips_y, img, gt, (1.f - lambda_dssim) / n, lambda_dssim / n, upstream_grad, gate, dm_dmu1, dm_dexx, \
+                dm_dexy, dL_dimg, deferred_partial_sums, (size_t)strips_x * strips_y * channels, lambda_dssim, deferred_loss,            \
+                deferred_partial_sums ? loss_running_sum : nullptr, per_plane, side_jobs
+    if (side) hipLaunchKernelGGL(k_l1_ssim_backward<true>, dim3(side_jobs + per_plane * (unsigned)channels), dim3(64 * WPB), 0, stream, LB_ARGS, *side);
+    else hipLaunchKernelGGL(k_l1_ssim_backward<false>, dim3(per_plane * (unsigned)channels), dim3(64 * WPB), 0, stream, LB_ARGS, none);
+#undef LB_ARGS
+    return (int)hipGetLastError();
+}
+
 extern "C" {
 
 size_t egs_l1_ssim_partial_count(int channels, int height, int width) {
@@ -323,16 +357,8 @@ int egs_l1_ssim_backward(int channels, int height, int width, const float* img, 
                          const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
                          const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
                          float* loss_running_sum, void* stream) {
-    if (channels <= 0 || height <= 0 || width <= 0 || !img || !gt || !upstream_grad || !dm_dmu1 || !dm_dexx || !dm_dexy || !dL_dimg)
-        return EGS_ERR_ARG;
-    const float n = (float)channels * (float)height * (float)width;
-    const int strips_x = (width + SW - 1) / SW, strips_y = (height + SR - 1) / SR;
-    dim3 grid((strips_x * strips_y + WPB - 1) / WPB + (deferred_partial_sums ? 1 : 0), 1, channels);
-    hipLaunchKernelGGL(k_l1_ssim_backward, grid, dim3(64 * WPB), 0, (hipStream_t)stream, height, width, strips_x, strips_y, img, gt,
-                       (1.f - lambda_dssim) / n, lambda_dssim / n, upstream_grad, gate, dm_dmu1, dm_dexx, dm_dexy, dL_dimg,
-                       deferred_partial_sums, (size_t)strips_x * strips_y * channels, lambda_dssim, deferred_loss,
-                       deferred_partial_sums ? loss_running_sum : nullptr);
-    return (int)hipGetLastError();
+    return egs_launch_l1_ssim_backward(channels, height, width, img, gt, lambda_dssim, upstream_grad, gate, dm_dmu1, dm_dexx, dm_dexy, dL_dimg,
+                                       deferred_partial_sums, deferred_loss, loss_running_sum, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

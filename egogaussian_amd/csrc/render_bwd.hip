@@ -21,6 +21,7 @@
 //     (egs_common.h) instead of ten.
 #include "egs_common.h"
 #include "blend_common.h"
+#include "backward_prologue.h"
 #include <algorithm>
 
 namespace {
@@ -50,146 +51,9 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
-// Work-aware placement of tiles for the backward blend.  All workgroups of that launch are resident at once (8 per CU),
-// so its duration is the busiest CU's total; with tiles dealt in index order the busiest CU carries 1.2-1.3x the mean.
-// Workgroup b runs on XCD b % 8 and, inside the XCD, on CU (b / 8) % 32 (tools/ubench/dispatch_map.hip; used for speed
-// only -- any placement gives the same results).  One workgroup per XCD band ranks the band's tiles by the cost the forward
-// recorded -- a counting sort over 1024 cost levels, O(tiles): the exact O(tiles^2) rank it replaces took 45 us at 1920x1080 --
-// and deals them to the 32 CUs in snake order (rank r -> round r/32, CU r%32 or 31 - r%32).
-// The same launch clears the gradient accumulator (workgroups 8..): two short kernels cost more than one.
-// Tried and rejected (round 1, config C, per-wave timelines from tools/lane_use.py): (a) persistent waves pulling
-// (tile, quadrant) tasks, sorted by cost, from one queue per XCD: perfectly balanced and 2.2x slower -- the four waves
-// of a workgroup then work on unrelated tiles and stop sharing list and record lines in the CU's L1; (b) dealing each
-// tile's quadrants to the CU's SIMDs by cost (a wave reads its SIMD from HW_ID): per-SIMD spread +-16% -> +-10%, but the
-// CU-level spread (-12%/+8% of blended splats) then bounds the launch and the longer prologue cancels the 2 us gained.
-// (c) running this prologue on a second stream right after the forward, so that it overlaps the loss kernels (fork / join
-// captured into the hipGraph): the step got 3 % SLOWER -- the graph's cross-stream dependencies cost more than the 11 us hidden.
-#define ORDER_MAX_BAND 8192
-#define ORDER_LEVELS 1024
-#define ORDER_BALANCE_MAX 256               // band size up to which every workgroup of the launch is resident at once (8 per CU x 32 CUs)
-#define EGS_ORDER_HAS_PERM 0x01000000u      // tile_order word: bits 0-15 tile, 16-23 quadrant for the wave on SIMD 0..3 (two bits each), 24 = those are set
-__global__ __launch_bounds__(1024) void k_backward_prologue(int n_tiles, const uint32_t* __restrict__ quad_work,
-                                                             uint32_t* __restrict__ tile_order, float4* __restrict__ acc4, size_t n4,
-                                                             int has_tick, EgsAdamTick tick) {
-    if (blockIdx.x >= EGS_XCDS) {
-        // an optimizer fused into this backward (egs_backward_adam): its once-per-step bookkeeping rides here, two launches ahead of
-        // its reader, in a workgroup of its own (the first after the ordering ones) so that no zeroing waits for the pow() calls
-        const unsigned first = EGS_XCDS + (has_tick ? 1u : 0u);
-        if (blockIdx.x < first) { if (threadIdx.x < 64) egs_adam_tick(tick, threadIdx.x); return; }
-        const size_t stride = (size_t)(gridDim.x - first) * 1024;
-        for (size_t i = (size_t)(blockIdx.x - first) * 1024 + threadIdx.x; i < n4; i += stride) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    // Order of one band: a counting sort on the cost quantised to ORDER_LEVELS levels (descending).  Ties land in arrival order --
-    // the order only decides which workgroup blends which tile, never a result.
-    __shared__ uint32_t work[ORDER_MAX_BAND];
-    __shared__ uint32_t level_base[ORDER_LEVELS], level_fill[ORDER_LEVELS], wsum[16], wmax_s;
-    __shared__ uint4 quad_cost[ORDER_BALANCE_MAX];                   // the four quadrant costs of every tile of a small band
-    __shared__ uint16_t sorted_tile[ORDER_BALANCE_MAX];
-    const int per = egs_tiles_per_xcd(n_tiles), x = blockIdx.x;
-    const int t0 = x * per, n = max(0, min(per, n_tiles - t0));
-    const int slots = ((per + 31) / 32) * 32;
-    if (per > ORDER_MAX_BAND) {                                      // very large images: keep index order
-        for (int sl = threadIdx.x; sl < per; sl += blockDim.x) tile_order[8 * sl + x] = sl < n ? (uint32_t)(t0 + sl) : 0xffffffffu;
-        return;
-    }
-    if (threadIdx.x == 0) wmax_s = 1u;
-    level_fill[threadIdx.x] = 0u;                                    // (ORDER_LEVELS == blockDim.x)
-    __syncthreads();
-    uint32_t mx = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint4 w4 = *reinterpret_cast<const uint4*>(quad_work + 4 * (size_t)(t0 + i));
-        const uint32_t wsum_i = w4.x + w4.y + w4.z + w4.w;
-        work[i] = wsum_i; mx = max(mx, wsum_i);
-        if (per <= ORDER_BALANCE_MAX) quad_cost[i] = w4;
-    }
-    if (per > ORDER_BALANCE_MAX)
-        for (int sl = threadIdx.x; sl < per; sl += blockDim.x) tile_order[8 * sl + x] = 0xffffffffu;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(&wmax_s, mx);
-    __syncthreads();
-    const float to_level = (float)(ORDER_LEVELS - 1) / (float)wmax_s;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t lv = (uint32_t)(ORDER_LEVELS - 1) - min((uint32_t)((float)work[i] * to_level), (uint32_t)(ORDER_LEVELS - 1));
-        work[i] = lv;                                                // 0 = most expensive
-        atomicAdd(&level_fill[lv], 1u);
-    }
-    __syncthreads();
-    {   // exclusive scan of the level counts (one level per thread)
-        const uint32_t c = level_fill[threadIdx.x];
-        uint32_t incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)(threadIdx.x & 63) >= d) incl += o; }
-        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        uint32_t base = incl - c;
-        for (unsigned k = 0; k < (threadIdx.x >> 6); k++) base += wsum[k];
-        level_base[threadIdx.x] = base;
-        level_fill[threadIdx.x] = 0u;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t lv = work[i];
-        const int rank = (int)(level_base[lv] + atomicAdd(&level_fill[lv], 1u));
-        if (per <= ORDER_BALANCE_MAX) { sorted_tile[rank] = (uint16_t)i; continue; }      // band-local index, most expensive first
-        const int round = rank / 32, pos = rank % 32;
-        int slot = round * 32 + ((round & 1) ? 31 - pos : pos);
-        if (slot >= per) slot = round * 32 + pos;                    // last, partial round: no room to mirror
-        if (slot >= per) slot = per - 1 - (slots - 1 - slot);        // (cannot happen when per is a multiple of 32)
-        tile_order[8 * slot + x] = (uint32_t)(t0 + i);
-    }
-    if (per > ORDER_BALANCE_MAX) return;
-    // Small band (every workgroup of the launch resident at once: the workgroup in slot 32 k + c of the band runs on CU c).  With the
-    // waves' issue priority following the work they have left (k_render_backward), a SIMD ends when its total work is done (measured
-    // correlation of blended splats per SIMD and SIMD end: 0.99), so what is left to balance is that total:
-    //   * CUs: dealt in sorted rounds -- in every round the CU that carries the least so far takes the round's most expensive tile;
-    //   * SIMDs: the four quadrant-waves of a workgroup land on the CU's four SIMDs, and which wave takes which quadrant is free, so
-    //     the tile's most expensive quadrant goes to the SIMD of that CU that carries the least.  The choice rides in bits 16-23 of
-    //     the tile_order word (two bits per SIMD = the quadrant its wave should take); the wave reads its SIMD from HW_ID.
-    // One wave does it (lane c = CU c), from the costs cached in LDS.
-    __syncthreads();
-    if (threadIdx.x >= 64) return;
-    const int c = (int)threadIdx.x;
-    uint32_t load_cu = 0, ls0 = 0, ls1 = 0, ls2 = 0, ls3 = 0;
-    const int rounds = (per + 31) / 32;
-    for (int k = 0; k < rounds; k++) {
-        const bool has_slot = c < 32 && 32 * k + c < per;
-        const int m = min(32, n - 32 * k);                           // tiles of this round (uniform)
-        // position of this CU among the CUs with a slot, lightest first: 32 v_readlane + compare on unique keys (a loop of __shfl
-        // = ds_bpermute, each waited for, made this launch 13 us longer)
-        const uint32_t key = has_slot ? (min(load_cu, 0x03ffffffu) << 5) | (uint32_t)c : 0xffffffffu;
-        int rank = 0;
-#pragma unroll
-        for (int j = 0; j < 32; j++) rank += (uint32_t)__builtin_amdgcn_readlane((int)key, j) < key ? 1 : 0;
-        uint32_t word = 0xffffffffu;
-        if (has_slot && rank < m) {
-            const int i = (int)sorted_tile[32 * k + rank];
-            const uint4 w4 = quad_cost[i];
-            // two four-element sorting networks on (value << 2 | index) keys: registers only (indexing a local array by a run-time
-            // value would go through scratch memory, ~1 us per access)
-            uint32_t a0 = (min(w4.x, 0x3fffffffu) << 2) | 0u, a1 = (min(w4.y, 0x3fffffffu) << 2) | 1u,
-                     a2 = (min(w4.z, 0x3fffffffu) << 2) | 2u, a3 = (min(w4.w, 0x3fffffffu) << 2) | 3u;      // quadrants, to be sorted descending
-            uint32_t b0 = (min(ls0, 0x3fffffffu) << 2) | 0u, b1 = (min(ls1, 0x3fffffffu) << 2) | 1u,
-                     b2 = (min(ls2, 0x3fffffffu) << 2) | 2u, b3 = (min(ls3, 0x3fffffffu) << 2) | 3u;        // SIMDs, ascending
-#define EGS_CS(lo, hi) { const uint32_t t_ = min(lo, hi); hi = max(lo, hi); lo = t_; }
-            EGS_CS(a0, a1) EGS_CS(a2, a3) EGS_CS(a0, a2) EGS_CS(a1, a3) EGS_CS(a1, a2)          // a0 <= a1 <= a2 <= a3
-            EGS_CS(b0, b1) EGS_CS(b2, b3) EGS_CS(b0, b2) EGS_CS(b1, b3) EGS_CS(b1, b2)          // b0 <= b1 <= b2 <= b3
-#undef EGS_CS
-            // the most expensive quadrant (a3) goes to the least loaded SIMD (b0), and so on
-            const uint32_t qd[4] = { a3 & 3u, a2 & 3u, a1 & 3u, a0 & 3u }, cd[4] = { a3 >> 2, a2 >> 2, a1 >> 2, a0 >> 2 };
-            const uint32_t sd[4] = { b0 & 3u, b1 & 3u, b2 & 3u, b3 & 3u };
-            uint32_t perm = 0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {                            // (r is a compile-time index after unrolling)
-                perm |= qd[r] << (2u * sd[r]);
-                ls0 += sd[r] == 0u ? cd[r] : 0u; ls1 += sd[r] == 1u ? cd[r] : 0u; ls2 += sd[r] == 2u ? cd[r] : 0u; ls3 += sd[r] == 3u ? cd[r] : 0u;
-            }
-            load_cu += w4.x + w4.y + w4.z + w4.w;
-            word = (uint32_t)(t0 + i) | (perm << 16) | EGS_ORDER_HAS_PERM;
-        }
-        if (has_slot) tile_order[8 * (32 * k + c) + x] = word;
-    }
+__global__ __launch_bounds__(1024) void k_backward_prologue(EgsPrologueArgs a) {
+    __shared__ EgsOrderLds L;
+    egs_prologue_job<1024>(a, blockIdx.x, gridDim.x, L);
 }
 
 // 8 waves per SIMD (64 VGPRs, one spilled): every wave of a 960x540 frame is resident from the start (-2% vs 70 VGPRs / 7 waves)
@@ -395,18 +259,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
-                                      const float* dL_dalpha, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick, hipStream_t s) {
+                                      const float* dL_dalpha, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick, int prologue_done, hipStream_t s) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
     if (n_tiles == 0) {
+        if (prologue_done) return hipSuccess;
         if (tick) { hipError_t e = egs_launch_adam_tick(*tick, s); if (e != hipSuccess) return e; }
         return egs_launch_zero_f4((float4*)grad_acc, acc_floats / 4, s);
     }
-    const size_t n4 = acc_floats / 4;
-    const unsigned zero_blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((n4 + 1023) / 1024, 1024));
-    EgsAdamTick no_tick = {};
-    hipLaunchKernelGGL(k_backward_prologue, dim3(EGS_XCDS + (tick ? 1 : 0) + zero_blocks), dim3(1024), 0, s, n_tiles, im.quad_work, im.tile_order,
-                       (float4*)grad_acc, n4, tick ? 1 : 0, tick ? *tick : no_tick);
+    if (!prologue_done) {
+        EgsPrologueArgs pa = {};
+        pa.n_tiles = n_tiles; pa.quad_work = im.quad_work; pa.tile_order = im.tile_order; pa.acc4 = (float4*)grad_acc; pa.n4 = acc_floats / 4;
+        pa.has_tick = tick ? 1 : 0; if (tick) pa.tick = *tick;
+        hipLaunchKernelGGL(k_backward_prologue, dim3(egs_prologue_jobs(pa.n4, pa.has_tick, 1024)), dim3(1024), 0, s, pa);
+    }
     if (dL_ddepth || dL_dalpha)
         hipLaunchKernelGGL(k_render_backward<true>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                            im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,

@@ -132,7 +132,7 @@ def rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation
 
 class _L1SSIM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, gt, lambda_dssim, gate, running_sum=None, defer_value=False):
+    def forward(ctx, img, gt, lambda_dssim, gate, running_sum=None, defer_value=False, raster_node=None):
         L = _lib.load()
         img, gt = _need_hip(img, "image"), _need_hip(gt, "gt")
         assert img.dim() == 3 and img.shape == gt.shape
@@ -147,6 +147,7 @@ class _L1SSIM(torch.autograd.Function):
         ctx.save_for_backward(img, gt, maps, gate if gate is not None else torch.empty(0))
         ctx.lam, ctx.has_gate = float(lambda_dssim), gate is not None
         ctx.deferred = (partial, loss, running_sum) if defer_value else None
+        ctx.raster_node = raster_node
         return loss
 
     @staticmethod
@@ -159,20 +160,33 @@ class _L1SSIM(torch.autograd.Function):
         if g.dtype != torch.float32 or not g.is_contiguous():
             g = g.float().contiguous()
         dimg = torch.empty_like(img)
+        side = None
+        if ctx.raster_node is not None:
+            from .rasterizer import backward_prologue_of
+            side = backward_prologue_of(ctx.raster_node)
         with torch.cuda.device(img.device):
             d = ctx.deferred
-            _lib.check(L.egs_l1_ssim_backward(Cc, H, W, _p(img), _p(gt), ctx.lam, _p(g), _p(gate), _p(maps[0]), _p(maps[1]),
-                                              _p(maps[2]), _p(dimg), _p(d[0]) if d else None, _p(d[1]) if d else None,
-                                              _p(d[2]) if d else None, _stream()))
-        return dimg, None, None, None, None, None
+            _lib.check(L.egs_l1_ssim_backward_ex(Cc, H, W, _p(img), _p(gt), ctx.lam, _p(g), _p(gate), _p(maps[0]), _p(maps[1]),
+                                                 _p(maps[2]), _p(dimg), _p(d[0]) if d else None, _p(d[1]) if d else None,
+                                                 _p(d[2]) if d else None, C.byref(side) if side is not None else None, _stream()))
+        return dimg, None, None, None, None, None, None
 
 
-def l1_ssim_loss(image, gt, lambda_dssim=0.2, grad_gate=None, running_sum=None, defer_value=False):
+def l1_ssim_loss(image, gt, lambda_dssim=0.2, grad_gate=None, running_sum=None, defer_value=False, raster_prologue=False):
     """(1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)).  `grad_gate` [H,W] multiplies d loss / d image
     per pixel (the reference's `render_image.register_hook(lambda grad: grad * (1 - hand_mask))`).
     running_sum: optional device scalar the loss value is also added to (logging without a launch or a host read per iteration).
     defer_value=True: the returned tensor receives its value during backward() instead of right away -- one launch less per
-    iteration, for steps whose loss is only read after the backward (graph.GraphedTrainStep)."""
+    iteration, for steps whose loss is only read after the backward (graph.GraphedTrainStep).
+    raster_prologue=True: see below -- one launch less per iteration when `image` is the rasterizer's output itself."""
     if running_sum is not None:
         running_sum = _need_hip(running_sum, "running_sum")
-    return _L1SSIM.apply(image, gt, lambda_dssim, grad_gate, running_sum, defer_value)
+    node = None
+    if raster_prologue:
+        # `image` straight from the rasterizer: this loss's backward launch also carries the preparation of the rasterizer's backward
+        # (tile order, cleared accumulator, fused-optimizer bookkeeping; include/egs_raster.h egs_l1_ssim_backward_ex) in extra
+        # workgroups, which otherwise is a launch of its own right after this one.  Results are the same either way.
+        fn = image.grad_fn
+        if fn is not None and getattr(fn, "egs_raster_node", False):
+            node = fn
+    return _L1SSIM.apply(image, gt, lambda_dssim, grad_gate, running_sum, defer_value, node)

@@ -135,7 +135,7 @@ class GraphedTrainStep:
                      optimizer=self.opt if self.fuse_optimizer else None, **kw)
         # the loss value and the running sum are produced by the loss BACKWARD kernel (nothing reads them before): two launches less
         loss = l1_ssim_loss(out["render"], f["gt"], self.lam, grad_gate=f["gate"] if self.gated else None, running_sum=self.loss_sum,
-                            defer_value=True)
+                            defer_value=True, raster_prologue=True)
         loss.backward(gradient=self._one)                            # a resident 1.0: no fill kernel per iteration
         self.opt.step()                                              # whatever the backward did not step itself (fuse_optimizer)
         return loss.detach(), out

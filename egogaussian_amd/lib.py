@@ -36,6 +36,11 @@ class AdamSink(C.Structure):                     # egs_adam_sink
                 ("active_rows", C.c_void_p)]
 
 
+class BackwardPrologue(C.Structure):             # egs_backward_prologue
+    _fields_ = [("P", C.c_int), ("width", C.c_int), ("height", C.c_int), ("image_buffer", C.c_void_p), ("scratch", C.c_void_p),
+                ("sink", C.POINTER(AdamSink)), ("skip_flag", C.c_void_p)]
+
+
 SINK_MEANS3D, SINK_OPACITY, SINK_SCALES, SINK_ROTATIONS, SINK_SH = range(5)      # EGS_SINK_*
 
 # name -> (restype, argtypes); every symbol include/egs_raster.h declares
@@ -61,7 +66,7 @@ SIGNATURES = {
     "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
                                vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_backward_adam": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
-                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(AdamSink), vp, vp, i32]),
+                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(AdamSink), i32, vp, vp, i32]),
     "egs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "egs_cov3d_forward": (C.c_int, [i32, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_cov3d_dm_scratch_floats": (C.c_size_t, [i32]),
@@ -69,6 +74,7 @@ SIGNATURES = {
     "egs_l1_ssim_partial_count": (C.c_size_t, [i32, i32, i32]),
     "egs_l1_ssim_forward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_l1_ssim_backward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "egs_l1_ssim_backward_ex": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(BackwardPrologue), vp]),
     "egs_adam_step": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
     "egs_adam_workgroups": (C.c_int64, [i64]),
     "egs_adam_step_capturable": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp]),

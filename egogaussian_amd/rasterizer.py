@@ -52,6 +52,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
             rs.campos, rs.prefiltered, rs.debug, activation_flags, sh_rest, active_count, guard)
         ctx.guard = guard
+        ctx.egs_raster_node = True                  # fused.l1_ssim_loss(raster_prologue=True) recognises its input's grad_fn by this
+        ctx.prologue_scratch = None
         ctx.raster_settings = rs
         ctx.activation_flags = int(activation_flags)
         ctx.densify_stats = densify_stats           # (tensors updated in place by the backward; not autograd inputs)
@@ -82,13 +84,42 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos, geom,
             ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags, sh_rest if split else None, ctx.densify_stats, ctx.guard,
-            ctx.sink)
+            ctx.sink, ctx.prologue_scratch)
+        ctx.prologue_scratch = None
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = grads[:8]
         none_if_absent = lambda g, x: g if (g is not None and x.numel() != 0) else None
         return (g_means3D, g_means2D, none_if_absent(g_sh, sh), none_if_absent(g_colors, colors_precomp),
                 g_opac, none_if_absent(g_scales, scales),
                 none_if_absent(g_rots, rotations), none_if_absent(g_cov3D, cov3Ds_precomp), None, None,
                 grads[8] if split else None, None, None, None, None)
+
+
+def backward_prologue_of(node):
+    """For the backward node of a rasterizer call that has not run yet: the egs_backward_prologue describing what that backward needs
+    prepared (include/egs_raster.h), or None.  The scratch buffer it names is allocated here and handed to the node, whose backward
+    then runs with prologue_done = 1.  Called by the image loss's backward, which carries the preparation in its own launch."""
+    from . import lib as _lib
+    import ctypes as C
+    try:
+        saved = node.saved_tensors
+    except RuntimeError:
+        return None                                   # already freed: that backward ran before
+    means3D, img = saved[1], saved[9]
+    P = means3D.shape[0]
+    sink = node.sink
+    if P == 0 or node.prologue_scratch is not None:
+        return None
+    rs = node.raster_settings
+    scratch = torch.empty((_lib.load().egs_backward_scratch_bytes(P),), device=means3D.device, dtype=torch.uint8)
+    side = _lib.BackwardPrologue()
+    side.P, side.width, side.height = P, int(rs.image_width), int(rs.image_height)
+    side.image_buffer, side.scratch = img.data_ptr(), scratch.data_ptr()
+    if sink is not None:
+        side.sink = C.pointer(sink.struct)
+    if node.guard is not None:
+        side.skip_flag = node.guard.overflow.data_ptr()
+    node.prologue_scratch = scratch
+    return side
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -260,7 +260,9 @@ int egs_backward_adam(
     float* dL_dmeans2D, float* dL_dcolors /*may be NULL with shs*/, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
     float* dL_dsh_rest, float* dL_dscales, float* dL_drotations,
     float* stat_grad_accum, float* stat_denom, float* stat_max_radii, const uint32_t* skip_flag,
-    const egs_adam_sink* sink /*HOST; NULL = egs_backward*/, void* scratch, void* stream, int debug);
+    const egs_adam_sink* sink /*HOST; NULL = no leaf is fused*/,
+    int prologue_done /*non-zero: egs_l1_ssim_backward_ex carried this frame's egs_backward_prologue (same scratch, same sink)*/,
+    void* scratch, void* stream, int debug);
 
 /* ---- frustum test only  (upstream: markVisible) -------------------------------------------------- */
 int egs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
@@ -315,6 +317,24 @@ int egs_l1_ssim_backward(int channels, int height, int width, const float* img, 
                          const float* deferred_partial_sums /*NULL unless the forward deferred the value*/,
                          float* deferred_loss /*device [1] out or NULL*/, float* loss_running_sum /*device [1] in/out or NULL*/,
                          void* stream);
+
+/* The same launch carrying, in extra workgroups, what a rasterizer backward of the same frame needs done before its blend
+ * kernel: ordering the tiles by the cost the forward recorded, clearing the gradient accumulator (`scratch`) and, with a sink, the
+ * fused optimizer's per-step bookkeeping.  In a training step this launch sits between the two blends and leaves most of the
+ * machine idle, while that preparation as a launch of its own (which egs_backward makes otherwise) costs ~12 us.  The
+ * egs_backward_adam call that follows on the same stream is told so with prologue_done = 1 and must receive the same scratch,
+ * image buffer, sink and skip_flag.  side == NULL: egs_l1_ssim_backward. */
+typedef struct egs_backward_prologue {
+    int P, width, height;            /* of the rasterizer call */
+    void* image_buffer;              /* of that call's forward */
+    void* scratch;                   /* egs_backward_scratch_bytes(P): the backward's scratch */
+    const egs_adam_sink* sink;       /* HOST, or NULL */
+    const uint32_t* skip_flag;       /* device uint32[1] or NULL */
+} egs_backward_prologue;
+int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
+                            const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
+                            const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
+                            float* loss_running_sum, const egs_backward_prologue* side /*HOST or NULL*/, void* stream);
 
 /* ---- f-4 (optimizer part): multi-tensor Adam step in one launch.  Same update as torch.optim.Adam(weight_decay=0,
  *      amsgrad=False), which the reference builds at /root/reference/scene/gaussian_model.py:198 and steps at

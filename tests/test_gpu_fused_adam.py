@@ -198,7 +198,7 @@ def test_c_abi_rejects_inconsistent_sinks():
                                    None if use_cov else vp(rots), vp(cov) if use_cov else None, 0, vp(cam), vp(cam), vp(pos), W, H, 1.0, 1.0,
                                    vp(radii), vp(geom), None, vp(img), vp(gcol), None, None, vp(z(P, 3)), vp(z(P, 3)), vp(z(P, 1)), vp(z(P, 3)),
                                    vp(z(P, 6)) if use_cov else None, vp(z(P, 1, 3)), None, None if use_cov else vp(z(P, 3)),
-                                   None if use_cov else vp(z(P, 4)), None, None, None, None, C.byref(sink), vp(scratch), None, 0)
+                                   None if use_cov else vp(z(P, 4)), None, None, None, None, C.byref(sink), 0, vp(scratch), None, 0)
 
     def sink_for(leaf, param, moments=True):
         s = lib.AdamSink()
@@ -217,3 +217,46 @@ def test_c_abi_rejects_inconsistent_sinks():
     assert call(sink_for(lib.SINK_MEANS3D, means, moments=False)) == ERR_ARG
     s = sink_for(lib.SINK_MEANS3D, means); s.coef = None
     assert call(s) == ERR_ARG
+
+
+def test_loss_backward_carrying_the_raster_prologue():
+    """l1_ssim_loss(raster_prologue=True): the loss's backward launch prepares the rasterizer's backward (tile order, cleared
+    accumulator, optimizer bookkeeping) and that backward starts at its blend kernel.  Same image gradient bit for bit, same
+    parameter gradients up to the order of the float atomics, every tile handed to exactly one workgroup, one Adam step counted."""
+    from egogaussian_amd import _C
+    from egogaussian_amd.scene_synth import SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.fused import l1_ssim_loss
+    from egogaussian_amd.optim import FusedAdam
+    H, W = 96, 160
+    student, cams, gts, bg = _scene(N=8000, H=H, W=W)
+    grads, orders = [], []
+    for carried in (False, True):
+        pc = SynthGaussians(student, device=DEV)
+        out = render(cams[1], pc, Pipe, bg)
+        img_buf = _C.stats["image_buffer"]
+        out["render"].retain_grad()
+        l1_ssim_loss(out["render"], gts[1], 0.2, raster_prologue=carried).backward()
+        torch.cuda.synchronize()
+        grads.append({a: getattr(pc, a).grad.clone() for a in LEAVES} | {"image": out["render"].grad.clone(), "screen": out["viewspace_points"].grad.clone()})
+        nt = ((W + 15) // 16) * ((H + 15) // 16)
+        lay = _C._lib.ImageLayout(); _C._lib.load().egs_get_image_layout(W, H, __import__("ctypes").byref(lay))
+        words = img_buf[lay.tile_order:lay.tile_order + 4 * 8 * ((nt + 7) // 8)].view(torch.int32).cpu().numpy().astype("uint32")
+        tiles = [int(w & 0xffff) if (w & 0x01000000) else int(w) for w in words if w != 0xffffffff]
+        orders.append(sorted(tiles))
+    assert orders[0] == orders[1] == list(range(nt))
+    assert torch.equal(grads[0]["image"], grads[1]["image"])
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-9, k
+    # with a fused optimizer: the bookkeeping rides in the loss launch, one step is counted and taken
+    pc = SynthGaussians(student, device=DEV)
+    opt = FusedAdam(_groups(pc), lr=0.0, eps=1e-15, capturable=True)
+    before = pc._xyz.detach().clone()
+    for it in range(2):
+        out = render(cams[it], pc, Pipe, bg, optimizer=opt)
+        l1_ssim_loss(out["render"], gts[it], 0.2, raster_prologue=True, defer_value=True).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    assert all(float(opt.state[getattr(pc, a)]["step"]) == 2.0 and getattr(pc, a).grad is None for a in LEAVES)
+    assert not torch.equal(before, pc._xyz.detach())

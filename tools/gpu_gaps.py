@@ -11,9 +11,12 @@ adam = [k for k, r in enumerate(rows) if "k_render_backward" in r[0]]
 rows = rows[adam[len(adam) // 4]:adam[3 * len(adam) // 4] + 1]       # the steady middle half of the training steps
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:44]
 gap_by, busy, steps = collections.defaultdict(float), 0.0, 0
+big = collections.defaultdict(list)
 for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
     busy += (e0 - s0)
     gap_by[short(n1)] += max(0, s1 - e0)
+    if s1 - e0 > 3000:
+        big[short(n1)].append((s1 - e0) / 1e3)
     steps += "k_render_backward" in n1
 wall = rows[-1][2] - rows[0][1]
 print(f"{steps} steps; per step: wall {wall / steps / 1e3:.1f} us, kernels busy {busy / steps / 1e3:.1f} us, idle {(wall - busy) / steps / 1e3:.1f} us")
@@ -25,3 +28,6 @@ for n, s0, e0 in rows:
 print("kernel time per step (us):")
 for n, (t, k) in sorted(per.items(), key=lambda kv: -kv[1][0])[:24]:
     print(f"  {n:46s} {t / steps / 1e3:7.1f}   ({k / steps:.1f} launches / step, {t / k / 1e3:.1f} us each)")
+
+for n, g in big.items():
+    print(f"  gaps > 3 us before {n}: {len(g)} (mean {sum(g) / len(g):.1f} us, max {max(g):.1f} us)")
