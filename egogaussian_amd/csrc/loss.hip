@@ -27,7 +27,12 @@
 #else
 #define SR 15                 // output rows per wave (3 x 540 x 960: 1944 waves, just under 2 per SIMD)
 #endif
+#ifndef WPB
 #define WPB 2                 // waves per workgroup (independent)
+#endif
+#ifndef EGS_LOSS_ABL
+#define EGS_LOSS_ABL 0        // ablation builds (wrong results): 1 no map stores, 2 no horizontal blur, 4 no SSIM arithmetic, 8 no loads
+#endif
 
 namespace {
 
@@ -42,11 +47,167 @@ __device__ __forceinline__ constexpr float kwin(int k) {
     return k == 0 || k == 10 ? KW0 : k == 1 || k == 9 ? KW1 : k == 2 || k == 8 ? KW2 : k == 3 || k == 7 ? KW3 : k == 4 || k == 6 ? KW4 : KW5;
 }
 
-// Horizontal blur of NV values per lane (= per column) through the wave's LDS rows: out[m] = sum_k w[k] v[m][lane - 5 + k].
+// Forward: the maps are blurred in PAIRS, (E[x], E[y]) and (E[x^2 + y^2], E[xy]).  A pair lives in a 64-bit register pair and every tap is one v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 -- the same IEEE
+// operations per component in the same order as the scalar formulation, at half the instruction count -- and one ds_write_b64 /
+// ds_read_b64 in the horizontal pass.  What bounds these kernels is the length of ONE wave's instruction stream: 1944 waves = 1.9 per
+// SIMD, each a chain of dependent steps (s_memtime stamps, tools/loss_rows.py: ~1300 cycles per output row = vertical blur 200, LDS
+// round trip + horizontal blur 400, SSIM arithmetic with its two IEEE divisions + stores 700), every instruction of any kind costs
+// the wave >= 4 cycles and ~9 when it depends on the previous one.  Ablations at 3x540x960 (of 19.6 us): no map stores -2.9, no
+// horizontal pass -4.2, no SSIM arithmetic -2.1, no loads +0.2; rows per wave 8 / 12 / 15 / 20: 18.5 / 17.7 / 18.3 / 19.9 us.
+// Pairs + one 11-row buffer refilled in place + 32-bit indices: 2277 -> 1395 static VALU, 144 -> 124 VGPRs, 19.6 -> 18.0 us.  The same
+// rewrite of the backward (1812 -> 1078 VALU) ran 2 us SLOWER and was dropped: its per-row chain is short, and the clamps and
+// selects of the branch-free loads lengthen the scalar part of the stream.
+typedef float v2f __attribute__((ext_vector_type(2)));
+#ifdef EGS_LOSS_TIMING
+// measurement builds: wave 0 of workgroup 0 stamps s_memtime around the phases of every row step (tools/loss_rows.py)
+__device__ unsigned long long egs_loss_stamps[4 * 64];
+__device__ __forceinline__ void loss_stamp(bool on, int row, int phase) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (on && row >= 0 && row < 64) egs_loss_stamps[4 * row + phase] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+}
+#define LOSS_STAMP(row, phase) loss_stamp(c.stamp, row, phase)
+#else
+#define LOSS_STAMP(row, phase)
+#endif
+__device__ __forceinline__ v2f pk_fma(float w, v2f a, v2f c) { return __builtin_elementwise_fma((v2f)(w), a, c); }
+
+// Horizontal blur of one pair per lane (= per column) through the wave's LDS row: out = sum_k w[k] v[lane - 5 + k].
+// Lanes 0..4 and 59..63 read the row's zero padding and return values nobody uses.
+__device__ __forceinline__ void hblur_issue(v2f v, v2f* row /* [80], lane L at [8 + L] */, unsigned lane) { row[8 + lane] = v; }
+__device__ __forceinline__ v2f hblur_collect(const v2f* row, unsigned lane) {
+    v2f r[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) r[k] = row[3 + lane + k];                     // r[k] = v[lane - 5 + k]
+    v2f acc = (v2f)(kwin(0)) * (r[0] + r[10]);                   // the window is symmetric: 6 multiplies instead of 11
+    acc = pk_fma(kwin(1), r[1] + r[9], acc); acc = pk_fma(kwin(2), r[2] + r[8], acc);
+    acc = pk_fma(kwin(3), r[3] + r[7], acc); acc = pk_fma(kwin(4), r[4] + r[6], acc);
+    return pk_fma(kwin(5), r[5], acc);
+}
+// Vertical blur over a window of the last 11 rows (slot = row % 11) when the newest row sits in slot NEWEST (compile-time):
+// out = sum_k w[k] row[NEWEST + 1 + k].
+template <int NEWEST>
+__device__ __forceinline__ v2f vblur(const v2f (&w)[11]) {
+    v2f acc = (v2f)(0.f);
+#pragma unroll
+    for (int k = 0; k < 11; k++) acc = pk_fma(kwin(k), w[(NEWEST + 1 + k) % 11], acc);
+    return acc;
+}
+struct FwdCtx {
+    int H, W, gx, y_first, y_end; size_t plane; bool col_ok, col_out; unsigned lane;
+    float* dm_dmu1; float* dm_dexx; float* dm_dexy; v2f* rows;   // rows: [2][80] pairs
+    float l1, sm; bool stamp; int row0;
+};
+
+// One input row enters (slot NEWEST); if 11 rows are in, the output row 5 above it leaves.
+template <int NEWEST>
+__device__ __forceinline__ void fwd_step(FwdCtx& c, v2f (&w01)[11], v2f (&w23)[11], int y_in, float u, float v) {
+    if (!c.col_ok || y_in < 0 || y_in >= c.H) { u = 0.f; v = 0.f; }    // outside the image: the window's zero padding (the loads were clamped)
+    // SSIM uses the two variances only as their sum, so E[x^2] and E[y^2] are blurred together: four maps, not five
+    LOSS_STAMP(y_in - c.row0, 0);
+    w01[NEWEST] = v2f{u, v}; w23[NEWEST] = v2f{fmaf(u, u, v * v), u * v};
+    const int y_out = y_in - HALO;
+    if (y_out < c.y_first || y_out >= c.y_end) return;                  // wave-uniform
+    const v2f vb01 = vblur<NEWEST>(w01), vb23 = vblur<NEWEST>(w23);
+    LOSS_STAMP(y_in - c.row0, 1);
+    v2f hb01, hb23;
+    if (EGS_LOSS_ABL & 2) { hb01 = vb01; hb23 = vb23; }
+    else {
+        // both rows are written, then all reads are issued together: one LDS round trip per image row
+        hblur_issue(vb01, c.rows, c.lane); hblur_issue(vb23, c.rows + 80, c.lane);
+        __builtin_amdgcn_wave_barrier();
+        hb01 = hblur_collect(c.rows, c.lane); hb23 = hblur_collect(c.rows + 80, c.lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+    LOSS_STAMP(y_in - c.row0, 2);
+    const float mu1 = hb01.x, mu2 = hb01.y, exx_eyy = hb23.x, exy = hb23.y;
+    if (c.col_out) {
+        const float C1 = 0.0001f, C2 = 0.0009f;
+        const float s12 = exy - mu1 * mu2;
+        const float A = 2.f * mu1 * mu2 + C1, B = 2.f * s12 + C2, D = mu1 * mu1 + mu2 * mu2 + C1, E = (exx_eyy - (D - C1)) + C2;
+        const size_t p = c.plane + (size_t)y_out * c.W + c.gx;
+        if (EGS_LOSS_ABL & 4) {
+            c.dm_dmu1[p] = A; c.dm_dexx[p] = B; c.dm_dexy[p] = D + E; c.sm += A;
+            return;
+        }
+        const float invDE = 1.f / (D * E);
+        const float sm = A * B * invDE;
+        // partial derivatives of the map holding the other windowed moments fixed
+        if (EGS_LOSS_ABL & 1) { c.sm += (2.f * mu2 * (B - A)) * invDE - sm * (2.f * mu1 * (E - D)) * invDE + -sm / E + 2.f * A * invDE; }
+        else {
+            c.dm_dmu1[p] = (2.f * mu2 * (B - A)) * invDE - sm * (2.f * mu1 * (E - D)) * invDE;
+            c.dm_dexx[p] = -sm / E;
+            c.dm_dexy[p] = 2.f * A * invDE;
+        }
+        constexpr int CENTRE = (NEWEST + 11 - HALO) % 11;               // the row that is leaving sits 5 slots behind the newest
+        c.l1 += fabsf(w01[CENTRE].x - w01[CENTRE].y);
+        c.sm += sm;
+    }
+    LOSS_STAMP(y_in - c.row0, 3);
+}
+
+// grid: (ceil(strips_x * strips_y / WPB), 1, C); a wave = one strip
+__global__ __launch_bounds__(64 * WPB) void k_l1_ssim_forward(int H, int W, int strips_x, int strips_y, const float* __restrict__ img,
+                                                               const float* __restrict__ gt, float* __restrict__ partial,
+                                                               float* __restrict__ dm_dmu1, float* __restrict__ dm_dexx,
+                                                               float* __restrict__ dm_dexy) {
+    __shared__ v2f lds[WPB][2 * 80];
+    const unsigned lane = threadIdx.x & 63, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
+    const int strip = blockIdx.x * WPB + (int)wv;
+    if (strip >= strips_x * strips_y) return;
+    for (int k = lane; k < 2 * 80; k += 64) lds[wv][k] = (v2f)(0.f);   // the padding words stay zero
+    __builtin_amdgcn_wave_barrier();
+    FwdCtx c;
+    c.H = H; c.W = W; c.lane = lane; c.dm_dmu1 = dm_dmu1; c.dm_dexx = dm_dexx; c.dm_dexy = dm_dexy;
+    c.rows = lds[wv]; c.plane = (size_t)blockIdx.z * H * W; c.l1 = 0.f; c.sm = 0.f;
+    const int sx = strip % strips_x, sy = strip / strips_x;
+    c.gx = sx * SW - HALO + (int)lane;
+    c.col_ok = c.gx >= 0 && c.gx < W;
+    c.col_out = c.col_ok && lane >= HALO && lane < HALO + SW;
+    c.y_first = sy * SR; c.y_end = min(c.y_first + SR, H);
+    c.stamp = false; c.row0 = c.y_first - HALO;
+#ifdef EGS_LOSS_TIMING
+    c.stamp = blockIdx.x == EGS_LOSS_TIMING && blockIdx.z == 0 && wv == 0;
+#endif
+    v2f w01[11], w23[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) { w01[k] = (v2f)(0.f); w23[k] = (v2f)(0.f); }
+    // Input rows y_first - 5 .. y_end + 4, eleven per trip so that every window slot index is a compile-time constant; the next
+    // trip's 22 loads are in flight while this trip computes (a row-by-row load would expose a full memory latency per row:
+    // 28 rows x ~1 us).  A row's address is a wave-uniform base (scalar registers, advanced by scalar adds) plus the lane's column,
+    // clamped into the image -- lanes beyond the image edge load a valid word and zero it when it enters the window; rows beyond
+    // the image are skipped by a uniform branch.  (Per-lane 64-bit addresses and selects cost ~6 VALU instructions per load.)
+    const unsigned col = (unsigned)min(max(c.gx, 0), W - 1);
+    const float* __restrict__ img_p = img + c.plane; const float* __restrict__ gt_p = gt + c.plane;
+    auto load_row = [&](int y, float& u, float& v) {
+        const unsigned ro = (unsigned)min(max(y, 0), H - 1) * (unsigned)W;   // wave-uniform; rows outside the image are zeroed when they enter the window
+        if (EGS_LOSS_ABL & 8) { u = (float)(col & 255) * 0.003f; v = (float)(col & 127) * 0.007f; }
+        else { u = img_p[ro + col]; v = gt_p[ro + col]; }                     // (one plane has fewer than 2^32 elements: check_dims)
+    };
+    // one buffer of eleven rows, refilled in place: as soon as row y0 + K has entered the window its registers receive row
+    // y0 + 11 + K -- every load is eleven row-steps ahead of its use with 22 registers instead of 44 (4 waves per SIMD instead of 2)
+    float cu[11], cv[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) load_row(c.y_first - HALO + k, cu[k], cv[k]);
+    for (int y0 = c.y_first - HALO; y0 < c.y_end + HALO; y0 += 11) {
+#define FSTEP(K) fwd_step<K>(c, w01, w23, y0 + K, cu[K], cv[K]); load_row(y0 + 11 + K, cu[K], cv[K])
+        FSTEP(0); FSTEP(1); FSTEP(2); FSTEP(3); FSTEP(4); FSTEP(5); FSTEP(6); FSTEP(7); FSTEP(8); FSTEP(9); FSTEP(10);
+#undef FSTEP
+    }
+    float l1 = c.l1, sm = c.sm;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { l1 += __shfl_xor(l1, d, 64); sm += __shfl_xor(sm, d, 64); }
+    if (lane == 0) {
+        const size_t b = (size_t)blockIdx.z * strips_x * strips_y + strip;
+        partial[2 * b] = l1; partial[2 * b + 1] = sm;
+    }
+}
+
+// (backward kernel: scalar formulation)  Horizontal blur of NV values per lane (= per column) through the wave's LDS rows: out[m] = sum_k w[k] v[m][lane - 5 + k].
 // All NV rows are written, then all reads are issued together: one LDS round trip per image row, not one per map.
 // Lanes 0..4 and 59..63 read the rows' zero padding and return values nobody uses.
 template <int NV>
-__device__ __forceinline__ void hblur(const float (&v)[NV], float (&out)[NV], float* rows /* [NV][80], lane L at [8 + L] */, unsigned lane) {
+__device__ __forceinline__ void hblur_s(const float (&v)[NV], float (&out)[NV], float* rows /* [NV][80], lane L at [8 + L] */, unsigned lane) {
 #pragma unroll
     for (int m = 0; m < NV; m++) rows[m * 80 + 8 + lane] = v[m];
     __builtin_amdgcn_wave_barrier();
@@ -72,104 +233,13 @@ struct Window {                                          // the last 11 rows of 
 
 // Vertical blur over the window when the newest row sits in slot `newest` (compile-time): out = sum_k w[k] row[newest+1+k].
 template <int NV, int NEWEST>
-__device__ __forceinline__ void vblur(const Window<NV>& w, float (&out)[NV]) {
+__device__ __forceinline__ void vblur_s(const Window<NV>& w, float (&out)[NV]) {
 #pragma unroll
     for (int m = 0; m < NV; m++) {
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; k++) acc = fmaf(kwin(k), w.v[m][(NEWEST + 1 + k) % 11], acc);
         out[m] = acc;
-    }
-}
-
-struct FwdCtx {
-    int H, W, gx, y_first, y_end; size_t plane; bool col_ok, col_out; unsigned lane;
-    const float* img; const float* gt; float* dm_dmu1; float* dm_dexx; float* dm_dexy; float* rows;   // rows: [4][80] floats
-    float l1, sm;
-};
-
-// One input row enters (slot NEWEST); if 11 rows are in, the output row 5 above it leaves.
-template <int NEWEST>
-__device__ __forceinline__ void fwd_step(FwdCtx& c, Window<4>& w, int y_in, float u, float v) {
-    // SSIM uses the two variances only as their sum, so E[x^2] and E[y^2] are blurred together: four maps, not five
-    w.v[0][NEWEST] = u; w.v[1][NEWEST] = v; w.v[2][NEWEST] = fmaf(u, u, v * v); w.v[3][NEWEST] = u * v;
-    const int y_out = y_in - HALO;
-    if (y_out < c.y_first || y_out >= c.y_end) return;                  // wave-uniform
-    float vb[4];
-    vblur<4, NEWEST>(w, vb);
-    float hbv[4];
-    hblur<4>(vb, hbv, c.rows, c.lane);
-    const float mu1 = hbv[0], mu2 = hbv[1], exx_eyy = hbv[2], exy = hbv[3];
-    if (c.col_out) {
-        const float C1 = 0.0001f, C2 = 0.0009f;
-        const float s12 = exy - mu1 * mu2;
-        const float A = 2.f * mu1 * mu2 + C1, B = 2.f * s12 + C2, D = mu1 * mu1 + mu2 * mu2 + C1, E = (exx_eyy - (D - C1)) + C2;
-        const float invDE = 1.f / (D * E);
-        const float sm = A * B * invDE;
-        // partial derivatives of the map holding the other windowed moments fixed
-        const size_t p = c.plane + (size_t)y_out * c.W + c.gx;
-        c.dm_dmu1[p] = (2.f * mu2 * (B - A)) * invDE - sm * (2.f * mu1 * (E - D)) * invDE;
-        c.dm_dexx[p] = -sm / E;
-        c.dm_dexy[p] = 2.f * A * invDE;
-        constexpr int CENTRE = (NEWEST + 11 - HALO) % 11;               // the row that is leaving sits 5 slots behind the newest
-        c.l1 += fabsf(w.v[0][CENTRE] - w.v[1][CENTRE]);
-        c.sm += sm;
-    }
-}
-
-// grid: (ceil(strips_x * strips_y / WPB), 1, C); a wave = one strip
-__global__ __launch_bounds__(64 * WPB) void k_l1_ssim_forward(int H, int W, int strips_x, int strips_y, const float* __restrict__ img,
-                                                               const float* __restrict__ gt, float* __restrict__ partial,
-                                                               float* __restrict__ dm_dmu1, float* __restrict__ dm_dexx,
-                                                               float* __restrict__ dm_dexy) {
-    __shared__ float lds[WPB][4 * 80];
-    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int strip = blockIdx.x * WPB + (int)wv;
-    if (strip >= strips_x * strips_y) return;
-    for (int k = lane; k < 4 * 80; k += 64) lds[wv][k] = 0.f;           // the padding words stay zero
-    __builtin_amdgcn_wave_barrier();
-    FwdCtx c;
-    c.H = H; c.W = W; c.lane = lane; c.img = img; c.gt = gt; c.dm_dmu1 = dm_dmu1; c.dm_dexx = dm_dexx; c.dm_dexy = dm_dexy;
-    c.rows = lds[wv]; c.plane = (size_t)blockIdx.z * H * W; c.l1 = 0.f; c.sm = 0.f;
-    const int sx = strip % strips_x, sy = strip / strips_x;
-    c.gx = sx * SW - HALO + (int)lane;
-    c.col_ok = c.gx >= 0 && c.gx < W;
-    c.col_out = c.col_ok && lane >= HALO && lane < HALO + SW;
-    c.y_first = sy * SR; c.y_end = min(c.y_first + SR, H);
-    Window<4> w;
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int k = 0; k < 11; k++) w.v[m][k] = 0.f;
-    // input rows y_first - 5 .. y_end + 4, eleven per trip so that every window slot index is a compile-time constant;
-    // the next trip's 22 loads are in flight while this trip computes (a row-by-row load would expose a full memory
-    // latency per row: 28 rows x ~1 us)
-    auto load_rows = [&](int y0, float (&u)[11], float (&v)[11]) {
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const int y = y0 + k;
-            const bool ok = c.col_ok && y >= 0 && y < H && y < c.y_end + HALO;
-            const size_t p = c.plane + (size_t)(ok ? y : 0) * W + (ok ? c.gx : 0);
-            u[k] = ok ? img[p] : 0.f; v[k] = ok ? gt[p] : 0.f;
-        }
-    };
-    float cu[11], cv[11], nu[11], nv[11];
-    load_rows(c.y_first - HALO, cu, cv);
-    for (int y0 = c.y_first - HALO; y0 < c.y_end + HALO; y0 += 11) {
-        load_rows(y0 + 11, nu, nv);
-        fwd_step<0>(c, w, y0, cu[0], cv[0]);         fwd_step<1>(c, w, y0 + 1, cu[1], cv[1]); fwd_step<2>(c, w, y0 + 2, cu[2], cv[2]);
-        fwd_step<3>(c, w, y0 + 3, cu[3], cv[3]);     fwd_step<4>(c, w, y0 + 4, cu[4], cv[4]); fwd_step<5>(c, w, y0 + 5, cu[5], cv[5]);
-        fwd_step<6>(c, w, y0 + 6, cu[6], cv[6]);     fwd_step<7>(c, w, y0 + 7, cu[7], cv[7]); fwd_step<8>(c, w, y0 + 8, cu[8], cv[8]);
-        fwd_step<9>(c, w, y0 + 9, cu[9], cv[9]);     fwd_step<10>(c, w, y0 + 10, cu[10], cv[10]);
-#pragma unroll
-        for (int k = 0; k < 11; k++) { cu[k] = nu[k]; cv[k] = nv[k]; }
-    }
-    float l1 = c.l1, sm = c.sm;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { l1 += __shfl_xor(l1, d, 64); sm += __shfl_xor(sm, d, 64); }
-    if (lane == 0) {
-        const size_t b = (size_t)blockIdx.z * strips_x * strips_y + strip;
-        partial[2 * b] = l1; partial[2 * b + 1] = sm;
     }
 }
 
@@ -185,9 +255,9 @@ __device__ __forceinline__ void bwd_step(BwdCtx& c, Window<3>& w, int y_in, floa
     const int y_out = y_in - HALO;
     if (y_out < c.y_first || y_out >= c.y_end) return;                  // wave-uniform
     float vb[3];
-    vblur<3, NEWEST>(w, vb);
+    vblur_s<3, NEWEST>(w, vb);
     float hbv[3];
-    hblur<3>(vb, hbv, c.rows, c.lane);
+    hblur_s<3>(vb, hbv, c.rows, c.lane);
     const float ba = hbv[0], bb = hbv[1], bd = hbv[2];
     if (c.col_out) {
         const size_t p = c.plane + (size_t)y_out * c.W + c.gx;
@@ -236,12 +306,12 @@ __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_backward(int H, int W, int
                                                                 const float* __restrict__ fin_partial, size_t fin_n, float fin_lambda,
                                                                 float* __restrict__ fin_loss, float* __restrict__ fin_running,
                                                                 unsigned per_plane, unsigned side_jobs, EgsPrologueArgs side) {
-    __shared__ float lds[WPB][3 * 80];
+    __shared__ __attribute__((aligned(8))) float lds[WPB][3 * 80];      // per wave: [80] pairs (two maps), then [80] floats (the third)
     if (SIDE) {
         __shared__ EgsOrderLds order_lds;
         if (blockIdx.x < side_jobs) { egs_prologue_job<64 * WPB>(side, blockIdx.x, side_jobs, order_lds); return; }
     }
-    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned lane = threadIdx.x & 63, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
     const unsigned rel = blockIdx.x - (SIDE ? side_jobs : 0u);
     const unsigned plane_z = rel / per_plane, bx = rel - plane_z * per_plane;
     const int strip = (int)bx * WPB + (int)wv;
@@ -330,6 +400,10 @@ int egs_launch_l1_ssim_backward(int channels, int height, int width, const float
 #undef LB_ARGS
     return (int)hipGetLastError();
 }
+
+#ifdef EGS_LOSS_TIMING
+extern "C" int egs_debug_loss_stamps(unsigned long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(egs_loss_stamps), sizeof(unsigned long long) * 4 * 64); }
+#endif
 
 extern "C" {
 
