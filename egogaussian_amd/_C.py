@@ -8,6 +8,7 @@ inputs are zero-length tensors, exactly as upstream passes them.
 Tensors must live on a HIP device (torch device type "cuda" on ROCm).  There is no CPU path.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -58,6 +59,20 @@ def last_instance_count(device=None, P=None):
         return 0
     P = stats.get("P", 0) if P is None else P
     return int(_lib.load().egs_sum_counts(int(P), C.c_void_p(pinned.data_ptr())))
+
+
+_placement = {}
+
+
+def placement_buffer(dev, W, H):
+    """The persistent placement buffer (include/egs_raster.h) of forwards at W x H on the current stream of `dev`: what the previous
+    such forward's blend spent per quadrant, by which the next one places its tiles.  Zero-filled when created."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(W), int(H), torch.cuda.current_stream(dev).cuda_stream)
+    t = _placement.get(key)
+    if t is None:
+        # (never dropped: a captured hipGraph keeps the address; 40 KB per resolution and stream at 960x540)
+        t = _placement[key] = torch.zeros((_lib.load().egs_placement_bytes(int(W), int(H)),), device=dev, dtype=torch.uint8)
+    return t
 
 
 def set_capacity_hint(instances, device=None):
@@ -138,6 +153,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             pinned = _pinned_counts[key] = torch.empty((max(nb, 4096),), dtype=torch.int32, pin_memory=True)
         binning = torch.empty((L.egs_binning_bytes(P, cap, W, H),), device=dev, dtype=torch.uint8)
         capturing = torch.cuda.is_current_stream_capturing()
+        place = placement_buffer(dev, W, H)
         if capturing:
             # hipGraph capture of a whole training step (egogaussian_amd/graph.py): nothing may wait on the host, so the
             # chain is enqueued against the capacity established by earlier eager calls and R is checked after replays.
@@ -148,7 +164,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), _ptr(background), W, H,
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
                 _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), None, _ptr(None if guard is None else guard.running_max),
-                _ptr(active_count), _ptr(None if guard is None else guard.overflow), _stream()))
+                _ptr(active_count), _ptr(None if guard is None else guard.overflow), _ptr(place), _stream()))
             R = C.c_int64(cap)                      # layout size; the true count is stats["total_view"] after a sync
             rc = 0
         else:
@@ -156,7 +172,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
                                _ptr(campos), _ptr(background), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                                _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img), _ptr(out_color), _ptr(out_depth),
-                               _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _ptr(active_count), _stream(), int(bool(debug)))
+                               _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _ptr(active_count), _ptr(place), _stream(), int(bool(debug)))
         if rc == _lib.RETRY_LARGER:
             cap = int(R.value * 1.25) + 65536
             binning = torch.empty((L.egs_binning_bytes(P, cap, W, H),), device=dev, dtype=torch.uint8)

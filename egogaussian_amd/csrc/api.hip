@@ -71,7 +71,8 @@ EgsImgPtrs img_ptrs(void* buf, int W, int H) {
     const ImgLayout L = img_layout(W, H); char* b = (char*)buf; EgsImgPtrs p;
     p.ranges = (uint2*)(b + L.o.ranges); p.final_T = (float*)(b + L.o.final_T);
     p.n_contrib = (uint32_t*)(b + L.o.n_contrib); p.quad_work = (uint32_t*)(b + L.o.quad_work);
-    p.tile_order = (uint32_t*)(b + L.o.tile_order); p.quad_pairs = (uint32_t*)(b + L.o.quad_pairs); return p;
+    p.tile_order = (uint32_t*)(b + L.o.tile_order); p.quad_pairs = (uint32_t*)(b + L.o.quad_pairs);
+    p.fwd_cost = nullptr; p.fwd_order = nullptr; return p;                // (set from the caller's placement buffer, forward_impl)
 }
 
 int check_dims(int P, int W, int H) {
@@ -185,6 +186,16 @@ int egs_get_binning_layout(int P, int64_t R, int width, int height, egs_binning_
     if (!out || P < 0 || R < 0 || width <= 0 || height <= 0) return EGS_ERR_ARG;
     *out = bin_layout(P, R, width, height).o; return 0;
 }
+size_t egs_placement_bytes(int width, int height) {
+    if (width <= 0 || height <= 0) return 0;
+    const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
+    return egs_align((nt * 4 + ((nt + 7) / 8) * 8) * sizeof(uint32_t));
+}
+static void placement_ptrs(void* placement, int width, int height, EgsImgPtrs& im) {
+    const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
+    im.fwd_cost = (uint32_t*)placement; im.fwd_order = placement ? (uint32_t*)placement + nt * 4 : nullptr;
+}
+
 int egs_get_image_layout(int width, int height, egs_image_layout* out) {
     if (!out || width <= 0 || height <= 0) return EGS_ERR_ARG;
     *out = img_layout(width, height).o; return 0;
@@ -211,7 +222,7 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
     egs_prof_start(EGS_K_PREPROCESS, s);
     const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);         // rows of 12 M bytes: the wave-tiled kernel (preprocess.hip)
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
-                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, nullptr, 0, active_count, s));
+                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, nullptr, 0, active_count, nullptr, s));
     if (sh_apart) EGS_TRY(egs_launch_sh_forward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     EGS_SYNC_IF_DEBUG(s);
@@ -237,7 +248,7 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
                 const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                 int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                 float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
-                int64_t* num_rendered, const int32_t* active_count, uint32_t* overflow_flag, void* stream, int debug) {
+                int64_t* num_rendered, const int32_t* active_count, uint32_t* overflow_flag, void* placement, void* stream, int debug) {
     (void)prefiltered;
     int rc = check_dims(P, width, height); if (rc) return rc;
     if (!num_rendered || capacity < 0 || capacity >= (1ll << 31)) return EGS_ERR_ARG;
@@ -268,9 +279,12 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
         const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
         n_sums = EGS_BIN_GROUPS * egs_table_chunks(nt, egs_table_stride(egs_bin_blocks(P)));
     }
+    // ... and carries the placement of the forward blend's tiles (backward_prologue.h), computed from the costs the image buffer holds
+    EgsImgPtrs im_spec = img_ptrs(image_buffer, width, height);
+    placement_ptrs(placement, width, height, im_spec);
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
                                   rotations, activation_flags, cov3D_precomp, cam, radii, g, capacity > 0 ? b_spec.chunk_sum : nullptr, n_sums,
-                                  active_count, s));
+                                  active_count, (capacity > 0 && placement) ? &im_spec : nullptr, s));
     if (sh_apart) EGS_TRY(egs_launch_sh_forward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     const size_t nb = ((size_t)P + 255) / 256;
@@ -278,10 +292,10 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     if (wait_for_count) EGS_TRY(hipEventRecord(ev, s));
     if (capacity > 0) {                                              // speculative: sized by the caller's guess
         EgsBinPtrs b = b_spec;
-        EgsImgPtrs im = img_ptrs(image_buffer, width, height);
+        EgsImgPtrs im = im_spec;
         EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, overflow_flag, 1, s, 0));
         egs_prof_start(EGS_K_RENDER_FWD, s);
-        EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, s));
+        EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, placement ? 1 : 0, s));
         egs_prof_stop(EGS_K_RENDER_FWD, s);
     }
     if (!wait_for_count) { *num_rendered = -1; return 0; }              // graph-capturable: no host wait at all
@@ -301,11 +315,11 @@ int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const
                 const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                 int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                 float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, int64_t* num_rendered,
-                const int32_t* active_count, void* stream, int debug) {
+                const int32_t* active_count, void* placement, void* stream, int debug) {
     return forward_impl(1, P, sh_degree, sh_coeffs, means3D, shs, shs_rest, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
-                        pinned_host_counts, nullptr, num_rendered, active_count, nullptr, stream, debug);
+                        pinned_host_counts, nullptr, num_rendered, active_count, nullptr, placement, stream, debug);
 }
 
 // Same chain with NO host wait: everything is only enqueued, so the call can be captured into a hipGraph.  Overflow of
@@ -318,12 +332,12 @@ int egs_forward_enqueue(int P, int sh_degree, int sh_coeffs, const float* means3
                         const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                         int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                         float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
-                        const int32_t* active_count, uint32_t* overflow_flag, void* stream) {
+                        const int32_t* active_count, uint32_t* overflow_flag, void* placement, void* stream) {
     int64_t unused = 0;
     return forward_impl(0, P, sh_degree, sh_coeffs, means3D, shs, shs_rest, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
-                        pinned_host_counts, running_max, &unused, active_count, overflow_flag, stream, 0);
+                        pinned_host_counts, running_max, &unused, active_count, overflow_flag, placement, stream, 0);
 }
 
 int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts) {
@@ -348,7 +362,7 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
     EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, nullptr, nullptr, 0, s, debug));
     const uint32_t* point_list = b.point_list;
     egs_prof_start(EGS_K_RENDER_FWD, s);
-    EGS_TRY(egs_launch_render_forward(width, height, background, g, point_list, im, out_color, out_depth, out_alpha, s));
+    EGS_TRY(egs_launch_render_forward(width, height, background, g, point_list, im, out_color, out_depth, out_alpha, 0, s));
     egs_prof_stop(EGS_K_RENDER_FWD, s);
     EGS_SYNC_IF_DEBUG(s);
     return 0;
@@ -421,9 +435,9 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
     }
     if (R > 0) {
         const uint32_t* point_list = b.point_list;
-        egs_prof_start(EGS_K_RENDER_BWD, s);
-        EGS_TRY(egs_launch_render_backward(width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth,
-                                           dL_dout_alpha, grad_acc, (size_t)P * EGS_GRAD_STRIDE, sink ? &tick : nullptr, prologue_done, s));
+        if (!prologue_done) EGS_TRY(egs_launch_backward_prologue(width, height, im, grad_acc, (size_t)P * EGS_GRAD_STRIDE, sink ? &tick : nullptr, s));
+        egs_prof_start(EGS_K_RENDER_BWD, s);                         // (the stage is the blend kernel alone)
+        EGS_TRY(egs_launch_render_backward(width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth, dL_dout_alpha, grad_acc, s));
         egs_prof_stop(EGS_K_RENDER_BWD, s);
         EGS_SYNC_IF_DEBUG(s);
     }

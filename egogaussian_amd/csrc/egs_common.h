@@ -41,7 +41,8 @@ struct EgsBinPtrs {
 #define EGS_BIN_GROUPS 8            // partial accumulators per scan chunk (a same-address atomic chain is bin_blocks / 8 long)
 static inline uint32_t egs_table_stride(uint32_t bin_blocks) { uint32_t s = 4; while (s < bin_blocks) s <<= 1; return s; }   // power of two <= 2048
 static inline size_t egs_table_chunks(size_t n_tiles, uint32_t stride) { const size_t rpc = 2048 / stride; return (n_tiles + rpc - 1) / rpc; }
-struct EgsImgPtrs { uint2* ranges; float* final_T; uint32_t* n_contrib; uint32_t* quad_work; uint32_t* tile_order; uint32_t* quad_pairs; };
+struct EgsImgPtrs { uint2* ranges; float* final_T; uint32_t* n_contrib; uint32_t* quad_work; uint32_t* tile_order; uint32_t* quad_pairs;
+                    uint32_t* fwd_cost; uint32_t* fwd_order; };
 
 static inline size_t egs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -113,7 +114,8 @@ struct EgsCamera {
 hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
                                  const float* opac, const float* scales, float mod, const float* rots, int act,
                                  const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, uint32_t* zero_words, size_t zero_n,
-                                 const int32_t* active_count, hipStream_t s);
+                                 const int32_t* active_count, const EgsImgPtrs* place /*NULL, or: also order im.fwd_cost into im.fwd_order*/,
+                                 hipStream_t s);
 hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* means3D, const float* shs,
                                           const float* scales, float mod, const float* rots, const float* cov3D, int act,
                                           EgsCamera cam, const int32_t* radii, EgsGeomPtrs g, const float* grad_acc,
@@ -138,14 +140,16 @@ hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int 
 // sums_zeroed: b.chunk_sum was cleared by this frame's preprocess launch (else a zero-fill launch comes first)
 hipError_t egs_launch_binning(int P, int64_t R, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
                               uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, hipStream_t s, int debug);
+// placed: im.fwd_order holds this frame's placement (the preprocess launch carried the ordering job); else the static mapping
 hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
-                                     EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha,
+                                     EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha, int placed,
                                      hipStream_t s);
-// `tick` (may be NULL): the per-step bookkeeping of an optimizer fused into this backward, done by one thread of the prologue launch
+// The backward blend, and what it needs in place first (tile order, cleared accumulator; `tick`, may be NULL: the per-step bookkeeping
+// of an optimizer fused into this backward) as a launch of its own -- or carried by egs_l1_ssim_backward_ex (backward_prologue.h).
+hipError_t egs_launch_backward_prologue(int W, int H, EgsImgPtrs im, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick, hipStream_t s);
 hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
-                                      const float* dL_dalpha, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick,
-                                      int prologue_done /*the tile order, the cleared accumulator and the tick are in place already*/, hipStream_t s);
+                                      const float* dL_dalpha, float* grad_acc, hipStream_t s);
 hipError_t egs_launch_adam_tick(const EgsAdamTick& tick, hipStream_t s);       // the same bookkeeping as a launch of its own (frames with no instance)
 
 // Zero-fill by a kernel.  hipMemsetAsync is avoided inside the per-step chain: captured into a hipGraph it becomes a memset

@@ -13,6 +13,7 @@
 // This translation unit is compiled with -ffp-contract=off and every expression follows the order of
 // oracle/raster_oracle.c, so radii, tile rectangles and depth bits are bit-identical to the oracle.
 #include "egs_common.h"
+#include "backward_prologue.h"
 
 namespace {
 
@@ -223,6 +224,9 @@ __device__ __forceinline__ uint32_t preprocess_one(
     return (uint32_t)((rx1 - rx0) * (ry1 - ry0));
 }
 
+// PLACE: the first eight workgroups do not preprocess anything -- each orders one XCD band of the forward blend's tiles by the
+// costs the image buffer holds (backward_prologue.h), a job that needs doing before that blend and fits under this launch.
+template <bool PLACE>
 __global__ __launch_bounds__(256) void k_preprocess(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors, const float* __restrict__ opac, const float* __restrict__ scales, float mod,
@@ -230,10 +234,16 @@ __global__ __launch_bounds__(256) void k_preprocess(
     const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
     uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible,
-    uint32_t* __restrict__ block_sums, uint32_t* __restrict__ zero_words, size_t zero_n, const int32_t* __restrict__ active_count) {
+    uint32_t* __restrict__ block_sums, uint32_t* __restrict__ zero_words, size_t zero_n, const int32_t* __restrict__ active_count,
+    EgsPrologueArgs place) {
     __shared__ uint32_t wsum[4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t z = (size_t)i; z < zero_n; z += (size_t)gridDim.x * blockDim.x) zero_words[z] = 0u;   // on the side (egs_common.h)
+    if (PLACE) {
+        __shared__ EgsOrderLds order_lds;
+        if (blockIdx.x < EGS_XCDS) { egs_order_band<256>(place, (int)blockIdx.x, order_lds); return; }
+    }
+    const unsigned bid = blockIdx.x - (PLACE ? EGS_XCDS : 0u), nblk = gridDim.x - (PLACE ? EGS_XCDS : 0u);
+    const int i = (int)(bid * blockDim.x + threadIdx.x);
+    for (size_t z = (size_t)i; z < zero_n; z += (size_t)nblk * blockDim.x) zero_words[z] = 0u;   // on the side (egs_common.h)
     uint32_t my_tiles = 0;
     // capacity-sized models (include/egs_raster.h): rows at and beyond the device-side live count are culled whatever they hold
     const int live = active_count ? min(P, max(*active_count, 0)) : P;
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
     for (int d = 32; d >= 1; d >>= 1) my_tiles += (uint32_t)__shfl_xor((int)my_tiles, d, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = my_tiles;
     __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) block_sums[bid] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // stage offsets (floats) of the leaves a fused optimizer owns: rows of the workgroup's 256 Gaussians, leaf after leaf
@@ -1037,12 +1047,20 @@ hipError_t egs_launch_zero_f4(float4* p, size_t n4, hipStream_t s) {
 hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
                                  const float* opac, const float* scales, float mod, const float* rots, int act,
                                  const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, uint32_t* zero_words, size_t zero_n,
-                                 const int32_t* active_count, hipStream_t s) {
+                                 const int32_t* active_count, const EgsImgPtrs* place, hipStream_t s) {
     if (P == 0) return hipSuccess;
     if (!zero_words) zero_n = 0;
-    hipLaunchKernelGGL(k_preprocess, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, colors, opac, scales,
-                       mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.tanfovx, cam.tanfovy, radii,
-                       g.rec, g.rect, g.offsets, g.clamped, g.visible, g.scan_scratch, zero_words, zero_n, active_count);
+    EgsPrologueArgs pa = {};
+#define PP_ARGS P, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.tanfovx, \
+                cam.tanfovy, radii, g.rec, g.rect, g.offsets, g.clamped, g.visible, g.scan_scratch, zero_words, zero_n, active_count
+    if (place) {
+        pa.n_tiles = ((cam.W + EGS_TILE - 1) / EGS_TILE) * ((cam.H + EGS_TILE - 1) / EGS_TILE);
+        pa.quad_work = place->fwd_cost; pa.tile_order = place->fwd_order;
+        hipLaunchKernelGGL(k_preprocess<true>, dim3((P + 255) / 256 + EGS_XCDS), dim3(256), 0, s, PP_ARGS, pa);
+    } else {
+        hipLaunchKernelGGL(k_preprocess<false>, dim3((P + 255) / 256), dim3(256), 0, s, PP_ARGS, pa);
+    }
+#undef PP_ARGS
     return hipGetLastError();
 }
 

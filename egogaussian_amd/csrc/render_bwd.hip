@@ -257,22 +257,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 }  // namespace
 
-hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
-                                      EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
-                                      const float* dL_dalpha, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick, int prologue_done, hipStream_t s) {
-    const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
-    const int n_tiles = gx * gy;
+// What the blend below needs in place: tile order, cleared accumulator, (fused optimizer) bookkeeping -- as a launch of its own
+// (egs_l1_ssim_backward_ex can carry the same jobs instead).
+hipError_t egs_launch_backward_prologue(int W, int H, EgsImgPtrs im, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick, hipStream_t s) {
+    const int n_tiles = ((W + EGS_TILE - 1) / EGS_TILE) * ((H + EGS_TILE - 1) / EGS_TILE);
     if (n_tiles == 0) {
-        if (prologue_done) return hipSuccess;
         if (tick) { hipError_t e = egs_launch_adam_tick(*tick, s); if (e != hipSuccess) return e; }
         return egs_launch_zero_f4((float4*)grad_acc, acc_floats / 4, s);
     }
-    if (!prologue_done) {
-        EgsPrologueArgs pa = {};
-        pa.n_tiles = n_tiles; pa.quad_work = im.quad_work; pa.tile_order = im.tile_order; pa.acc4 = (float4*)grad_acc; pa.n4 = acc_floats / 4;
-        pa.has_tick = tick ? 1 : 0; if (tick) pa.tick = *tick;
-        hipLaunchKernelGGL(k_backward_prologue, dim3(egs_prologue_jobs(pa.n4, pa.has_tick, 1024)), dim3(1024), 0, s, pa);
-    }
+    EgsPrologueArgs pa = {};
+    pa.n_tiles = n_tiles; pa.quad_work = im.quad_work; pa.tile_order = im.tile_order; pa.acc4 = (float4*)grad_acc; pa.n4 = acc_floats / 4;
+    pa.has_tick = tick ? 1 : 0; if (tick) pa.tick = *tick;
+    hipLaunchKernelGGL(k_backward_prologue, dim3(egs_prologue_jobs(pa.n4, pa.has_tick, 1024)), dim3(1024), 0, s, pa);
+    return hipGetLastError();
+}
+
+hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
+                                      EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
+                                      const float* dL_dalpha, float* grad_acc, hipStream_t s) {
+    const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
+    const int n_tiles = gx * gy;
+    if (n_tiles == 0) return hipSuccess;
     if (dL_ddepth || dL_dalpha)
         hipLaunchKernelGGL(k_render_backward<true>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                            im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,

@@ -27,6 +27,7 @@
 // keep/skip decisions.
 #include "egs_common.h"
 #include "blend_common.h"
+#include "backward_prologue.h"
 
 namespace {
 
@@ -40,16 +41,44 @@ __global__ __launch_bounds__(256) void k_render_forward(
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ quad_work, uint32_t* __restrict__ quad_pairs) {
+    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ quad_work, uint32_t* __restrict__ quad_pairs,
+    const uint32_t* __restrict__ order, uint32_t* __restrict__ cost_hint) {
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
-    const int tile = egs_tile_of_block(blockIdx.x, n_tiles);
-    if (tile < 0) return;
-    const unsigned lane = threadIdx.x & 63, q = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
-    float4* my = lds[q];
+    __shared__ uint32_t quad_claimed;
+    const unsigned lane = threadIdx.x & 63, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
+    // Placement.  Without a cost hint: workgroup b takes tile egs_tile_of_block(b) and wave w quadrant w.  With one (`order`: the
+    // words the ordering job made of the hint, backward_prologue.h): the tile and the quadrant -> SIMD assignment come from there, so
+    // that CUs and SIMDs carry equal work (a wave reads its SIMD from HW_ID and claims the quadrant through an LDS word, as in the
+    // backward).  Placement decides when a quadrant is blended, never what it computes.
+    int tile; unsigned q = wv;
+    if (order) {
+        const uint32_t order_word = order[blockIdx.x];               // 0xffffffff = padding workgroup
+        if (order_word == 0xffffffffu) return;
+        tile = (int)(order_word & ((order_word & EGS_ORDER_HAS_PERM) ? 0xffffu : 0xffffffffu));
+        if (order_word & EGS_ORDER_HAS_PERM) {
+            if (threadIdx.x == 0) quad_claimed = 0u;
+            __syncthreads();
+            uint32_t hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned want = (order_word >> (16 + 2 * ((hw >> 4) & 3u))) & 3u;
+            if (lane == 0) {
+                uint32_t before = atomicOr(&quad_claimed, 1u << want);
+                while (before & (1u << want)) {                      // taken (two waves of the workgroup on one SIMD): any free one
+                    want = (unsigned)__builtin_ctz(~before & 0xfu);
+                    before = atomicOr(&quad_claimed, 1u << want);
+                }
+            }
+            q = (unsigned)__builtin_amdgcn_readfirstlane((int)want);
+        }
+    } else {
+        tile = egs_tile_of_block(blockIdx.x, n_tiles);
+        if (tile < 0) return;
+    }
+    float4* my = lds[wv];
     const unsigned my_addr = (unsigned)(uintptr_t)my;             // LDS byte offset of the wave's slice (low half of the generic address)
     const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
     if (qx0 >= W || qy0 >= H) {                                    // quadrant entirely outside the image
-        if (lane == 0) { quad_work[tile * 4 + q] = 0; quad_pairs[tile * 4 + q] = 0; quad_pairs[(n_tiles + tile) * 4 + q] = 0; }
+        if (lane == 0) { quad_work[tile * 4 + q] = 0; quad_pairs[tile * 4 + q] = 0; quad_pairs[(n_tiles + tile) * 4 + q] = 0; if (cost_hint) cost_hint[tile * 4 + q] = 0; }
         return;
     }
     const int px = qx0 + (int)(lane & 7), py = qy0 + (int)(lane >> 3);
@@ -79,7 +108,9 @@ __global__ __launch_bounds__(256) void k_render_forward(
     id_next = 64 + lane < n ? list[64 + lane] : 0u;
 
     bool alive = true;                                             // wave-uniform: some pixel still live
+    uint32_t scanned = 0;                                           // wave-uniform: batches of 64 list entries looked at
     for (uint32_t base = 0; alive && base < n; base += 64) {
+        scanned++;
 #ifndef EGS_NO_LRPT
         // Longest-remaining-work-first, as in the backward (render_bwd.hip) -- but here the work left is not known, so it is estimated
         // once per batch from the quadrant's own history: its least saturated pixel has come ln(Tmax) of the way to ln(1e-4) with the
@@ -197,6 +228,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
         if (lane == 0) {
             quad_work[tile * 4 + q] = 10u * visits + 18u * ((wmax + 63u) / 64u);
             quad_pairs[tile * 4 + q] = pairs; quad_pairs[(n_tiles + tile) * 4 + q] = visits;     // measurement only (bench.py: Q, visits)
+            if (cost_hint) cost_hint[tile * 4 + q] = 10u * visits + 25u * scanned;             // what THIS kernel spent on the quadrant
         }
 #ifdef EGS_MEASURE
         if (lane == 0) quad_work[tile * 4 + q] = meas;
@@ -227,12 +259,13 @@ __global__ __launch_bounds__(256) void k_render_forward(
 }  // namespace
 
 hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
-                                     EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha,
+                                     EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha, int placed,
                                      hipStream_t s) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_render_forward, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
-                       im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, im.quad_work, im.quad_pairs);
+                       im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, im.quad_work, im.quad_pairs,
+                       placed ? im.fwd_order : (const uint32_t*)nullptr, im.fwd_cost);
     return hipGetLastError();
 }

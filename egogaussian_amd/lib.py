@@ -58,9 +58,10 @@ SIGNATURES = {
     "egs_forward_geometry": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
                                        i32, vp, vp, C.POINTER(i64), vp, vp, i32]),
     "egs_forward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, i64,
-                               vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp, vp, i32]),
+                               vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp, vp, vp, i32]),
     "egs_forward_enqueue": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp,
-                                       i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+                                       i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "egs_placement_bytes": (C.c_size_t, [i32, i32]),
     "egs_sum_counts": (C.c_int64, [i32, vp]),
     "egs_forward_render": (C.c_int, [i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,

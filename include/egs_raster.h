@@ -175,7 +175,17 @@ int egs_forward(
     int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
     int32_t* radii /*[P] out*/, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
     float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts /*HOST, page-locked*/,
-    int64_t* num_rendered /*HOST out*/, const int32_t* active_count /*device int32[1] or NULL*/, void* stream, int debug);
+    int64_t* num_rendered /*HOST out*/, const int32_t* active_count /*device int32[1] or NULL*/,
+    void* placement /*egs_placement_bytes(width, height) or NULL; see below*/, void* stream, int debug);
+
+/* Placement buffer (ABI 2 addition).  The forward blend runs one workgroup per tile, all resident at once, so the launch lasts as
+ * long as its busiest SIMD; which tiles share a CU / SIMD is free.  `placement` is caller-owned device memory that PERSISTS between
+ * calls: every forward leaves there what its blend spent on each 8x8 quadrant, and the next forward given the same buffer deals its
+ * tiles to CUs and its quadrants to SIMDs by those numbers (an ordering job carried by the preprocess launch).  It pays when
+ * consecutive calls render similar frames -- a video or an orbit in order, the static buffers of a replayed hipGraph -- and is neutral
+ * otherwise.  ANY contents are valid (zeros, another resolution's data): they decide when a quadrant is blended, never what is
+ * computed.  One buffer per concurrently running forward (it is read and written by the call).  NULL: the static tile mapping. */
+size_t egs_placement_bytes(int width, int height);
 
 /* ---- the same chain with NO host wait, for hipGraph capture of a whole training step: everything is only enqueued
  *      (capacity must be > 0).  A frame that needs more than `capacity` instances is invalid (its kernels were clipped to
@@ -191,7 +201,8 @@ int egs_forward_enqueue(
     int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
     int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
     float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
-    const int32_t* active_count /*device int32[1] or NULL*/, uint32_t* overflow_flag /*device uint32[2] out or NULL*/, void* stream);
+    const int32_t* active_count /*device int32[1] or NULL*/, uint32_t* overflow_flag /*device uint32[2] out or NULL*/,
+    void* placement /*or NULL*/, void* stream);
 int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts /*HOST*/);
 
 /* ---- backward  (upstream: render backward + computeCov2D backward + preprocess backward) ------- */

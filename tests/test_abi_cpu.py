@@ -84,7 +84,8 @@ def test_argument_errors_precede_device_work():
     assert b"exactly one" in L.egs_error_string(-2) and b"capacity" in L.egs_error_string(lib.RETRY_LARGER)
     # one-call forward: argument errors before any device work
     assert L.egs_forward(10, 0, 1, none, none, none, none, none, none, 1.0, none, none, 0, none, none, none, none, 64, 64, 1.0, 1.0, 0,
-                         none, none, 100, none, none, none, none, none, none, C.byref(R), none, none, 0) == -1
+                         none, none, 100, none, none, none, none, none, none, C.byref(R), none, none, none, 0) == -1
+    assert L.egs_placement_bytes(960, 540) >= (2040 * 4 + 2040) * 4 and L.egs_placement_bytes(0, 5) == 0
     assert L.egs_mark_visible(5, none, none, none, none, none) == -1
 
 

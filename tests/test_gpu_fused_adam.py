@@ -260,3 +260,40 @@ def test_loss_backward_carrying_the_raster_prologue():
     torch.cuda.synchronize()
     assert all(float(opt.state[getattr(pc, a)]["step"]) == 2.0 and getattr(pc, a).grad is None for a in LEAVES)
     assert not torch.equal(before, pc._xyz.detach())
+
+
+def test_forward_placement_buffer_never_changes_results():
+    """The persistent placement buffer (include/egs_raster.h): whatever it holds -- zeros, the previous frame's costs, random words --
+    every tile is blended exactly once and the outputs are bit-identical; after a forward it holds that forward's per-quadrant costs."""
+    from egogaussian_amd import _C
+    from egogaussian_amd.scene_synth import SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    import egogaussian_amd.lib as lib
+    H, W = 96, 160
+    student, cams, gts, bg = _scene(N=8000, H=H, W=W)
+    pc = SynthGaussians(student, device=DEV, requires_grad=False)
+    nt = ((W + 15) // 16) * ((H + 15) // 16)
+    place = _C.placement_buffer(torch.device(DEV), W, H)
+    words = place.view(torch.int32)
+    outs = []
+    gen = torch.Generator().manual_seed(5)
+    for fill in ("zeros", "previous", "random", "huge"):
+        if fill == "zeros":
+            words.zero_()
+        elif fill == "random":
+            words.copy_(torch.randint(-2**31, 2**31 - 1, words.shape, generator=gen, dtype=torch.int64).to(torch.int32).to(DEV))
+        elif fill == "huge":
+            words.fill_(-1)
+        with torch.no_grad():
+            out = render(cams[2], pc, Pipe, bg)
+        torch.cuda.synchronize()
+        outs.append((out["render"].clone(), out["depth"].clone(), out["alpha"].clone()))
+        order = words[nt * 4:nt * 4 + 8 * ((nt + 7) // 8)].cpu().numpy().astype("uint32")
+        tiles = sorted(int(w & 0xffff) if (w & 0x01000000) else int(w) for w in order if w != 0xffffffff)
+        assert tiles == list(range(nt)), fill
+        cost = words[:nt * 4].cpu().numpy()
+        visits = _C.image_views(_C.stats["image_buffer"], W, H)["quad_visits"].cpu().numpy().reshape(-1)
+        assert (cost >= 10 * visits).all() and cost.sum() > 0
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
+    assert lib.load().egs_placement_bytes(W, H) == place.numel()
