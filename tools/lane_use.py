@@ -19,7 +19,7 @@ cam, bg = make_camera(0, H, W, device=dev), torch.zeros(3, device=dev)
 rs = get_raster_settings(cam, pc, bg)
 e = torch.empty(0, device=dev)
 with torch.no_grad():
-    for _ in range(2):                                  # the second call runs at an adequate capacity
+    for _ in range(3):                                  # the second call runs at an adequate capacity, the third is placed by the second's costs
         r = _C.rasterize_gaussians(bg, pc.get_xyz, e, pc.get_opacity, e, e, 1.0, pc.get_covariance(1.0), rs.viewmatrix,
                                    rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, pc.get_features, 0, rs.campos, False, False)
 torch.cuda.synchronize()
