@@ -120,14 +120,16 @@ def test_fused_leaves_have_no_gradient_arrays_and_step_once():
 
 
 def test_graph_step_with_and_without_fused_optimizer_agree():
-    """GraphedTrainStep(fuse_optimizer=True / False) on the same frames: same parameters up to the order of the backward's float
-    atomics (the tolerance the eager-vs-graph tests use), same step counts; the fused graph has no gradient arrays for the leaves."""
+    """GraphedTrainStep(fuse_optimizer=True / False) on the same frames: same step counts, no gradient arrays for the leaves in the
+    fused graph, and parameters that differ from the unfused run's no more than two unfused runs differ from each other (the backward's
+    float atomics land in a different order on every run, and Adam at eps = 1e-15 amplifies last-bit differences of near-zero gradients;
+    the bit-for-bit statement is test_fused_step_is_the_standalone_step_bit_for_bit)."""
     from egogaussian_amd.scene_synth import SynthGaussians
     from egogaussian_amd.optim import FusedAdam
     from egogaussian_amd.graph import GraphedTrainStep
     student, cams, gts, bg = _scene(N=15000)
     res = []
-    for fuse in (False, True):
+    for fuse in (False, False, True):
         pc = SynthGaussians(student, device=DEV)
         opt = FusedAdam(_groups(pc), lr=0.0, eps=1e-15, capturable=True)
         step = GraphedTrainStep(pc, opt, bg, 0.2, fuse_optimizer=fuse, densify_stats=False).capture(cams[0], gts[0], warmup=2)
@@ -139,10 +141,15 @@ def test_graph_step_with_and_without_fused_optimizer_agree():
             assert float(opt.state[getattr(pc, a)]["step"]) == 10.0
             assert (getattr(pc, a).grad is None) == fuse
         res.append(pc)
-    for a in LEAVES:
-        x, y = getattr(res[0], a).detach(), getattr(res[1], a).detach()
+
+    def off(pa, pb, a):                                               # (fraction of entries apart by more than the tolerance, largest difference)
+        x, y = getattr(pa, a).detach(), getattr(pb, a).detach()
         diff = (x - y).abs()
-        assert float((diff > 2e-5 * float(x.abs().max()) + 1e-6).float().mean()) < 2e-3 and float(diff.max()) < 0.02, a
+        return float((diff > 2e-5 * float(x.abs().max()) + 1e-6).float().mean()), float(diff.max())
+    for a in LEAVES:
+        noise_frac, noise_max = off(res[0], res[1], a)                # unfused vs unfused: the run-to-run noise
+        frac, mx = off(res[0], res[2], a)
+        assert frac <= max(3.0 * noise_frac, 2e-3) and mx <= max(3.0 * noise_max, 0.02), (a, frac, mx, noise_frac, noise_max)
 
 
 def test_partial_sinks_follow_the_library_conditions():
