@@ -226,8 +226,10 @@ def test_c_abi_rejects_inconsistent_sinks():
     assert call(s) == ERR_ARG
 
 
-def test_loss_backward_carrying_the_raster_prologue():
-    """l1_ssim_loss(raster_prologue=True): the loss's backward launch prepares the rasterizer's backward (tile order, cleared
+@pytest.mark.parametrize("H,W", [(96, 160), (540, 960), (1080, 1920), (2160, 3840)])
+def test_loss_backward_carrying_the_raster_prologue(H, W):
+    """(sizes: a band of 8 / 255 / 1 020 / 4 050 tiles per XCD -- the balanced small-band path, its limit, the snake-order path)
+    l1_ssim_loss(raster_prologue=True): the loss's backward launch prepares the rasterizer's backward (tile order, cleared
     accumulator, optimizer bookkeeping) and that backward starts at its blend kernel.  Same image gradient bit for bit, same
     parameter gradients up to the order of the float atomics, every tile handed to exactly one workgroup, one Adam step counted."""
     from egogaussian_amd import _C
@@ -235,7 +237,6 @@ def test_loss_backward_carrying_the_raster_prologue():
     from egogaussian_amd.renderer import render
     from egogaussian_amd.fused import l1_ssim_loss
     from egogaussian_amd.optim import FusedAdam
-    H, W = 96, 160
     student, cams, gts, bg = _scene(N=8000, H=H, W=W)
     grads, orders = [], []
     for carried in (False, True):
@@ -269,14 +270,14 @@ def test_loss_backward_carrying_the_raster_prologue():
     assert not torch.equal(before, pc._xyz.detach())
 
 
-def test_forward_placement_buffer_never_changes_results():
+@pytest.mark.parametrize("H,W", [(96, 160), (1080, 1920), (2160, 3840)])
+def test_forward_placement_buffer_never_changes_results(H, W):
     """The persistent placement buffer (include/egs_raster.h): whatever it holds -- zeros, the previous frame's costs, random words --
     every tile is blended exactly once and the outputs are bit-identical; after a forward it holds that forward's per-quadrant costs."""
     from egogaussian_amd import _C
     from egogaussian_amd.scene_synth import SynthGaussians, Pipe
     from egogaussian_amd.renderer import render
     import egogaussian_amd.lib as lib
-    H, W = 96, 160
     student, cams, gts, bg = _scene(N=8000, H=H, W=W)
     pc = SynthGaussians(student, device=DEV, requires_grad=False)
     nt = ((W + 15) // 16) * ((H + 15) // 16)
