@@ -136,7 +136,11 @@ __device__ __forceinline__ void fwd_step(FwdCtx& c, v2f (&w01)[11], v2f (&w23)[1
         if (EGS_LOSS_ABL & 1) { c.sm += (2.f * mu2 * (B - A)) * invDE - sm * (2.f * mu1 * (E - D)) * invDE + -sm / E + 2.f * A * invDE; }
         else {
             c.dm_dmu1[p] = (2.f * mu2 * (B - A)) * invDE - sm * (2.f * mu1 * (E - D)) * invDE;
+#ifdef EGS_LOSS_ONE_DIV
+            c.dm_dexx[p] = -sm * (D * invDE);
+#else
             c.dm_dexx[p] = -sm / E;
+#endif
             c.dm_dexy[p] = 2.f * A * invDE;
         }
         constexpr int CENTRE = (NEWEST + 11 - HALO) % 11;               // the row that is leaving sits 5 slots behind the newest

@@ -31,6 +31,9 @@
 
 namespace {
 
+#ifndef EGS_FWD_COST_BATCH      // cost model of the placement hint: 10 per blended splat + this per batch of 64 list entries scanned
+#define EGS_FWD_COST_BATCH 25u
+#endif
 #ifndef EGS_FWD_LRPT1           // estimated splats left at which the forward's issue priority steps up (swept at config C)
 #define EGS_FWD_LRPT1 16
 #define EGS_FWD_LRPT2 48
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
         if (lane == 0) {
             quad_work[tile * 4 + q] = 10u * visits + 18u * ((wmax + 63u) / 64u);
             quad_pairs[tile * 4 + q] = pairs; quad_pairs[(n_tiles + tile) * 4 + q] = visits;     // measurement only (bench.py: Q, visits)
-            if (cost_hint) cost_hint[tile * 4 + q] = 10u * visits + 25u * scanned;             // what THIS kernel spent on the quadrant
+            if (cost_hint) cost_hint[tile * 4 + q] = 10u * visits + EGS_FWD_COST_BATCH * scanned;  // what THIS kernel spent on the quadrant
         }
 #ifdef EGS_MEASURE
         if (lane == 0) quad_work[tile * 4 + q] = meas;
