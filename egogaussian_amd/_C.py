@@ -242,9 +242,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dcolors = None if (owned and not keep and sh is not None and sh_rest is None and M == 1) else e(P, 3)      # scratch nobody reads in that case
         dopacity = None if fused(_lib.SINK_OPACITY) else e(P, 1)
         dmeans3D = None if fused(_lib.SINK_MEANS3D) else e(P, 3)
+        # (split harmonics: the positions' gradient is finished by the spherical-harmonics launch and travels there through this array)
+        dmeans3D_arg = e(P, 3) if (dmeans3D is None and sh_rest is not None) else dmeans3D
         dcov3D = e(0, 6) if own_cov else e(P, 6)             # not produced when the library built the covariance itself
         dsh = None if fused(_lib.SINK_SH) else (e(*sh.shape) if sh is not None else e(0, 0, 3))
-        dsh_rest = e(*sh_rest.shape) if sh_rest is not None else None
+        dsh_rest = None if fused(_lib.SINK_SH_REST) else (e(*sh_rest.shape) if sh_rest is not None else None)
         dscales = None if fused(_lib.SINK_SCALES) else (e(P, 3) if own_cov else e(0, 3))   # absent inputs get empty gradients (the autograd Function maps them to None)
         drots = None if fused(_lib.SINK_ROTATIONS) else (e(P, 4) if own_cov else e(0, 4))
         if P != 0 and (owned or prologue_scratch is not None):
@@ -254,7 +256,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
                 _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
                 _ptr(imageBuffer), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(dmeans2D), _ptr(dcolors),
-                _ptr(dopacity), _ptr(dmeans3D), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
+                _ptr(dopacity), _ptr(dmeans3D_arg), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
                 _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
                 C.byref(sink.struct) if owned else None, 1 if prologue_scratch is not None else 0, _ptr(scratch), _stream(), int(bool(debug))))
             if owned:

@@ -396,7 +396,8 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
         return EGS_ERR_ARG;
     // leaves a fused optimizer owns: their gradient arrays are optional
     const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);
-    bool own[EGS_SINK_LEAVES] = { false, false, false, false, false };
+    bool own[EGS_SINK_LEAVES] = { false, false, false, false, false, false };
+    const bool sh_sink_ok = sh_apart && egs_sh_backward_can_sink(sh_coeffs, shs, shs_rest);      // the split M = 16 kernel steps dc / rest / positions
     if (sink) {
         if (!sink->coef) return EGS_ERR_ARG;
         for (int l = 0; l < EGS_SINK_LEAVES; l++) {
@@ -405,8 +406,10 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
             if (own[l] && (!f.exp_avg || !f.exp_avg_sq || !f.lr || !f.step)) return EGS_ERR_ARG;
         }
         if ((own[EGS_SINK_SCALES] || own[EGS_SINK_ROTATIONS]) && cov3D_precomp) return EGS_ERR_MODE;
-        if (own[EGS_SINK_SH] && (!shs || sh_apart)) return EGS_ERR_MODE;
-        if (own[EGS_SINK_MEANS3D] && sh_apart) return EGS_ERR_MODE;
+        if (own[EGS_SINK_SH] && (!shs || (sh_apart && !sh_sink_ok))) return EGS_ERR_MODE;
+        if (own[EGS_SINK_SH_REST] && (!sh_sink_ok || sink->leaf[EGS_SINK_SH_REST].param != shs_rest)) return EGS_ERR_MODE;
+        if (own[EGS_SINK_MEANS3D] && sh_apart && (!sh_sink_ok || !dL_dmeans3D)) return EGS_ERR_MODE;
+        if (sh_apart && (own[EGS_SINK_SH] || own[EGS_SINK_SH_REST]) && ((dL_dsh != nullptr) != (dL_dsh_rest != nullptr))) return EGS_ERR_ARG;
         if ((own[EGS_SINK_MEANS3D] && sink->leaf[EGS_SINK_MEANS3D].param != means3D) || (own[EGS_SINK_SCALES] && sink->leaf[EGS_SINK_SCALES].param != scales) ||
             (own[EGS_SINK_ROTATIONS] && sink->leaf[EGS_SINK_ROTATIONS].param != rotations) || (own[EGS_SINK_SH] && sink->leaf[EGS_SINK_SH].param != shs))
             return EGS_ERR_ARG;
@@ -416,8 +419,10 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
     if (R > 0 && !binning_buffer) return EGS_ERR_ARG;
     rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp, activation_flags); if (rc) return rc;
     if (shs && !dL_dsh && !own[EGS_SINK_SH]) return EGS_ERR_ARG;
+    if (sh_apart && !dL_dsh && !(own[EGS_SINK_SH] && (own[EGS_SINK_SH_REST] || !shs_rest))) return EGS_ERR_ARG;
     if (shs_rest && (!shs || sh_coeffs < 2)) return EGS_ERR_MODE;
-    if ((shs_rest != nullptr) != (dL_dsh_rest != nullptr)) return EGS_ERR_ARG;
+    if (!shs_rest && dL_dsh_rest) return EGS_ERR_ARG;
+    if (shs_rest && !dL_dsh_rest && !own[EGS_SINK_SH_REST]) return EGS_ERR_ARG;
     if ((stat_grad_accum != nullptr) != (stat_denom != nullptr) || (stat_max_radii && !stat_grad_accum)) return EGS_ERR_ARG;
     if (!cov3D_precomp && ((!dL_dscales && !own[EGS_SINK_SCALES]) || (!dL_drotations && !own[EGS_SINK_ROTATIONS]))) return EGS_ERR_ARG;
     if (cov3D_precomp && !dL_dcov3D) return EGS_ERR_ARG;
@@ -426,8 +431,17 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
     EgsBinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), P, R, width, height);
     EgsImgPtrs im = img_ptrs(const_cast<void*>(image_buffer), width, height);
     float* grad_acc = (float*)scratch;
-    EgsSink ks = {}; EgsAdamTick tick = {};
-    if (sink) sink_to_kernel_args(sink, skip_flag, ks, tick);
+    EgsSink ks = {}, ks_sh = {}; EgsAdamTick tick = {};
+    bool pp_sinks = false, sh_sinks = false;
+    if (sink) {
+        sink_to_kernel_args(sink, skip_flag, ks, tick);
+        ks_sh = ks;
+        for (int l = 0; l < EGS_SINK_LEAVES; l++) {                    // who finishes which gradient: the spherical-harmonics launch, or the one before it
+            const bool by_sh = sh_apart && (l == EGS_SINK_SH || l == EGS_SINK_SH_REST || l == EGS_SINK_MEANS3D);
+            if (by_sh) ks.leaf[l] = EgsSinkLeaf{ nullptr, nullptr, nullptr }; else ks_sh.leaf[l] = EgsSinkLeaf{ nullptr, nullptr, nullptr };
+            pp_sinks = pp_sinks || ks.leaf[l].p; sh_sinks = sh_sinks || ks_sh.leaf[l].p;
+        }
+    }
     // the accumulator is cleared by a kernel, not a memset node (see egs_launch_zero_f4): fused into the blend's prologue
     if (R == 0 && !prologue_done) {
         EGS_TRY(egs_launch_zero_f4((float4*)grad_acc, (size_t)P * EGS_GRAD_STRIDE / 4, s));
@@ -446,9 +460,9 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
     EGS_TRY(egs_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, scales, scale_modifier, rotations,
                                            cov3D_precomp, activation_flags, cam, radii, g, grad_acc, colors_precomp != nullptr, dL_dmeans2D,
                                            dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, sh_apart ? nullptr : dL_dsh, dL_dscales,
-                                           dL_drotations, stat_grad_accum, stat_denom, stat_max_radii, skip_flag, sink ? &ks : nullptr, s));
+                                           dL_drotations, stat_grad_accum, stat_denom, stat_max_radii, skip_flag, pp_sinks ? &ks : nullptr, s));
     if (sh_apart) EGS_TRY(egs_launch_sh_backward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, radii, g, dL_dcolors, dL_dsh,
-                                                 dL_dsh_rest, dL_dmeans3D, s));
+                                                 dL_dsh_rest, dL_dmeans3D, sh_sinks ? &ks_sh : nullptr, s));
     egs_prof_stop(EGS_K_PREPROCESS_BWD, s);
     EGS_SYNC_IF_DEBUG(s);
     return 0;

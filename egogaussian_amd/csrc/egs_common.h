@@ -76,7 +76,8 @@ __device__ __forceinline__ void egs_adam1(float& p, float g, float& m, float& v,
 }
 // Leaves a fused optimizer can own (include/egs_raster.h: EGS_SINK_*), in the order their rows are staged: floats per row and
 // the float4 task at which each leaf's share of a 256-Gaussian workgroup starts (64 * row floats tasks each).
-#define EGS_SINK_LEAVES 5
+#define EGS_SINK_LEAVES 6          // the sixth (EGS_SINK_SH_REST) is stepped by k_sh16_backward only
+#define EGS_SINK_PP_LEAVES 5       // leaves k_preprocess_backward can step
 #define EGS_SINK_TASKS 896
 struct EgsSinkLeaf { float* p; float* m; float* v; };
 struct EgsSink {                       // kernel argument of k_preprocess_backward<true>
@@ -128,9 +129,11 @@ hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* mean
 // dL/dSH and the view-direction part of dL/dmean3D to egs_launch_sh_backward (which must run after it).
 hipError_t egs_launch_sh_forward(int P, int D, int M, const float* means3D, const float* sh_a, const float* sh_rest, EgsCamera cam,
                                  EgsGeomPtrs g, hipStream_t s);
+// sink (may be NULL; only with egs_sh_backward_can_sink): the Adam step of features_dc / features_rest / positions taken by this launch
 hipError_t egs_launch_sh_backward(int P, int D, int M, const float* means3D, const float* sh_a, const float* sh_rest, EgsCamera cam,
                                   const int32_t* radii, EgsGeomPtrs g, const float* dcolors, float* dsh_a, float* dsh_rest,
-                                  float* dmeans3D, hipStream_t s);
+                                  float* dmeans3D, const EgsSink* sink, hipStream_t s);
+bool egs_sh_backward_can_sink(int M, const float* sh_a, const float* sh_rest);      // the M = 16 split-array kernel will run
 hipError_t egs_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 
 // exclusive/inclusive u32 scan of n elements; scratch holds egs_scan_scratch_elems(n) u32; optionally

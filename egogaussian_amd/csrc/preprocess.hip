@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     unsigned fused = 0;
     if (SINK) {
 #pragma unroll
-        for (int l = 0; l < EGS_SINK_LEAVES; l++) fused |= sink.leaf[l].p ? (1u << l) : 0u;
+        for (int l = 0; l < EGS_SINK_PP_LEAVES; l++) fused |= sink.leaf[l].p ? (1u << l) : 0u;
     }
     if (i < P)
         pp_bwd_one<SINK>(i, D, M, means3D, shs, scales, mod, rots, cov3D_in, act, V, PM, campos, W, H, tanfovx, tanfovy, radii, clamped, rec,
@@ -528,8 +528,8 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     const int row0 = blockIdx.x * 256;
     const int live = min(256, rows - row0);                          // rows of this workgroup that take the step
     if (live <= 0) return;
-    constexpr int RF[EGS_SINK_LEAVES] = { 3, 1, 3, 4, 3 };
-    constexpr int T0[EGS_SINK_LEAVES + 1] = { 0, 192, 256, 448, 704, 896 };
+    constexpr int RF[EGS_SINK_PP_LEAVES] = { 3, 1, 3, 4, 3 };
+    constexpr int T0[EGS_SINK_PP_LEAVES + 1] = { 0, 192, 256, 448, 704, 896 };
     // all loads of the thread's (up to four) tasks first, then the arithmetic, then the stores
     float4 Pq[4], Mq[4], Vq[4]; int cnt[4]; float* pp[4]; float* pm[4]; float* pv[4]; float ss[4], ib[4];
 #pragma unroll
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
         const int task = (int)threadIdx.x + 256 * k;
         cnt[k] = 0;
 #pragma unroll
-        for (int l = 0; l < EGS_SINK_LEAVES; l++) {
+        for (int l = 0; l < EGS_SINK_PP_LEAVES; l++) {
             if (task < T0[l] || task >= T0[l + 1] || !sink.leaf[l].p) continue;
             const int e = 4 * (task - T0[l]);                         // first element of the task inside the workgroup's span of leaf l
             const size_t off = (size_t)row0 * RF[l] + e;
@@ -928,12 +928,46 @@ __global__ __launch_bounds__(64) void k_sh16_forward(int P, int D, const float* 
     r[6] = rgb[0]; r[7] = rgb[1]; r[8] = rgb[2];
 }
 
-template <int MODE>
+// One span of `n` floats (n4 = n / 4 float4 + a tail) of a leaf stepped with the gradients in `t` (LDS, same order): the stand-alone
+// optimizer kernel's arithmetic on the store pattern of sh16_stage_out.
+__device__ __forceinline__ void sh16_adam_span(const float* t, const EgsSinkLeaf& f, size_t first, int n, float ss, float ib, float b1, float b2,
+                                               float eps, unsigned lane) {
+    float* __restrict__ p = f.p + first; float* __restrict__ m = f.m + first; float* __restrict__ v = f.v + first;
+    const bool vec = ((((size_t)p) | ((size_t)m) | ((size_t)v)) & 15) == 0;
+    for (int q0 = 0; 4 * q0 < n; q0 += 4 * 64) {                      // four float4 per lane and round: twelve loads in flight
+        float4 P4[4], M4[4], V4[4]; bool on[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int q = q0 + (int)lane + 64 * k;
+            on[k] = vec && 4 * q + 3 < n;
+            if (on[k]) { P4[k] = reinterpret_cast<const float4*>(p)[q]; M4[k] = reinterpret_cast<const float4*>(m)[q]; V4[k] = reinterpret_cast<const float4*>(v)[q]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!on[k]) continue;
+            const int q = q0 + (int)lane + 64 * k;
+            const float4 G = reinterpret_cast<const float4*>(t)[q];
+            egs_adam1(P4[k].x, G.x, M4[k].x, V4[k].x, b1, b2, eps, ss, ib); egs_adam1(P4[k].y, G.y, M4[k].y, V4[k].y, b1, b2, eps, ss, ib);
+            egs_adam1(P4[k].z, G.z, M4[k].z, V4[k].z, b1, b2, eps, ss, ib); egs_adam1(P4[k].w, G.w, M4[k].w, V4[k].w, b1, b2, eps, ss, ib);
+            reinterpret_cast<float4*>(p)[q] = P4[k]; reinterpret_cast<float4*>(m)[q] = M4[k]; reinterpret_cast<float4*>(v)[q] = V4[k];
+        }
+    }
+    const int done = vec ? (n & ~3) : 0;                              // the tail (and everything, if a base is not 16-byte aligned) element by element
+    for (int e = done + (int)lane; e < n; e += 64) {
+        float P1 = p[e], M1 = m[e], V1 = v[e];
+        egs_adam1(P1, t[e], M1, V1, b1, b2, eps, ss, ib);
+        p[e] = P1; m[e] = M1; v[e] = V1;
+    }
+}
+
+// SINK (split arrays only; include/egs_raster.h egs_backward_adam): the launch also takes the Adam step of the leaves whose gradient it
+// finishes -- features_dc, features_rest and, because the view-direction term lands here, the positions -- for its 64 rows.
+template <int MODE, bool SINK>
 __global__ __launch_bounds__(64) void k_sh16_backward(int P, int D, const float* __restrict__ means3D, const float* __restrict__ campos,
                                                       const float* __restrict__ sh_a, const float* __restrict__ sh_rest,
                                                       const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
                                                       const float* __restrict__ dcolors, float* __restrict__ dsh_a, float* __restrict__ dsh_rest,
-                                                      float* __restrict__ dmeans3D) {
+                                                      float* __restrict__ dmeans3D, EgsSink sink) {
     const unsigned lane = threadIdx.x;
     const int i0 = blockIdx.x * 64, i = i0 + (int)lane;
     const bool inb = i < P;
@@ -944,7 +978,7 @@ __global__ __launch_bounds__(64) void k_sh16_backward(int P, int D, const float*
         p[0] = means3D[3 * i]; p[1] = means3D[3 * i + 1]; p[2] = means3D[3 * i + 2];
         dc[0] = dcolors[3 * i]; dc[1] = dcolors[3 * i + 1]; dc[2] = dcolors[3 * i + 2];
         cl = clamped[i];
-        if (D > 0) { gm[0] = dmeans3D[3 * i]; gm[1] = dmeans3D[3 * i + 1]; gm[2] = dmeans3D[3 * i + 2]; }
+        if (D > 0 || (SINK && sink.leaf[EGS_SINK_MEANS3D].p)) { gm[0] = dmeans3D[3 * i]; gm[1] = dmeans3D[3 * i + 1]; gm[2] = dmeans3D[3 * i + 2]; }
     }
     const uint64_t vmask = __ballot(vis);
     const int nvalid = min(64, P - i0), need = 3 * (D + 1) * (D + 1);
@@ -1001,13 +1035,35 @@ __global__ __launch_bounds__(64) void k_sh16_backward(int P, int D, const float*
         }
         if (D > 0) {
             const float dot = x * gdir[0] + y * gdir[1] + z * gdir[2];
-            dmeans3D[3 * i] = gm[0] + (gdir[0] - x * dot) * inv; dmeans3D[3 * i + 1] = gm[1] + (gdir[1] - y * dot) * inv;
-            dmeans3D[3 * i + 2] = gm[2] + (gdir[2] - z * dot) * inv;
+            gm[0] += (gdir[0] - x * dot) * inv; gm[1] += (gdir[1] - y * dot) * inv; gm[2] += (gdir[2] - z * dot) * inv;
+            dmeans3D[3 * i] = gm[0]; dmeans3D[3 * i + 1] = gm[1]; dmeans3D[3 * i + 2] = gm[2];
         }
     }
     sh16_regs_to_row<MODE>(sh_tile, lane, g);                          // (a lane touches only its own row: no barrier since the reads above)
     __syncthreads();
-    sh16_stage_out<MODE>(sh_tile, dsh_a, dsh_rest, i0, nvalid, lane);
+    if (!SINK || dsh_a) sh16_stage_out<MODE>(sh_tile, dsh_a, dsh_rest, i0, nvalid, lane);
+    if (SINK && MODE == SH16_SPLIT) {
+        if (sink.skip && *sink.skip) return;                          // overflowed frame: no step
+        const int rows = sink.active_rows ? min(P, max(*sink.active_rows, 0)) : P;
+        const int live = min(64, rows - i0);
+        if (live <= 0) return;
+        if (sink.leaf[EGS_SINK_SH_REST].p)
+            sh16_adam_span(sh_tile, sink.leaf[EGS_SINK_SH_REST], (size_t)i0 * 45, live * 45, sink.coef[2 * EGS_SINK_SH_REST],
+                           sink.coef[2 * EGS_SINK_SH_REST + 1], sink.b1, sink.b2, sink.eps, lane);
+        if (sink.leaf[EGS_SINK_SH].p)
+            sh16_adam_span(sh_tile + SH16_REST_WORDS, sink.leaf[EGS_SINK_SH], (size_t)i0 * 3, live * 3, sink.coef[2 * EGS_SINK_SH],
+                           sink.coef[2 * EGS_SINK_SH + 1], sink.b1, sink.b2, sink.eps, lane);
+        if (sink.leaf[EGS_SINK_MEANS3D].p && (int)lane < live) {       // three floats per lane (gm is zero for a culled row, as its gradient is)
+            const EgsSinkLeaf& f = sink.leaf[EGS_SINK_MEANS3D];
+            const float ss = sink.coef[2 * EGS_SINK_MEANS3D], ib = sink.coef[2 * EGS_SINK_MEANS3D + 1];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float P1 = f.p[3 * i + k], M1 = f.m[3 * i + k], V1 = f.v[3 * i + k];
+                egs_adam1(P1, gm[k], M1, V1, sink.b1, sink.b2, sink.eps, ss, ib);
+                f.p[3 * i + k] = P1; f.m[3 * i + k] = M1; f.v[3 * i + k] = V1;
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
@@ -1083,6 +1139,9 @@ hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* mean
     return hipGetLastError();
 }
 
+bool egs_sh_backward_can_sink(int M, const float* sh_a, const float* sh_rest) {
+    return M == 16 && sh_rest && ((((uintptr_t)sh_a) | ((uintptr_t)sh_rest)) & 15) == 0;
+}
 static bool sh16_fast(int M, const void* a, const void* b, const void* c, const void* d) {
     return M == 16 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
 }
@@ -1105,14 +1164,20 @@ hipError_t egs_launch_sh_forward(int P, int D, int M, const float* means3D, cons
 
 hipError_t egs_launch_sh_backward(int P, int D, int M, const float* means3D, const float* sh_a, const float* sh_rest, EgsCamera cam,
                                   const int32_t* radii, EgsGeomPtrs g, const float* dcolors, float* dsh_a, float* dsh_rest,
-                                  float* dmeans3D, hipStream_t s) {
+                                  float* dmeans3D, const EgsSink* sink, hipStream_t s) {
     if (P == 0) return hipSuccess;
     const dim3 grid((P + 63) / 64), block(64);
+    EgsSink none = {};
+    if (sink) {                                                       // (the caller checked egs_sh_backward_can_sink)
+        hipLaunchKernelGGL((k_sh16_backward<SH16_SPLIT, true>), grid, block, (SH16_REST_WORDS + 192) * sizeof(float), s, P, D, means3D, cam.campos,
+                           sh_a, sh_rest, radii, g.clamped, dcolors, dsh_a, dsh_rest, dmeans3D, *sink);
+        return hipGetLastError();
+    }
     if (sh16_fast(M, sh_a, sh_rest, dsh_a, dsh_rest)) {
-        if (sh_rest) hipLaunchKernelGGL(k_sh16_backward<SH16_SPLIT>, grid, block, (SH16_REST_WORDS + 192) * sizeof(float), s, P, D, means3D, cam.campos,
-                                        sh_a, sh_rest, radii, g.clamped, dcolors, dsh_a, dsh_rest, dmeans3D);
-        else hipLaunchKernelGGL(k_sh16_backward<SH16_CAT>, grid, block, 64 * 13 * sizeof(float4), s, P, D, means3D, cam.campos, sh_a, sh_rest,
-                                radii, g.clamped, dcolors, dsh_a, dsh_rest, dmeans3D);
+        if (sh_rest) hipLaunchKernelGGL((k_sh16_backward<SH16_SPLIT, false>), grid, block, (SH16_REST_WORDS + 192) * sizeof(float), s, P, D, means3D, cam.campos,
+                                        sh_a, sh_rest, radii, g.clamped, dcolors, dsh_a, dsh_rest, dmeans3D, none);
+        else hipLaunchKernelGGL((k_sh16_backward<SH16_CAT, false>), grid, block, 64 * 13 * sizeof(float4), s, P, D, means3D, cam.campos, sh_a, sh_rest,
+                                radii, g.clamped, dcolors, dsh_a, dsh_rest, dmeans3D, none);
         return hipGetLastError();
     }
     const size_t lds = (size_t)64 * (3 * M + 1) * sizeof(float);

@@ -32,7 +32,7 @@ class AdamLeaf(C.Structure):
 
 
 class AdamSink(C.Structure):                     # egs_adam_sink
-    _fields_ = [("leaf", AdamLeaf * 5), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("coef", C.c_void_p),
+    _fields_ = [("leaf", AdamLeaf * 6), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("coef", C.c_void_p),
                 ("active_rows", C.c_void_p)]
 
 
@@ -41,7 +41,7 @@ class BackwardPrologue(C.Structure):             # egs_backward_prologue
                 ("sink", C.POINTER(AdamSink)), ("skip_flag", C.c_void_p)]
 
 
-SINK_MEANS3D, SINK_OPACITY, SINK_SCALES, SINK_ROTATIONS, SINK_SH = range(5)      # EGS_SINK_*
+SINK_MEANS3D, SINK_OPACITY, SINK_SCALES, SINK_ROTATIONS, SINK_SH, SINK_SH_REST = range(6)      # EGS_SINK_*
 
 # name -> (restype, argtypes); every symbol include/egs_raster.h declares
 SIGNATURES = {

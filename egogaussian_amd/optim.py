@@ -20,6 +20,7 @@ class AdamSink:
 
     def __init__(self, struct, owned, ptrs, keep, opt=None, params=()):
         self.struct, self.owned, self.ptrs, self._keep = struct, owned, ptrs, keep
+        self.split16 = False              # True: features_dc / features_rest / positions are stepped by the spherical-harmonics launch
         self._opt, self._params = opt, tuple(params)
         self.keep_grads = False           # True: the backward also writes (and returns) the owned leaves' gradients -- inspection / tests
 
@@ -31,7 +32,7 @@ class AdamSink:
 
     def check(self, means3D, scales, rotations, sh, sh_rest, own_cov, colors):
         """Called by _C.rasterize_gaussians_backward with the arrays it is about to pass: the owned leaves must be those arrays."""
-        got = {_lib.SINK_MEANS3D: means3D, _lib.SINK_SCALES: scales, _lib.SINK_ROTATIONS: rotations, _lib.SINK_SH: sh}
+        got = {_lib.SINK_MEANS3D: means3D, _lib.SINK_SCALES: scales, _lib.SINK_ROTATIONS: rotations, _lib.SINK_SH: sh, _lib.SINK_SH_REST: sh_rest}
         for leaf, t in got.items():
             if leaf in self.owned and (t is None or t.data_ptr() != self.ptrs[leaf]):
                 raise RuntimeError("AdamSink: the backward received a different array than the leaf the sink was built for")
@@ -53,7 +54,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._aux = WeakIdKeyDictionary()
         self.guard = None                 # _C.StepGuard of a captured step: its overflow word makes step() a no-op for a clipped frame
         self.active_rows = None           # (int32[1] device tensor, capacity rows): only the live rows of a capacity-sized model are stepped
-        self._coef = {}                   # device -> float32[10] scratch of the fused path (make_sink)
+        self._coef = {}                   # device -> float32[12] scratch of the fused path (make_sink)
         self._sunk = set()                # id(p) of parameters a rasterizer backward stepped since the last step()
 
     def load_state_dict(self, state_dict):
@@ -97,10 +98,16 @@ class FusedAdam(torch.optim.Optimizer):
             for p in group["params"]:
                 by_ptr[p.data_ptr()] = (p, group)
         P = None if means3D is None else means3D.shape[0]
-        sh_single = sh is not None and sh.numel() != 0 and sh.dim() == 3 and sh.shape[1] == 1 and (sh_rest is None or sh_rest.numel() == 0)
-        want = {_lib.SINK_MEANS3D: (means3D, 3, colors_given or sh_single), _lib.SINK_OPACITY: (opacities, 1, True),
+        has_rest = sh_rest is not None and sh_rest.numel() != 0
+        sh_dc = sh is not None and sh.numel() != 0 and sh.dim() == 3 and sh.shape[1] == 1
+        sh_single = sh_dc and not has_rest                             # one coefficient: finished by the preprocess backward
+        # split harmonics with 16 coefficients, 16-byte aligned: finished (with the positions) by the M = 16 spherical-harmonics launch
+        sh_split16 = sh_dc and has_rest and sh_rest.dim() == 3 and sh_rest.shape[1] == 15 and sh_rest.is_contiguous() and \
+            sh.data_ptr() % 16 == 0 and sh_rest.data_ptr() % 16 == 0
+        colour_ok = not colors_given and (sh_single or sh_split16)
+        want = {_lib.SINK_MEANS3D: (means3D, 3, colors_given or sh_single or sh_split16), _lib.SINK_OPACITY: (opacities, 1, True),
                 _lib.SINK_SCALES: (scales, 3, not cov3D_given), _lib.SINK_ROTATIONS: (rotations, 4, not cov3D_given),
-                _lib.SINK_SH: (sh, 3, sh_single and not colors_given)}
+                _lib.SINK_SH: (sh, 3, colour_ok), _lib.SINK_SH_REST: (sh_rest if has_rest else None, 45, colour_ok and sh_split16)}
         struct, owned, ptrs, keep, cfg, params = _lib.AdamSink(), set(), {}, [], None, []
         for leaf, (t, rf, allowed) in want.items():
             if t is None or not allowed or t.numel() == 0 or not t.requires_grad:
@@ -123,19 +130,26 @@ class FusedAdam(torch.optim.Optimizer):
             f.param, f.exp_avg, f.exp_avg_sq, f.lr, f.step = p.data_ptr(), m.data_ptr(), v.data_ptr(), lr_t.data_ptr(), step.data_ptr()
             owned.add(leaf); ptrs[leaf] = p.data_ptr(); keep += [p, m, v, lr_t, step]; params.append(p)
             self._aux_of(p)["counter_stale"] = True                   # k_adam's own step counters no longer follow state["step"]
+        if sh_split16 and (_lib.SINK_SH in owned) != (_lib.SINK_SH_REST in owned):      # the two colour blocks go together or not at all
+            for leaf in (_lib.SINK_SH, _lib.SINK_SH_REST):
+                if leaf in owned:
+                    owned.discard(leaf); ptrs.pop(leaf)
+                    f = struct.leaf[leaf]; f.param = f.exp_avg = f.exp_avg_sq = f.lr = f.step = None
         if not owned:
             return None
         dev = means3D.device
         coef = self._coef.get(dev)
         if coef is None:
-            coef = self._coef[dev] = torch.zeros(10, device=dev)
+            coef = self._coef[dev] = torch.zeros(12, device=dev)
         struct.beta1, struct.beta2, struct.eps, struct.coef = float(cfg[0][0]), float(cfg[0][1]), float(cfg[1]), coef.data_ptr()
         if self.active_rows is not None and P == self.active_rows[1]:
             struct.active_rows = self.active_rows[0].data_ptr()
             keep.append(self.active_rows[0])
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
-        return AdamSink(struct, owned, ptrs, keep + [coef], self, params)
+        sink = AdamSink(struct, owned, ptrs, keep + [coef], self, params)
+        sink.split16 = bool(sh_split16)
+        return sink
 
     def sync_lr(self):
         for group in self.param_groups:

@@ -238,26 +238,30 @@ int egs_backward(
  *     geometry buffer).  It is updated IN PLACE after its last read; exp_avg / exp_avg_sq have its shape, lr / step are device float[1]:
  *     torch's state["step"], advanced by one per call.  param == NULL: that leaf is not fused.
  *   - The dL_d* output of a fused leaf may be NULL (nothing written); if given, the gradient is written as well.
- *   - Conditions (else EGS_ERR_MODE): EGS_SINK_SCALES / EGS_SINK_ROTATIONS need scales + rotations (not cov3D_precomp);
- *     EGS_SINK_SH needs `shs` with sh_coeffs == 1 and no shs_rest; EGS_SINK_MEANS3D needs `colors_precomp` or such an `shs`
- *     (with more coefficients the view-direction term reaches dL_dmeans3D in a later launch).
+ *   - Conditions (else EGS_ERR_MODE): EGS_SINK_SCALES / EGS_SINK_ROTATIONS need scales + rotations (not cov3D_precomp).
+ *     Colour: either `shs` with sh_coeffs == 1 and no shs_rest (EGS_SINK_SH, and EGS_SINK_MEANS3D is then stepped by the same
+ *     kernel as the others), or split spherical harmonics with sh_coeffs == 16 and 16-byte aligned arrays: EGS_SINK_SH (the DC
+ *     block), EGS_SINK_SH_REST and EGS_SINK_MEANS3D are then stepped by the spherical-harmonics launch that finishes their gradients
+ *     (dL_dmeans3D must be given: it carries the partial gradient between the two launches); with `colors_precomp` only
+ *     EGS_SINK_MEANS3D of the three.  Any other colour layout: those three leaves cannot be fused.
  *   - skip_flag set: no step is taken and none is counted.  active_rows: rows >= *active_rows are left alone (capacity-sized
  *     models), as in egs_adam_step_capturable.
- *   - coef: device float[2 * EGS_SINK_LEAVES] scratch owned by the caller, written and read by this call only. */
+ *   - coef: device float[12] scratch owned by the caller, written and read by this call only. */
 #define EGS_SINK_MEANS3D   0    /* [P,3] */
 #define EGS_SINK_OPACITY   1    /* [P,1] */
 #define EGS_SINK_SCALES    2    /* [P,3] */
 #define EGS_SINK_ROTATIONS 3    /* [P,4] */
-#define EGS_SINK_SH        4    /* [P,1,3] */
+#define EGS_SINK_SH        4    /* [P,1,3]: `shs` when it has one coefficient, or the DC block of split spherical harmonics */
+#define EGS_SINK_SH_REST   5    /* [P,15,3]: `shs_rest` of split spherical harmonics with sh_coeffs == 16 */
 typedef struct egs_adam_leaf {
     float* param; float* exp_avg; float* exp_avg_sq;
     const float* lr;     /* device float[1] */
     float* step;         /* device float[1], in/out */
 } egs_adam_leaf;
 typedef struct egs_adam_sink {
-    egs_adam_leaf leaf[5];       /* indexed by EGS_SINK_* */
+    egs_adam_leaf leaf[6];       /* indexed by EGS_SINK_* */
     float beta1, beta2, eps;
-    float* coef;                 /* device float[10] scratch */
+    float* coef;                 /* device float[12] scratch */
     const int32_t* active_rows;  /* device int32[1] or NULL */
 } egs_adam_sink;
 int egs_backward_adam(

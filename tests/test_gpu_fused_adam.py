@@ -15,25 +15,31 @@ LEAVES = ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation")
 
 
 def _groups(pc):
-    return [{"params": [pc._xyz], "lr": 1.6e-4, "name": "xyz"}, {"params": [pc._features_dc], "lr": 2.5e-3, "name": "f_dc"},
-            {"params": [pc._opacity], "lr": 0.05, "name": "opacity"}, {"params": [pc._scaling], "lr": 5e-3, "name": "scaling"},
-            {"params": [pc._rotation], "lr": 1e-3, "name": "rotation"}]
+    g = [{"params": [pc._xyz], "lr": 1.6e-4, "name": "xyz"}, {"params": [pc._features_dc], "lr": 2.5e-3, "name": "f_dc"},
+         {"params": [pc._opacity], "lr": 0.05, "name": "opacity"}, {"params": [pc._scaling], "lr": 5e-3, "name": "scaling"},
+         {"params": [pc._rotation], "lr": 1e-3, "name": "rotation"}]
+    if pc._features_rest.numel():
+        g.append({"params": [pc._features_rest], "lr": 2.5e-3 / 20, "name": "f_rest"})      # gaussian_model.py:189
+    return g
 
 
-def _scene(N=12000, H=96, W=160, seed=0):
+def _scene(N=12000, H=96, W=160, seed=0, sh_degree=0):
     from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
     from egogaussian_amd.renderer import render
-    teacher = make_scene(N, H, W, seed); teacher["log_scale"] += math.log(2.0)
+    teacher = make_scene(N, H, W, seed, sh_degree=sh_degree); teacher["log_scale"] += math.log(2.0)
     cams = [make_camera(k, H, W, device=DEV) for k in (0, 40, 80, 120)]
     bg = torch.zeros(3, device=DEV)
     with torch.no_grad():
-        tpc = SynthGaussians(teacher, device=DEV, requires_grad=False)
+        tpc = SynthGaussians(teacher, device=DEV, sh_degree=sh_degree, requires_grad=False)
         gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
     return perturb_student(teacher), cams, gts, bg
 
 
-def test_fused_step_is_the_standalone_step_bit_for_bit():
-    """Four iterations; in each the backward steps the five leaves itself AND writes their gradients; a twin optimizer on copies of
+@pytest.mark.parametrize("sh_degree", [0, 3])
+def test_fused_step_is_the_standalone_step_bit_for_bit(sh_degree):
+    """(sh_degree 3: features_dc / features_rest handed over split, 16 coefficients -- those two and the positions are then stepped by
+    the spherical-harmonics launch, the other three by the preprocess backward.)
+    Four iterations; in each the backward steps the five leaves itself AND writes their gradients; a twin optimizer on copies of
     (parameter, exp_avg, exp_avg_sq) taken before the backward steps with those gradients through the stand-alone kernel: parameters,
     both moments and state["step"] must be equal bit for bit.  The fifth iteration goes the other way round -- the optimizer that was
     fused so far takes a stand-alone step (its own step counters are re-seeded from state["step"]) -- and must again agree."""
@@ -42,11 +48,12 @@ def test_fused_step_is_the_standalone_step_bit_for_bit():
     from egogaussian_amd.fused import l1_ssim_loss
     from egogaussian_amd.optim import FusedAdam
     import egogaussian_amd.optim as optim
-    student, cams, gts, bg = _scene()
-    pa = SynthGaussians(student, device=DEV)
+    student, cams, gts, bg = _scene(sh_degree=sh_degree)
+    pa = SynthGaussians(student, device=DEV, sh_degree=sh_degree)
     oa = FusedAdam(_groups(pa), lr=0.0, eps=1e-15, capturable=True)
-    pb = SynthGaussians(student, device=DEV)
+    pb = SynthGaussians(student, device=DEV, sh_degree=sh_degree)
     ob = FusedAdam(_groups(pb), lr=0.0, eps=1e-15, capturable=True)
+    LEAVES = globals()["LEAVES"] + (("_features_rest",) if sh_degree else ())
     real_make = oa.make_sink
 
     def keeping(**kw):
@@ -68,7 +75,7 @@ def test_fused_step_is_the_standalone_step_bit_for_bit():
         before = {a: getattr(pa, a).detach().clone() for a in LEAVES}
         loss.backward()
         if fused:
-            assert keeping.last.owned == {0, 1, 2, 3, 4}
+            assert keeping.last.owned == ({0, 1, 2, 3, 4, 5} if sh_degree else {0, 1, 2, 3, 4})
             for a in LEAVES:
                 g = getattr(pa, a).grad
                 assert g is not None and float(g.abs().max()) > 0            # (keep_grads) the gradient arrays were written too
