@@ -84,6 +84,29 @@ def _ptr(t):
     return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
 
 
+def _object_rotation_struct(object_rotation, dev, P):
+    """(egs_object_rotation struct or None, tensors to keep alive) from (M [3,3] or [9], selected uint8[P] / bool[P] or None, row-0 gradient
+    multiplier: float or float32[1] device tensor) -- fused.object_selection's result plugs in as (M,) + selection."""
+    if object_rotation is None:
+        return None, ()
+    M, sel, mult = object_rotation
+    M = _f32c(M.detach(), "object rotation").reshape(9)
+    keep = [M]
+    st = _lib.ObjectRotation()
+    st.M9 = M.data_ptr()
+    if sel is not None:
+        sel = sel.to(torch.uint8).contiguous()
+        if sel.numel() != P or sel.device != dev:
+            raise RuntimeError("object_rotation: `selected` must hold one byte per Gaussian on the rasterizer's device")
+        st.selected = sel.data_ptr(); keep.append(sel)
+    if torch.is_tensor(mult):
+        mult = mult.detach().float().reshape(1).contiguous()
+        st.row0_grad_mult, st.row0_grad_mult_dev = 1.0, mult.data_ptr(); keep.append(mult)
+    else:
+        st.row0_grad_mult = float(mult)
+    return st, tuple(keep)
+
+
 def _f32c(t, name):
     if t is None:
         return None
@@ -109,10 +132,12 @@ ACT_RAW_PARAMETERS = ACT_LOG_SCALES | ACT_RAW_QUATS | ACT_LOGIT_OPACITY
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, activation_flags=0, sh_rest=None, active_count=None, guard=None):
+                        prefiltered, debug, activation_flags=0, sh_rest=None, active_count=None, guard=None, object_rotation=None):
     """-> (num_rendered, color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer)
     active_count (extension): int32[1] device tensor, the number of live rows of a capacity-sized model (include/egs_raster.h);
     guard (extension): a StepGuard whose words a captured forward writes.
+    object_rotation (extension): (M, selected, row-0 gradient multiplier) -- the `fine_all` call shape's rotated covariance built
+    inside the rasterizer from scales + rotations (include/egs_raster.h egs_object_rotation); pass the same to the backward.
     sh_rest (extension): `sh` is then the DC block [P,1,3] and `sh_rest` the other coefficients [P,M-1,3] -- the two parameters the
     reference's GaussianModel stores, without the torch.cat of get_features (include/egs_raster.h: split spherical harmonics)."""
     L = _lib.load()
@@ -154,6 +179,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         binning = torch.empty((L.egs_binning_bytes(P, cap, W, H),), device=dev, dtype=torch.uint8)
         capturing = torch.cuda.is_current_stream_capturing()
         place = placement_buffer(dev, W, H)
+        rot_st, _rot_keep = _object_rotation_struct(object_rotation, dev, P)
+        rot_arg = C.byref(rot_st) if rot_st is not None else None
         if capturing:
             # hipGraph capture of a whole training step (egogaussian_amd/graph.py): nothing may wait on the host, so the
             # chain is enqueued against the capacity established by earlier eager calls and R is checked after replays.
@@ -164,7 +191,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), _ptr(background), W, H,
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
                 _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), None, _ptr(None if guard is None else guard.running_max),
-                _ptr(active_count), _ptr(None if guard is None else guard.overflow), _ptr(place), _stream()))
+                _ptr(active_count), _ptr(None if guard is None else guard.overflow), _ptr(place), rot_arg, _stream()))
             R = C.c_int64(cap)                      # layout size; the true count is stats["total_view"] after a sync
             rc = 0
         else:
@@ -172,7 +199,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
                                _ptr(campos), _ptr(background), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                                _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img), _ptr(out_color), _ptr(out_depth),
-                               _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _ptr(active_count), _ptr(place), _stream(), int(bool(debug)))
+                               _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _ptr(active_count), _ptr(place), rot_arg, _stream(),
+                               int(bool(debug)))
         if rc == _lib.RETRY_LARGER:
             cap = int(R.value * 1.25) + 65536
             binning = torch.empty((L.egs_binning_bytes(P, cap, W, H),), device=dev, dtype=torch.uint8)
@@ -207,7 +235,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alpha,
                                  debug, activation_flags=0, sh_rest=None, densify_stats=None, guard=None, sink=None,
-                                 prologue_scratch=None):
+                                 prologue_scratch=None, object_rotation=None):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
            dL_dscales[P,3], dL_drotations[P,4]); with sh_rest, dL_dsh is [P,1,3] and a ninth element dL_dsh_rest[P,M-1,3] follows.
     densify_stats (extension): (xyz_gradient_accum[P,1], denom[P,1], max_radii2D[P] or None), float32, updated in place by the kernel
@@ -249,7 +277,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dsh_rest = None if fused(_lib.SINK_SH_REST) else (e(*sh_rest.shape) if sh_rest is not None else None)
         dscales = None if fused(_lib.SINK_SCALES) else (e(P, 3) if own_cov else e(0, 3))   # absent inputs get empty gradients (the autograd Function maps them to None)
         drots = None if fused(_lib.SINK_ROTATIONS) else (e(P, 4) if own_cov else e(0, 4))
-        if P != 0 and (owned or prologue_scratch is not None):
+        rot_st, _rot_keep = _object_rotation_struct(object_rotation, dev, P)
+        if P != 0 and (owned or prologue_scratch is not None or rot_st is not None):
             scratch = prologue_scratch if prologue_scratch is not None else torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
             _lib.check(L.egs_backward_adam(
                 P, int(degree), M, int(R), _ptr(background), _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors), _ptr(scales),
@@ -258,7 +287,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(imageBuffer), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(dmeans2D), _ptr(dcolors),
                 _ptr(dopacity), _ptr(dmeans3D_arg), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
                 _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
-                C.byref(sink.struct) if owned else None, 1 if prologue_scratch is not None else 0, _ptr(scratch), _stream(), int(bool(debug))))
+                C.byref(sink.struct) if owned else None, 1 if prologue_scratch is not None else 0,
+                C.byref(rot_st) if rot_st is not None else None, _ptr(scratch), _stream(), int(bool(debug))))
             if owned:
                 sink.mark_stepped()
         elif P != 0:

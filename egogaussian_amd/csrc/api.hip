@@ -201,12 +201,21 @@ int egs_get_image_layout(int width, int height, egs_image_layout* out) {
     *out = img_layout(width, height).o; return 0;
 }
 
+// egs_object_rotation (HOST struct) -> kernel argument; needs the scales + rotations mode
+static int obj_rot_args(const egs_object_rotation* rot, const float* scales, EgsObjRot& r) {
+    r = EgsObjRot{ nullptr, nullptr, 1.f, nullptr };
+    if (!rot || !rot->M9) return 0;
+    if (!scales) return EGS_ERR_MODE;
+    r.M = rot->M9; r.sel = rot->selected; r.mult = rot->row0_grad_mult; r.mult_dev = rot->row0_grad_mult_dev;
+    return 0;
+}
+
 int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means3D, const float* shs, const float* shs_rest,
                          const float* colors_precomp, const float* opacities, const float* scales,
                          float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
                          const float* viewmatrix, const float* projmatrix, const float* campos, int width, int height,
                          float tan_fovx, float tan_fovy, int prefiltered, int32_t* radii, void* geom_buffer,
-                         int64_t* num_rendered, const int32_t* active_count, void* stream, int debug) {
+                         int64_t* num_rendered, const int32_t* active_count, const egs_object_rotation* rot, void* stream, int debug) {
     (void)prefiltered;
     int rc = check_dims(P, width, height); if (rc) return rc;
     if (!num_rendered) return EGS_ERR_ARG;
@@ -217,12 +226,13 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
     if (shs && (sh_degree < 0 || sh_degree > EGS_MAX_SH_DEGREE || sh_coeffs < (sh_degree + 1) * (sh_degree + 1))) return EGS_ERR_RANGE;
     if (shs_rest && (!shs || sh_coeffs < 2)) return EGS_ERR_MODE;
     hipStream_t s = (hipStream_t)stream;
+    EgsObjRot orot; rc = obj_rot_args(rot, scales, orot); if (rc) return rc;
     EgsGeomPtrs g = geom_ptrs(geom_buffer, P);
     EgsCamera cam = { viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy };
     egs_prof_start(EGS_K_PREPROCESS, s);
     const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);         // rows of 12 M bytes: the wave-tiled kernel (preprocess.hip)
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
-                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, nullptr, 0, active_count, nullptr, s));
+                                  rotations, activation_flags, cov3D_precomp, cam, radii, g, nullptr, 0, active_count, nullptr, orot, s));
     if (sh_apart) EGS_TRY(egs_launch_sh_forward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     EGS_SYNC_IF_DEBUG(s);
@@ -248,7 +258,8 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
                 const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                 int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                 float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
-                int64_t* num_rendered, const int32_t* active_count, uint32_t* overflow_flag, void* placement, void* stream, int debug) {
+                int64_t* num_rendered, const int32_t* active_count, uint32_t* overflow_flag, void* placement, const egs_object_rotation* rot,
+                void* stream, int debug) {
     (void)prefiltered;
     int rc = check_dims(P, width, height); if (rc) return rc;
     if (!num_rendered || capacity < 0 || capacity >= (1ll << 31)) return EGS_ERR_ARG;
@@ -264,6 +275,7 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp, activation_flags); if (rc) return rc;
     if (shs && (sh_degree < 0 || sh_degree > EGS_MAX_SH_DEGREE || sh_coeffs < (sh_degree + 1) * (sh_degree + 1))) return EGS_ERR_RANGE;
     if (shs_rest && (!shs || sh_coeffs < 2)) return EGS_ERR_MODE;
+    EgsObjRot orot; rc = obj_rot_args(rot, scales, orot); if (rc) return rc;
     static thread_local hipEvent_t ev = nullptr;
     if (wait_for_count && !ev) EGS_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     EgsGeomPtrs g = geom_ptrs(geom_buffer, P);
@@ -284,7 +296,7 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     placement_ptrs(placement, width, height, im_spec);
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
                                   rotations, activation_flags, cov3D_precomp, cam, radii, g, capacity > 0 ? b_spec.chunk_sum : nullptr, n_sums,
-                                  active_count, (capacity > 0 && placement) ? &im_spec : nullptr, s));
+                                  active_count, (capacity > 0 && placement) ? &im_spec : nullptr, orot, s));
     if (sh_apart) EGS_TRY(egs_launch_sh_forward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, g, s));
     egs_prof_stop(EGS_K_PREPROCESS, s);
     const size_t nb = ((size_t)P + 255) / 256;
@@ -315,11 +327,11 @@ int egs_forward(int P, int sh_degree, int sh_coeffs, const float* means3D, const
                 const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                 int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                 float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, int64_t* num_rendered,
-                const int32_t* active_count, void* placement, void* stream, int debug) {
+                const int32_t* active_count, void* placement, const egs_object_rotation* rot, void* stream, int debug) {
     return forward_impl(1, P, sh_degree, sh_coeffs, means3D, shs, shs_rest, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
-                        pinned_host_counts, nullptr, num_rendered, active_count, nullptr, placement, stream, debug);
+                        pinned_host_counts, nullptr, num_rendered, active_count, nullptr, placement, rot, stream, debug);
 }
 
 // Same chain with NO host wait: everything is only enqueued, so the call can be captured into a hipGraph.  Overflow of
@@ -332,12 +344,12 @@ int egs_forward_enqueue(int P, int sh_degree, int sh_coeffs, const float* means3
                         const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                         int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                         float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
-                        const int32_t* active_count, uint32_t* overflow_flag, void* placement, void* stream) {
+                        const int32_t* active_count, uint32_t* overflow_flag, void* placement, const egs_object_rotation* rot, void* stream) {
     int64_t unused = 0;
     return forward_impl(0, P, sh_degree, sh_coeffs, means3D, shs, shs_rest, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
-                        pinned_host_counts, running_max, &unused, active_count, overflow_flag, placement, stream, 0);
+                        pinned_host_counts, running_max, &unused, active_count, overflow_flag, placement, rot, stream, 0);
 }
 
 int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts) {
@@ -387,8 +399,10 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
                  const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
                  float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
                  float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
-                 const uint32_t* skip_flag, const egs_adam_sink* sink, int prologue_done, void* scratch, void* stream, int debug) {
+                 const uint32_t* skip_flag, const egs_adam_sink* sink, int prologue_done, const egs_object_rotation* rot, void* scratch,
+                 void* stream, int debug) {
     int rc = check_dims(P, width, height); if (rc) return rc;
+    EgsObjRot orot; rc = obj_rot_args(rot, scales, orot); if (rc) return rc;
     if (P == 0) return 0;
     if (R < 0 || R >= (1ll << 31)) return EGS_ERR_RANGE;
     if (!background || !means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer ||
@@ -460,7 +474,7 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
     EGS_TRY(egs_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, scales, scale_modifier, rotations,
                                            cov3D_precomp, activation_flags, cam, radii, g, grad_acc, colors_precomp != nullptr, dL_dmeans2D,
                                            dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, sh_apart ? nullptr : dL_dsh, dL_dscales,
-                                           dL_drotations, stat_grad_accum, stat_denom, stat_max_radii, skip_flag, pp_sinks ? &ks : nullptr, s));
+                                           dL_drotations, stat_grad_accum, stat_denom, stat_max_radii, skip_flag, pp_sinks ? &ks : nullptr, orot, s));
     if (sh_apart) EGS_TRY(egs_launch_sh_backward(P, sh_degree, sh_coeffs, means3D, shs, shs_rest, cam, radii, g, dL_dcolors, dL_dsh,
                                                  dL_dsh_rest, dL_dmeans3D, sh_sinks ? &ks_sh : nullptr, s));
     egs_prof_stop(EGS_K_PREPROCESS_BWD, s);
@@ -482,7 +496,7 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
                          cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, geom_buffer,
                          binning_buffer, image_buffer, dL_dout_color, dL_dout_depth, dL_dout_alpha, dL_dmeans2D, dL_dcolors, dL_dopacity,
                          dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscales, dL_drotations, stat_grad_accum, stat_denom, stat_max_radii,
-                         skip_flag, nullptr, 0, scratch, stream, debug);
+                         skip_flag, nullptr, 0, nullptr, scratch, stream, debug);
 }
 
 int egs_backward_adam(int P, int sh_degree, int sh_coeffs, int64_t R, const float* background, const float* means3D,
@@ -493,12 +507,13 @@ int egs_backward_adam(int P, int sh_degree, int sh_coeffs, int64_t R, const floa
                       const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
                       float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
                       float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
-                      const uint32_t* skip_flag, const egs_adam_sink* sink, int prologue_done, void* scratch, void* stream, int debug) {
+                      const uint32_t* skip_flag, const egs_adam_sink* sink, int prologue_done, const egs_object_rotation* rot, void* scratch,
+                      void* stream, int debug) {
     return backward_impl(P, sh_degree, sh_coeffs, R, background, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations,
                          cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, geom_buffer,
                          binning_buffer, image_buffer, dL_dout_color, dL_dout_depth, dL_dout_alpha, dL_dmeans2D, dL_dcolors, dL_dopacity,
                          dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscales, dL_drotations, stat_grad_accum, stat_denom, stat_max_radii,
-                         skip_flag, sink, prologue_done, scratch, stream, debug);
+                         skip_flag, sink, prologue_done, rot, scratch, stream, debug);
 }
 
 int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,

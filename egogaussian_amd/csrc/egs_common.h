@@ -105,6 +105,10 @@ __device__ __forceinline__ void egs_adam_tick(const EgsAdamTick& t, unsigned lan
     }
 }
 
+// The `fine_all` call shape inside the preprocess kernels (include/egs_raster.h egs_object_rotation): rows with sel[i] != 0 (all rows if
+// sel == NULL) get cov3D = (M R S)(M R S)^T.  M == NULL: nothing is moved.
+struct EgsObjRot { const float* M; const uint8_t* sel; float mult; const float* mult_dev; };
+
 // ---- launchers (host side, one per translation unit) -------------------------------------------
 struct EgsCamera {
     const float* view; const float* proj; const float* campos;
@@ -116,14 +120,14 @@ hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, cons
                                  const float* opac, const float* scales, float mod, const float* rots, int act,
                                  const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, uint32_t* zero_words, size_t zero_n,
                                  const int32_t* active_count, const EgsImgPtrs* place /*NULL, or: also order im.fwd_cost into im.fwd_order*/,
-                                 hipStream_t s);
+                                 EgsObjRot rot, hipStream_t s);
 hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* means3D, const float* shs,
                                           const float* scales, float mod, const float* rots, const float* cov3D, int act,
                                           EgsCamera cam, const int32_t* radii, EgsGeomPtrs g, const float* grad_acc,
                                           int colors_given, float* dmeans2D, float* dcolors, float* dopac,
                                           float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,
                                           float* stat_grad_accum, float* stat_denom, float* stat_max_radii, const uint32_t* skip_flag,
-                                          const EgsSink* sink /*NULL: gradients only*/, hipStream_t s);
+                                          const EgsSink* sink /*NULL: gradients only*/, EgsObjRot rot, hipStream_t s);
 // Spherical harmonics as separate launches (M > 1 coefficients, or DC / rest given as two arrays: sh_rest != NULL).  The
 // preprocess launchers are then called with shs = NULL: the forward leaves the record's colour open, the backward leaves
 // dL/dSH and the view-direction part of dL/dmean3D to egs_launch_sh_backward (which must run after it).

@@ -45,7 +45,9 @@ __device__ __forceinline__ void quat_to_rot(const float* q, float* R) {
 }
 
 // cov3D = (R S)(R S)^T, six unique entries (00,01,02,11,12,22); quaternion used as given.
-__device__ __forceinline__ void cov3d_from_scale_rot(const float* s, float mod, const float* q, float* c6) {
+// Mrot != NULL: the object rotation of the `fine_all` call shape, L <- M L, with the operation order of cov3d.hip (k_cov3d_forward), so
+// that the covariance -- hence radii, rectangles, sort order -- is the one the stand-alone producer would have handed over.
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* s, float mod, const float* q, float* c6, const float* Mrot = nullptr) {
     float R[9]; quat_to_rot(q, R);
     float sc[3] = { mod * s[0], mod * s[1], mod * s[2] };
     float L[9];
@@ -53,6 +55,15 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* s, float mod, 
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int k = 0; k < 3; k++) L[3 * i + k] = R[3 * i + k] * sc[k];
+    if (Mrot) {
+        float L2[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) L2[3 * i + j] = Mrot[3 * i] * L[j] + Mrot[3 * i + 1] * L[3 + j] + Mrot[3 * i + 2] * L[6 + j];
+#pragma unroll
+        for (int k = 0; k < 9; k++) L[k] = L2[k];
+    }
     c6[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
     c6[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
     c6[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8];
@@ -132,7 +143,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
     const float* __restrict__ rots, const float* __restrict__ cov3D_in, int act, const float* __restrict__ V,
     const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
-    uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible) {
+    uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible, const EgsObjRot rot) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     radii[i] = 0; tiles_touched[i] = 0; visible[i] = 0;
 
@@ -145,7 +156,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
         float s[3] = { scales[3 * i], scales[3 * i + 1], scales[3 * i + 2] };
         float q[4] = { rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3] };
         float qinv; activate_scale_rot(act, s, q, qinv);
-        cov3d_from_scale_rot(s, mod, q, c6);
+        cov3d_from_scale_rot(s, mod, q, c6, (rot.M && (!rot.sel || rot.sel[i])) ? rot.M : nullptr);
     }
     Ewa e; ewa_project(p, c6, V, W, H, tanfovx, tanfovy, e);
     if (e.t[2] <= 0.2f) return 0u;                                // near-plane cull
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
     uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible,
     uint32_t* __restrict__ block_sums, uint32_t* __restrict__ zero_words, size_t zero_n, const int32_t* __restrict__ active_count,
-    EgsPrologueArgs place) {
+    EgsPrologueArgs place, EgsObjRot rot) {
     __shared__ uint32_t wsum[4];
     if (PLACE) {
         __shared__ EgsOrderLds order_lds;
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
     const int live = active_count ? min(P, max(*active_count, 0)) : P;
     if (i >= live && i < P) { radii[i] = 0; tiles_touched[i] = 0; visible[i] = 0; }
     if (i < live) my_tiles = preprocess_one(i, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D_in, act, V, PM, campos, W, H,
-                                         tanfovx, tanfovy, radii, rec, rect_out, tiles_touched, clamped_out, visible);
+                                         tanfovx, tanfovy, radii, rec, rect_out, tiles_touched, clamped_out, visible, rot);
     // per-block instance count; the host adds the block sums to get R (no contended atomic, deterministic)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) my_tiles += (uint32_t)__shfl_xor((int)my_tiles, d, 64);
@@ -274,7 +285,7 @@ __device__ __forceinline__ void pp_bwd_one(
     float* __restrict__ dopac, float* __restrict__ dmeans3D, float* __restrict__ dcov3D, float* __restrict__ dsh,
     float* __restrict__ dscales, float* __restrict__ drots,
     float* __restrict__ stat_grad_accum, float* __restrict__ stat_denom, float* __restrict__ stat_max_radii,
-    const uint32_t* __restrict__ skip_flag, float* __restrict__ stage, const unsigned fused) {
+    const uint32_t* __restrict__ skip_flag, float* __restrict__ stage, const unsigned fused, const EgsObjRot rot) {
     // SINK: the gradients of the leaves in `fused` (bit = EGS_SINK_*) also go to `stage` (LDS), from where the workgroup applies
     // Adam to its 256 rows; their dX arrays may then be NULL (nothing written)
     const unsigned tid = threadIdx.x;
@@ -341,7 +352,7 @@ __device__ __forceinline__ void pp_bwd_one(
         s[0] = scales[3 * i]; s[1] = scales[3 * i + 1]; s[2] = scales[3 * i + 2];
         q[0] = rots[4 * i]; q[1] = rots[4 * i + 1]; q[2] = rots[4 * i + 2]; q[3] = rots[4 * i + 3];
         activate_scale_rot(act, s, q, qinv);
-        cov3d_from_scale_rot(s, mod, q, c6);
+        cov3d_from_scale_rot(s, mod, q, c6, (rot.M && (!rot.sel || rot.sel[i])) ? rot.M : nullptr);
     }
     Ewa e; ewa_project(p, c6, V, W, H, tanfovx, tanfovy, e);
 
@@ -463,11 +474,34 @@ __device__ __forceinline__ void pp_bwd_one(
         for (int a = 0; a < 3; a++)
 #pragma unroll
             for (int k = 0; k < 3; k++) L[3 * a + k] = Rm[3 * a + k] * sc[k];
+        // object rotation (egs_object_rotation; operation for operation k_cov3d_backward of cov3d.hip): L = M L0, dL/dL0 = M^T dL/dL, and
+        // the reference's duplicated-index multiplier on row 0 (covariance.py)
+        const bool moved = rot.M && (!rot.sel || rot.sel[i]);
+        float Mm[9];
+        if (moved) {
+            float L0[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) { Mm[k] = rot.M[k]; L0[k] = L[k]; }
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) L[3 * a + b] = Mm[3 * a] * L0[b] + Mm[3 * a + 1] * L0[3 + b] + Mm[3 * a + 2] * L0[6 + b];
+        }
+        const float mult = (moved && i == 0) ? (rot.mult_dev ? rot.mult_dev[0] : rot.mult) : 1.f;
 #pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
             for (int k = 0; k < 3; k++)
-                gL[3 * a + k] = 2.f * (Gs[3 * a] * L[k] + Gs[3 * a + 1] * L[3 + k] + Gs[3 * a + 2] * L[6 + k]);
+                gL[3 * a + k] = (Gs[3 * a] * L[k] + Gs[3 * a + 1] * L[3 + k] + Gs[3 * a + 2] * L[6 + k]) * (2.f * mult);
+        if (moved) {
+            float g0[9];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) g0[3 * a + b] = Mm[a] * gL[b] + Mm[3 + a] * gL[3 + b] + Mm[6 + a] * gL[6 + b];
+#pragma unroll
+            for (int k = 0; k < 9; k++) gL[k] = g0[k];
+        }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const float ds = mod * (gL[k] * Rm[k] + gL[3 + k] * Rm[3 + k] + gL[6 + k] * Rm[6 + k]);
@@ -509,7 +543,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     float* __restrict__ dopac, float* __restrict__ dmeans3D, float* __restrict__ dcov3D, float* __restrict__ dsh,
     float* __restrict__ dscales, float* __restrict__ drots,
     float* __restrict__ stat_grad_accum, float* __restrict__ stat_denom, float* __restrict__ stat_max_radii,
-    const uint32_t* __restrict__ skip_flag, EgsSink sink) {
+    const uint32_t* __restrict__ skip_flag, EgsSink sink, EgsObjRot rot) {
     __shared__ __attribute__((aligned(16))) float stage[SINK ? 4 * EGS_SINK_TASKS : 4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned fused = 0;
@@ -520,7 +554,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     if (i < P)
         pp_bwd_one<SINK>(i, D, M, means3D, shs, scales, mod, rots, cov3D_in, act, V, PM, campos, W, H, tanfovx, tanfovy, radii, clamped, rec,
                          grad_acc, dmeans2D, dcolors, dopac, dmeans3D, dcov3D, dsh, dscales, drots, stat_grad_accum, stat_denom,
-                         stat_max_radii, skip_flag, stage, fused);
+                         stat_max_radii, skip_flag, stage, fused, rot);
     if (!SINK) return;
     __syncthreads();
     if (sink.skip && *sink.skip) return;                            // the frame overflowed its instance capacity: no step (and none was counted)
@@ -1103,7 +1137,7 @@ hipError_t egs_launch_zero_f4(float4* p, size_t n4, hipStream_t s) {
 hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
                                  const float* opac, const float* scales, float mod, const float* rots, int act,
                                  const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, uint32_t* zero_words, size_t zero_n,
-                                 const int32_t* active_count, const EgsImgPtrs* place, hipStream_t s) {
+                                 const int32_t* active_count, const EgsImgPtrs* place, EgsObjRot rot, hipStream_t s) {
     if (P == 0) return hipSuccess;
     if (!zero_words) zero_n = 0;
     EgsPrologueArgs pa = {};
@@ -1112,9 +1146,9 @@ hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, cons
     if (place) {
         pa.n_tiles = ((cam.W + EGS_TILE - 1) / EGS_TILE) * ((cam.H + EGS_TILE - 1) / EGS_TILE);
         pa.quad_work = place->fwd_cost; pa.tile_order = place->fwd_order;
-        hipLaunchKernelGGL(k_preprocess<true>, dim3((P + 255) / 256 + EGS_XCDS), dim3(256), 0, s, PP_ARGS, pa);
+        hipLaunchKernelGGL(k_preprocess<true>, dim3((P + 255) / 256 + EGS_XCDS), dim3(256), 0, s, PP_ARGS, pa, rot);
     } else {
-        hipLaunchKernelGGL(k_preprocess<false>, dim3((P + 255) / 256), dim3(256), 0, s, PP_ARGS, pa);
+        hipLaunchKernelGGL(k_preprocess<false>, dim3((P + 255) / 256), dim3(256), 0, s, PP_ARGS, pa, rot);
     }
 #undef PP_ARGS
     return hipGetLastError();
@@ -1126,15 +1160,15 @@ hipError_t egs_launch_preprocess_backward(int P, int D, int M, const float* mean
                                           int colors_given, float* dmeans2D, float* dcolors, float* dopac,
                                           float* dmeans3D, float* dcov3D, float* dsh, float* dscales, float* drots,
                                           float* stat_grad_accum, float* stat_denom, float* stat_max_radii, const uint32_t* skip_flag,
-                                          const EgsSink* sink, hipStream_t s) {
+                                          const EgsSink* sink, EgsObjRot rot, hipStream_t s) {
     if (P == 0) return hipSuccess;
     EgsSink none = {};
 #define PPB_ARGS P, D, M, means3D, colors_given ? nullptr : shs, scales, mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W, \
                  cam.H, cam.tanfovx, cam.tanfovy, radii, g.clamped, g.rec, grad_acc, dmeans2D, dcolors, dopac, dmeans3D, \
                  dcov3D, colors_given ? nullptr : dsh, cov3D ? nullptr : dscales, cov3D ? nullptr : drots, \
                  stat_grad_accum, stat_denom, stat_max_radii, skip_flag
-    if (sink) hipLaunchKernelGGL(k_preprocess_backward<true>, dim3((P + 255) / 256), dim3(256), 0, s, PPB_ARGS, *sink);
-    else hipLaunchKernelGGL(k_preprocess_backward<false>, dim3((P + 255) / 256), dim3(256), 0, s, PPB_ARGS, none);
+    if (sink) hipLaunchKernelGGL(k_preprocess_backward<true>, dim3((P + 255) / 256), dim3(256), 0, s, PPB_ARGS, *sink, rot);
+    else hipLaunchKernelGGL(k_preprocess_backward<false>, dim3((P + 255) / 256), dim3(256), 0, s, PPB_ARGS, none, rot);
 #undef PPB_ARGS
     return hipGetLastError();
 }

@@ -36,6 +36,10 @@ class AdamSink(C.Structure):                     # egs_adam_sink
                 ("active_rows", C.c_void_p)]
 
 
+class ObjectRotation(C.Structure):               # egs_object_rotation
+    _fields_ = [("M9", C.c_void_p), ("selected", C.c_void_p), ("row0_grad_mult", C.c_float), ("row0_grad_mult_dev", C.c_void_p)]
+
+
 class BackwardPrologue(C.Structure):             # egs_backward_prologue
     _fields_ = [("P", C.c_int), ("width", C.c_int), ("height", C.c_int), ("image_buffer", C.c_void_p), ("scratch", C.c_void_p),
                 ("sink", C.POINTER(AdamSink)), ("skip_flag", C.c_void_p)]
@@ -56,18 +60,18 @@ SIGNATURES = {
     "egs_get_binning_layout": (C.c_int, [i32, i64, i32, i32, C.POINTER(BinningLayout)]),
     "egs_get_image_layout": (C.c_int, [i32, i32, C.POINTER(ImageLayout)]),
     "egs_forward_geometry": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
-                                       i32, vp, vp, C.POINTER(i64), vp, vp, i32]),
+                                       i32, vp, vp, C.POINTER(i64), vp, C.POINTER(ObjectRotation), vp, i32]),
     "egs_forward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, i64,
-                               vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp, vp, vp, i32]),
+                               vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp, vp, C.POINTER(ObjectRotation), vp, i32]),
     "egs_forward_enqueue": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp,
-                                       i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+                                       i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(ObjectRotation), vp]),
     "egs_placement_bytes": (C.c_size_t, [i32, i32]),
     "egs_sum_counts": (C.c_int64, [i32, vp]),
     "egs_forward_render": (C.c_int, [i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_backward": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
                                vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
     "egs_backward_adam": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
-                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(AdamSink), i32, vp, vp, i32]),
+                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(AdamSink), i32, C.POINTER(ObjectRotation), vp, vp, i32]),
     "egs_mark_visible": (C.c_int, [i32, vp, vp, vp, vp, vp]),
     "egs_cov3d_forward": (C.c_int, [i32, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_cov3d_dm_scratch_floats": (C.c_size_t, [i32]),

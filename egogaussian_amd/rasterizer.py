@@ -39,8 +39,10 @@ class GaussianRasterizationSettings(NamedTuple):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None, optimizer=None):
+                activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None, optimizer=None,
+                object_rotation=None):
         rs = raster_settings
+        ctx.object_rotation = object_rotation     # (M, selected, multiplier): constants of the loss (include/egs_raster.h egs_object_rotation)
         # optimizer (extension): a FusedAdam(capturable=True) whose leaves among THIS call's inputs take their step inside the backward
         ctx.sink = None if (optimizer is None or not any(ctx.needs_input_grad)) else optimizer.make_sink(
             means3D=means3D, opacities=opacities, scales=scales, rotations=rotations, sh=sh, sh_rest=sh_rest,
@@ -50,7 +52,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
-            rs.campos, rs.prefiltered, rs.debug, activation_flags, sh_rest, active_count, guard)
+            rs.campos, rs.prefiltered, rs.debug, activation_flags, sh_rest, active_count, guard, object_rotation)
         ctx.guard = guard
         ctx.egs_raster_node = True                  # fused.l1_ssim_loss(raster_prologue=True) recognises its input's grad_fn by this
         ctx.prologue_scratch = None
@@ -84,14 +86,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos, geom,
             ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags, sh_rest if split else None, ctx.densify_stats, ctx.guard,
-            ctx.sink, ctx.prologue_scratch)
+            ctx.sink, ctx.prologue_scratch, ctx.object_rotation)
         ctx.prologue_scratch = None
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = grads[:8]
         none_if_absent = lambda g, x: g if (g is not None and x.numel() != 0) else None
         return (g_means3D, g_means2D, none_if_absent(g_sh, sh), none_if_absent(g_colors, colors_precomp),
                 g_opac, none_if_absent(g_scales, scales),
                 none_if_absent(g_rots, rotations), none_if_absent(g_cov3D, cov3Ds_precomp), None, None,
-                grads[8] if split else None, None, None, None, None)
+                grads[8] if split else None, None, None, None, None, None)
 
 
 def backward_prologue_of(node):
@@ -123,11 +125,13 @@ def backward_prologue_of(node):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None, optimizer=None):
+                        raster_settings, activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None, optimizer=None,
+                        object_rotation=None):
     """-> (color, radii, depth, alpha, visible); upstream's function returns the first four, `visible` (bool[P] = radii > 0) is an
     extension GaussianRasterizer keeps for render()."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, activation_flags, sh_rest, densify_stats, active_count, guard, optimizer)
+                                     cov3Ds_precomp, raster_settings, activation_flags, sh_rest, densify_stats, active_count, guard, optimizer,
+                                     object_rotation)
 
 
 class GaussianRasterizer(nn.Module):
@@ -142,7 +146,8 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, raw_parameters=False, densify_stats=None, active_count=None, guard=None, optimizer=None):
+                cov3D_precomp=None, raw_parameters=False, densify_stats=None, active_count=None, guard=None, optimizer=None,
+                object_rotation=None):
         """Same call as upstream's.  raw_parameters=True (an extension): `scales`, `rotations` and `opacities` are the model's RAW
         parameters (log-scales, unnormalised quaternions, opacity logits); the activations run inside the preprocess kernel and
         the gradients come back w.r.t. the raw tensors (include/egs_raster.h, EGS_ACT_*).
@@ -151,6 +156,9 @@ class GaussianRasterizer(nn.Module):
         # densify_stats (an extension): (xyz_gradient_accum, denom, max_radii2D or None) -- the backward updates the trainer's
         # densification statistics in place, in the kernel that produces the screen-space gradient (include/egs_raster.h)
         # active_count (an extension): int32[1] device tensor = live rows of a capacity-sized model; guard: a _C.StepGuard
+        # object_rotation (an extension): (M [3,3], selected [P] or None, row-0 gradient multiplier) with `scales` + `rotations`: the
+        # covariance of the selected rows is (M R S)(M R S)^T, built inside the rasterizer -- the reference's render(rot_cov=True,
+        # accum_R, which_object) without a covariance tensor; M is a constant of the loss (include/egs_raster.h egs_object_rotation)
         # optimizer (an extension): a FusedAdam(capturable=True).  Every input of this call that IS one of its parameters takes its
         # Adam step inside the backward (its .grad stays None and optimizer.step() skips it) -- only valid when this call is the
         # sole consumer of those parameters in the backward pass (optim.FusedAdam.make_sink)
@@ -172,9 +180,9 @@ class GaussianRasterizer(nn.Module):
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
-        if raw_parameters and cov3D_precomp.numel() != 0:
-            raise Exception("GaussianRasterizer: raw_parameters needs `scales` and `rotations`, not `cov3D_precomp`")
+        if (raw_parameters or object_rotation is not None) and cov3D_precomp.numel() != 0:
+            raise Exception("GaussianRasterizer: raw_parameters / object_rotation need `scales` and `rotations`, not `cov3D_precomp`")
         color, radii, depth, alpha, self.visible = rasterize_gaussians(
             means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, self.raster_settings,
-            _C.ACT_RAW_PARAMETERS if raw_parameters else 0, shs_rest, densify_stats, active_count, guard, optimizer)
+            _C.ACT_RAW_PARAMETERS if raw_parameters else 0, shs_rest, densify_stats, active_count, guard, optimizer, object_rotation)
         return color, radii, depth, alpha

@@ -54,8 +54,16 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
 
     scales = rotations = cov3D_precomp = opacity = None
     raw = False
+    object_rotation = None
     if pipe.compute_cov3D_python:
-        if rot_cov:
+        rotated_raw = pc.get_raw_parameters_rotated(accum_R, which_object, during_training) \
+            if (rot_cov and getattr(pc, "get_raw_parameters_rotated", None) is not None) else None
+        if rotated_raw is not None:
+            # optional hook: the RAW parameters plus (M, selected rows, row-0 multiplier) -- the rasterizer builds the object-rotated
+            # covariance itself (rasterizer.py object_rotation): no covariance tensor, no producer launches either way
+            scales, rotations, opacity, object_rotation = rotated_raw
+            raw = True
+        elif rot_cov:
             if getattr(pc, "get_rotated_covariance_and_opacity", None) is not None:
                 # optional fused producer: rotated covariance and activated opacity from the raw parameters in one launch
                 cov3D_precomp, opacity = pc.get_rotated_covariance_and_opacity(accum_R, which_object, during_training, scaling_modifier)
@@ -95,7 +103,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
                                             **({"densify_stats": (pc.xyz_gradient_accum, pc.denom, pc.max_radii2D)} if fused_densify_stats else {}),
                                             **({"active_count": pc.active_count} if getattr(pc, "active_count", None) is not None else {}),
                                             **({"guard": guard} if guard is not None else {}),
-                                            **({"optimizer": optimizer} if optimizer is not None else {}))
+                                            **({"optimizer": optimizer} if optimizer is not None else {}),
+                                            **({"object_rotation": object_rotation} if object_rotation is not None else {}))
     visible = rasterizer.visible                           # radii > 0 from the preprocess kernel of THIS call (returned, not shared state)
     if visible is None:
         visible = radii > 0

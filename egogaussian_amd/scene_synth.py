@@ -123,6 +123,7 @@ class SynthGaussians:
         from . import covariance as _cov
         self._cov = _cov
         self.fused = fused            # use the fused HIP covariance producer (row f-1) when on a HIP device
+        self.rotate_in_rasterizer = True   # render(rot_cov=True): hand the raw parameters + object rotation to the rasterizer (else: fused producer)
         t = lambda a: torch.tensor(a, device=device).requires_grad_(requires_grad)
         self._xyz = t(scene["xyz"])
         self._features_dc = t(scene["features"][:, :1].copy())
@@ -196,6 +197,20 @@ class SynthGaussians:
         if self.fused and self._xyz.is_cuda:
             return self._scaling, self._rotation, self._opacity
         return None
+
+    def get_raw_parameters_rotated(self, accum_R, which_object, during_training):
+        """Optional hook render(rot_cov=True) looks for: (log-scales, raw quaternions, opacity logits, (M, selected, row-0 gradient
+        multiplier)) for the rasterizer's object_rotation mode -- the `fine_all` call shape with no covariance tensor at all.  None
+        when the object rotation is being trained (its gradient needs the covariance path) or off a HIP device."""
+        if not (self.fused and self._xyz.is_cuda and self.rotate_in_rasterizer):
+            return None
+        if during_training and self.trainable_object_move is not None:
+            return None
+        M = torch.eye(3, device=self._xyz.device) if accum_R is None else accum_R
+        if M.requires_grad:
+            return None
+        sel, mult = self._object_selection(which_object)
+        return self._scaling, self._rotation, self._opacity, (M, sel, mult)
 
     def get_covariance_and_opacity(self, scaling_modifier=1):
         """Optional hook render() looks for: covariance and activated opacity from one fused launch (HIP devices only)."""

@@ -56,35 +56,35 @@ def test_argument_errors_precede_device_work():
     none = None
     # null required pointers
     rc = L.egs_forward_geometry(10, 0, 1, none, none, none, none, none, none, 1.0, none, none, 0, none, none, none, 64, 64, 1.0, 1.0, 0,
-                                none, none, C.byref(R), none, none, 0)
+                                none, none, C.byref(R), none, none, none, 0)
     assert rc == -1 and R.value == 0
     assert L.egs_forward_geometry(-1, 0, 1, none, none, none, none, none, none, 1.0, none, none, 0, none, none, none, 64, 64, 1.0, 1.0, 0,
-                                  none, none, C.byref(R), none, none, 0) == -1
+                                  none, none, C.byref(R), none, none, none, 0) == -1
     assert L.egs_forward_geometry(10, 0, 1, none, none, none, none, none, none, 1.0, none, none, 0, none, none, none, 70000, 64, 1.0, 1.0,
-                                  0, none, none, C.byref(R), none, none, 0) == -3
+                                  0, none, none, C.byref(R), none, none, none, 0) == -3
     assert L.egs_forward_geometry(10, 0, 1, none, none, none, none, none, none, 1.0, none, none, 0, none, none, none, 8192, 8192, 1.0, 1.0,
-                                  0, none, none, C.byref(R), none, none, 0) == -3      # 262144 tiles > 36864 (one LDS counter per tile)
+                                  0, none, none, C.byref(R), none, none, none, 0) == -3      # 262144 tiles > 36864 (one LDS counter per tile)
     # P == 0 is a valid no-op
     assert L.egs_forward_geometry(0, 0, 0, none, none, none, none, none, none, 1.0, none, none, 0, none, none, none, 64, 64, 1.0, 1.0, 0,
-                                  none, none, C.byref(R), none, none, 0) == 0 and R.value == 0
+                                  none, none, C.byref(R), none, none, none, 0) == 0 and R.value == 0
     # mode errors: both shs and colours given (fake non-null pointers are never dereferenced before the check)
     p = C.c_void_p(4096)
     assert L.egs_forward_geometry(10, 0, 1, p, p, none, p, p, none, 1.0, none, p, 0, p, p, p, 64, 64, 1.0, 1.0, 0, p, p, C.byref(R),
-                                  none, none, 0) == -2
+                                  none, none, none, 0) == -2
     assert L.egs_forward_geometry(10, 0, 1, p, p, none, none, p, p, 1.0, none, none, 0, p, p, p, 64, 64, 1.0, 1.0, 0, p, p, C.byref(R),
-                                  none, none, 0) == -2      # scales without rotations
+                                  none, none, none, 0) == -2      # scales without rotations
     assert L.egs_forward_geometry(10, 4, 25, p, p, none, none, p, none, 1.0, none, p, 0, p, p, p, 64, 64, 1.0, 1.0, 0, p, p, C.byref(R),
-                                  none, none, 0) == -3      # SH degree 4 unsupported
+                                  none, none, none, 0) == -3      # SH degree 4 unsupported
     assert L.egs_forward_geometry(10, 0, 1, p, p, none, none, p, none, 1.0, none, p, 1, p, p, p, 64, 64, 1.0, 1.0, 0, p, p, C.byref(R),
-                                  none, none, 0) == -2      # log-scale activation asked for, but the covariance is given
+                                  none, none, none, 0) == -2      # log-scale activation asked for, but the covariance is given
     assert L.egs_forward_geometry(10, 0, 1, p, p, none, none, p, p, 1.0, p, none, 8, p, p, p, 64, 64, 1.0, 1.0, 0, p, p, C.byref(R),
-                                  none, none, 0) == -2      # unknown activation flag
+                                  none, none, none, 0) == -2      # unknown activation flag
     assert L.egs_forward_geometry(10, 0, 1, p, p, p, none, p, none, 1.0, none, p, 0, p, p, p, 64, 64, 1.0, 1.0, 0, p, p, C.byref(R),
-                                  none, none, 0) == -2      # split spherical harmonics need at least two coefficients
+                                  none, none, none, 0) == -2      # split spherical harmonics need at least two coefficients
     assert b"exactly one" in L.egs_error_string(-2) and b"capacity" in L.egs_error_string(lib.RETRY_LARGER)
     # one-call forward: argument errors before any device work
     assert L.egs_forward(10, 0, 1, none, none, none, none, none, none, 1.0, none, none, 0, none, none, none, none, 64, 64, 1.0, 1.0, 0,
-                         none, none, 100, none, none, none, none, none, none, C.byref(R), none, none, none, 0) == -1
+                         none, none, 100, none, none, none, none, none, none, C.byref(R), none, none, none, none, 0) == -1
     assert L.egs_placement_bytes(960, 540) >= (2040 * 4 + 2040) * 4 and L.egs_placement_bytes(0, 5) == 0
     assert L.egs_mark_visible(5, none, none, none, none, none) == -1
 

@@ -401,3 +401,43 @@ def test_l1_ssim_deferred_value_and_running_sum():
     (l0, a0, g0), (l1, a1, g1) = res
     assert abs(l0 - l1) < 1e-6 * max(1.0, abs(l0)) and abs(a0 - a1) < 1e-5 and abs(a1 - 10.0 - l1) < 1e-5
     assert torch.equal(g0, g1)
+
+
+def test_object_rotation_inside_the_rasterizer_matches_the_covariance_path():
+    """render(rot_cov=True, accum_R, which_object=1) with the covariance of the object's rows rotated INSIDE the preprocess kernels
+    (egs_object_rotation) against the same call through the fused covariance producer (cov3D_precomp): identical covariance arithmetic,
+    so radii and images are equal bit for bit; parameter gradients equal up to the order of the backward's float atomics -- including
+    row 0, which the reference's [N,1]-index quirk rotates and whose gradient it multiplies (covariance.py)."""
+    import math
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.fused import l1_ssim_loss
+    N, H, W = 12000, 96, 160
+    teacher = make_scene(N, H, W, 3); teacher["log_scale"] += math.log(2.0)
+    student = perturb_student(teacher)
+    gen = torch.Generator().manual_seed(4)
+    is_obj = (torch.rand(N, 1, generator=gen) < 0.3).float().to(DEV)
+    is_obj[0, 0] = 0.0                                                   # row 0 is background: only the quirk moves it
+    cam, bg = make_camera(30, H, W, device=DEV), torch.zeros(3, device=DEV)
+    c, s_ = math.cos(0.7), math.sin(0.7)
+    R = torch.tensor([[c, -s_, 0.0], [s_, c * 0.9, -0.3], [0.1, 0.3, 0.95]], device=DEV)     # (any 3x3: nothing requires a rotation)
+    gt = torch.rand(3, H, W, generator=gen).to(DEV)
+    outs = []
+    for inside in (True, False):
+        pc = SynthGaussians(student, device=DEV); pc._is_object = is_obj
+        pc.rotate_in_rasterizer = inside
+        out = render(cam, pc, Pipe, bg, rot_cov=True, accum_R=R, which_object=1, during_training=False)
+        l1_ssim_loss(out["render"], gt, 0.2).backward()
+        torch.cuda.synchronize()
+        outs.append((out, pc))
+    (oa, pa), (ob, pb) = outs
+    assert torch.equal(oa["radii"], ob["radii"]) and int((oa["radii"] > 0).sum()) > 1000
+    for k in ("render", "depth", "alpha"):
+        assert torch.equal(oa[k], ob[k]), k
+    for name in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"):
+        ga, gb = getattr(pa, name).grad, getattr(pb, name).grad
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-9, name
+    assert float(pa._scaling.grad[0].abs().max()) > 0                    # row 0 saw the rotation (and the multiplier) on both paths
+    # and a rotation that is being trained keeps the covariance path (its gradient needs it)
+    pc = SynthGaussians(student, device=DEV); pc._is_object = is_obj
+    assert pc.get_raw_parameters_rotated(R.clone().requires_grad_(True), 1, False) is None

@@ -160,9 +160,10 @@ def test_graph_step_with_and_without_fused_optimizer_agree():
 
 
 def test_partial_sinks_follow_the_library_conditions():
-    """cov3D_precomp given (the `fine_all` call shape): scaling / rotation / opacity reach the rasterizer as activations, so only xyz
-    and features_dc are owned and the other three are stepped by optimizer.step() from their gradient arrays; colours precomputed:
-    only xyz can be owned."""
+    """cov3D_precomp given (the `fine_all` call shape through the covariance producer): scaling / rotation / opacity reach the
+    rasterizer as activations, so only xyz and features_dc are owned and the other three are stepped by optimizer.step() from their
+    gradient arrays; the same call with the object rotation inside the rasterizer: all five are owned; colours precomputed: only xyz
+    can be owned."""
     from egogaussian_amd.scene_synth import SynthGaussians, Pipe
     from egogaussian_amd.renderer import render
     from egogaussian_amd.fused import l1_ssim_loss
@@ -175,6 +176,7 @@ def test_partial_sinks_follow_the_library_conditions():
     seen = []
     real = opt.make_sink
     opt.make_sink = lambda **kw: seen.append(real(**kw)) or seen[-1]
+    pc.rotate_in_rasterizer = False                                  # (the producer path: cov3D_precomp + activated opacity)
     out = render(cams[0], pc, Pipe, bg, rot_cov=True, accum_R=torch.eye(3, device=DEV), which_object=1, during_training=False, optimizer=opt)
     l1_ssim_loss(out["render"], gts[0], 0.2).backward()
     opt.step(); opt.zero_grad(set_to_none=True)
@@ -182,6 +184,16 @@ def test_partial_sinks_follow_the_library_conditions():
     assert seen[-1].owned == {lib.SINK_MEANS3D, lib.SINK_SH}
     for a in LEAVES:
         assert float(opt.state[getattr(pc, a)]["step"]) == 1.0, a
+    pc.rotate_in_rasterizer = True
+    out = render(cams[0], pc, Pipe, bg, rot_cov=True, accum_R=torch.eye(3, device=DEV), which_object=1, during_training=False, optimizer=opt)
+    l1_ssim_loss(out["render"], gts[0], 0.2).backward()
+    opt.step(); opt.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    assert seen[-1].owned == {0, 1, 2, 3, 4} and all(getattr(pc, a).grad is None for a in LEAVES)
+    for a in LEAVES:
+        assert float(opt.state[getattr(pc, a)]["step"]) == 2.0, a
+    for a in LEAVES:                                                 # (the counts below start from here)
+        opt.state[getattr(pc, a)]["step"].fill_(1.0)
     out = render(cams[1], pc, Pipe, bg, override_color=torch.rand(pc.get_xyz.shape[0], 3, device=DEV), optimizer=opt)
     l1_ssim_loss(out["render"], gts[1], 0.2).backward()
     opt.step(); opt.zero_grad(set_to_none=True)
@@ -212,7 +224,7 @@ def test_c_abi_rejects_inconsistent_sinks():
                                    None if use_cov else vp(rots), vp(cov) if use_cov else None, 0, vp(cam), vp(cam), vp(pos), W, H, 1.0, 1.0,
                                    vp(radii), vp(geom), None, vp(img), vp(gcol), None, None, vp(z(P, 3)), vp(z(P, 3)), vp(z(P, 1)), vp(z(P, 3)),
                                    vp(z(P, 6)) if use_cov else None, vp(z(P, 1, 3)), None, None if use_cov else vp(z(P, 3)),
-                                   None if use_cov else vp(z(P, 4)), None, None, None, None, C.byref(sink), 0, vp(scratch), None, 0)
+                                   None if use_cov else vp(z(P, 4)), None, None, None, None, C.byref(sink), 0, None, vp(scratch), None, 0)
 
     def sink_for(leaf, param, moments=True):
         s = lib.AdamSink()
