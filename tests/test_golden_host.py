@@ -217,17 +217,19 @@ def test_rot_cov_arguments_match_reference_render():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [True, False])
-def test_rot_cov_render_through_hip_matches_reference_end_to_end(fused):
+@pytest.mark.parametrize("path", ["rasterizer", "producer", "torch"])
+def test_rot_cov_render_through_hip_matches_reference_end_to_end(path):
     """GPU, BASELINE.json config 4's call shape (/root/reference/trainers/fine_all.py:88-94): render(rot_cov=True, accum_R,
-    which_object=1) through the HIP covariance producer (fused=True: cov3d.hip; False: the PyTorch mirror) and the HIP rasterizer
-    reproduces the images and the PARAMETER gradients the reference's render() + GaussianModel produced, including the
-    hand-mask gradient hook on the second frame."""
+    which_object=1) reproduces the images and the PARAMETER gradients the reference's render() + GaussianModel produced, including the
+    hand-mask gradient hook on the second frame and the [N,1]-index quirk on row 0 -- with the object rotation applied inside the
+    rasterizer (egs_object_rotation, raw parameters), by the HIP covariance producer (cov3d.hip -> cov3D_precomp), or by the PyTorch
+    mirror of the reference's ops."""
     from egogaussian_amd.renderer import render
     from egogaussian_amd.scene_synth import Pipe
     g = load("boundary_rot.npz")
     dev = "cuda:0"
-    pc = _model_from_boundary_rot(g, dev, fused=fused)
+    pc = _model_from_boundary_rot(g, dev, fused=path != "torch")
+    pc.rotate_in_rasterizer = path == "rasterizer"
     bg = torch.tensor(g["bg"], device=dev)
     close = lambda a, b, tol=1e-4: np.abs(a.detach().cpu().numpy() - b).max() <= tol * max(np.abs(b).max(), 1e-12)
     for f in range(2):
