@@ -197,21 +197,46 @@ __device__ __forceinline__ unsigned bin_logical_block(unsigned nblocks) {
 // sort and the lists the blend kernels scan (config C: 2.94M -> 1.87M instances).  The test is the exact, conservative
 // ellipse-vs-block test the blend kernels apply per 8x8 quadrant (blend_common.h), on the whole 16x16 tile; each slot-lane
 // reads its Gaussian's prepared ellipse parameters from the LDS block the set-up wave wrote.
+#ifdef EGS_BIN_TIMING
+// measurement builds (tools/bin_phases.py): every wave of every workgroup of k_bin_count stamps s_memtime at its phase boundaries
+__device__ unsigned long long egs_bin_stamps[512 * 16 * 6];
+__device__ unsigned long long egs_bin_unit_stamps[8 * 6];
+#define BIN_USTAMP(ph) do { __builtin_amdgcn_sched_barrier(0); if (!need_depth && threadIdx.x == 0 && bid == 7 && ucount < 8) egs_bin_unit_stamps[ucount * 6 + (ph)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BIN_STAMP(ph) do { __builtin_amdgcn_sched_barrier(0); if (!need_depth && (threadIdx.x & 63) == 0 && bid < 512) egs_bin_stamps[(bid * 16 + (threadIdx.x >> 6)) * 6 + (ph)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define BIN_STAMP(ph)
+#define BIN_USTAMP(ph)
+#endif
 #define EGS_BIN_WAVES (EGS_BIN_THREADS / 64)
 // LDS behind the per-tile counters, for a round of `gpr` groups (words): span starts, rectangles, depth words, 16 unit counts +
 // 16 group totals, then (culling only, 16-byte aligned) two float4 per Gaussian.
-__host__ __device__ inline size_t bin_round_words(int gpr, bool cull) { return (size_t)gpr * 64 * 4 + 32 + (cull ? (size_t)gpr * 64 * 8 : 0); }
+// + per group the owner map of the slot walk (see for_each_instance): 64 packed (span start << 6 | lane) words of the Gaussians that have
+// tiles, a 4096-bit map of the slots at which a span starts and 64 prefix counts of it.
+#define BIN_MAP_SLOTS 4096
+__host__ __device__ inline size_t bin_round_words(int gpr, bool cull, bool map) {
+    return (size_t)gpr * 64 * 4 + 32 + (cull ? (size_t)gpr * 64 * 8 : 0) + (map ? (size_t)gpr * 256 : 0);
+}
 
 template <typename Body>
 __device__ __forceinline__ void for_each_instance(unsigned bid, unsigned nblocks, int gpr, int P, const uint32_t* __restrict__ tiles_touched,
                                                   const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
-                                                  bool need_depth, bool cull, int W, int H, uint32_t* __restrict__ round_lds, Body body) {
+                                                  bool need_depth, bool cull, bool use_map, int W, int H, uint32_t* __restrict__ round_lds, Body body) {
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t* span = round_lds;                                        // [gpr * 64] exclusive slot offset inside the group
     uint2* rcs = reinterpret_cast<uint2*>(span + gpr * 64);            // [gpr * 64]
     uint32_t* dbs = span + gpr * 64 * 3;                               // [gpr * 64]
     uint32_t* units = dbs + gpr * 64;                                  // [16] 64-slot units per group, [16] slots per group
     float4* stage = reinterpret_cast<float4*>(units + 32);             // [gpr * 64][2]
+    // Owner map (which Gaussian of the group does slot s belong to?).  A 6-step binary search over the span starts by ds_bpermute was
+    // 1 000 of the 2 400 cycles a wave spends per 64-slot unit (tools/bin_phases.py); instead the set-up wave leaves, per group,
+    //   packed[r]   (span start << 6 | lane) of the r-th Gaussian that has tiles,
+    //   bm          one bit per slot < BIN_MAP_SLOTS at which a span starts,      bmpre[u] = span starts before slot 64 u,
+    // and a slot's owner is packed[bmpre[u] + popcount(bm[u] & bits up to the slot) - 1]: two LDS round trips, the first at a uniform
+    // address.  Units beyond the map (a group covering more than 4 096 tiles) keep the search, and so does everything when the per-tile
+    // counters of a large image leave no room for the map (`use_map`).
+    uint32_t* packed = reinterpret_cast<uint32_t*>(stage + (cull ? (size_t)gpr * 64 * 2 : 0));   // [gpr * 64]
+    uint32_t* bm = packed + gpr * 64;                                  // [gpr][128]
+    uint32_t* bmpre = bm + gpr * 128;                                  // [gpr][64]
     const unsigned groups = ((unsigned)P + 63u) / 64u;
     const unsigned per_block = (groups + nblocks - 1) / nblocks;       // groups of the busiest workgroup
     for (unsigned g0 = 0; g0 < per_block; g0 += (unsigned)gpr) {
@@ -220,6 +245,24 @@ __device__ __forceinline__ void for_each_instance(unsigned bid, unsigned nblocks
             const unsigned j = bid + nblocks * (g0 + w);
             const int i = (int)(j * 64u + lane);
             const bool have = g0 + w < per_block && j < groups && i < P;
+            // Everything a Gaussian contributes is requested at once -- the rectangle and the record words do not wait for the tile
+            // count to come back (a culled Gaussian's words are loaded for nothing; the set-up phase was two dependent round trips
+            // of ~2 us each in a workgroup that does nothing else meanwhile, tools/bin_phases.py).
+#ifndef EGS_BIN_LOAD_AFTER_COUNT
+            const int il = have ? i : 0;
+            const uint32_t cnt = have ? tiles_touched[i] : 0u;
+            const uint2 rc_l = rect[il];
+            const float dep_l = need_depth ? rec[(size_t)il * EGS_SPLAT_REC_F4 + 2].y : 0.f;
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+            if (cull) { r0 = rec[(size_t)il * EGS_SPLAT_REC_F4]; r1 = rec[(size_t)il * EGS_SPLAT_REC_F4 + 1]; }
+            const uint32_t incl = wave_incl_scan(cnt);
+            span[w * 64 + lane] = have ? incl - cnt : 0xffffffffu;   // invalid lanes sort to the end
+            if (cnt) {
+                rcs[w * 64 + lane] = rc_l;
+                if (need_depth) dbs[w * 64 + lane] = __float_as_uint(dep_l);
+                if (cull) { stage[2 * (w * 64 + lane)] = r0; stage[2 * (w * 64 + lane) + 1] = egs_ellipse_prep(r0.z, r0.w, r1.x, r1.y); }
+            }
+#else
             const uint32_t cnt = have ? tiles_touched[i] : 0u;
             const uint32_t incl = wave_incl_scan(cnt);
             span[w * 64 + lane] = have ? incl - cnt : 0xffffffffu;   // invalid lanes sort to the end
@@ -231,25 +274,52 @@ __device__ __forceinline__ void for_each_instance(unsigned bid, unsigned nblocks
                     stage[2 * (w * 64 + lane)] = r0; stage[2 * (w * 64 + lane) + 1] = egs_ellipse_prep(r0.z, r0.w, r1.x, r1.y);
                 }
             }
+#endif
             if (lane == 63) { units[w] = (incl + 63u) >> 6; units[16 + w] = incl; }
+            if (use_map) {   // owner map of this group (one wave: its LDS operations execute in order)
+                const uint32_t excl_l = incl - cnt;
+                const uint64_t nzm = __ballot(cnt != 0);
+                if (cnt) packed[w * 64 + __popcll(nzm & lanemask_lt())] = (excl_l << 6) | lane;       // (a group has < 2^24 slots)
+                bm[w * 128 + lane] = 0u; bm[w * 128 + 64 + lane] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                if (cnt && excl_l < BIN_MAP_SLOTS) atomicOr(&bm[w * 128 + (excl_l >> 5)], 1u << (excl_l & 31u));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const uint32_t pc = (uint32_t)__popc(*(volatile uint32_t*)&bm[w * 128 + 2 * lane]) + (uint32_t)__popc(*(volatile uint32_t*)&bm[w * 128 + 2 * lane + 1]);
+                bmpre[w * 64 + lane] = wave_incl_scan(pc) - pc;
+            }
         }
+        BIN_STAMP(1);
         __syncthreads();
+        BIN_STAMP(2);
         const uint32_t un = (int)lane < gpr ? units[lane] : 0u, tot = (int)lane < gpr ? units[16 + lane] : 0u;
         const uint32_t uincl = wave_incl_scan(un);
         const uint32_t n_units = __shfl(uincl, 63, 64);
+        int ucount = -1; (void)ucount;
         for (uint32_t u = w; u < n_units; u += EGS_BIN_WAVES) {
+            ucount++;
+            BIN_USTAMP(0);
             const int k = __popcll(__ballot(uincl <= u && (int)lane < gpr));       // the group unit u falls in (uniform)
             const uint32_t s = ((u - (__shfl(uincl, k, 64) - __shfl(un, k, 64))) << 6) + lane;
             const uint32_t total = __shfl(tot, k, 64);
-            const uint32_t excl = span[k * 64 + lane];
-            int lo = 0;                                              // last lane whose span starts at or before s
+            const uint32_t uu = s >> 6;                                // unit inside the group (uniform)
+            int lo; uint32_t ost;
+            if (use_map && uu < BIN_MAP_SLOTS / 64) {
+                const uint64_t B = *reinterpret_cast<const uint64_t*>(&bm[k * 128 + 2 * uu]);
+                const uint32_t R = bmpre[k * 64 + uu] + (uint32_t)__popcll(B & (lanemask_lt() | (1ull << lane))) - 1u;
+                const uint32_t pk = packed[k * 64 + (R & 63u)];        // (lanes past the group's last slot read a valid word and are masked below)
+                lo = (int)(pk & 63u); ost = pk >> 6;
+            } else {
+                const uint32_t excl = span[k * 64 + lane];
+                lo = 0;                                                  // last lane whose span starts at or before s
 #pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) {
-                const int probe = lo + step;
-                const uint32_t st = __shfl(excl, probe & 63, 64);
-                if (probe < 64 && st <= s) lo = probe;
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const int probe = lo + step;
+                    const uint32_t st = __shfl(excl, probe & 63, 64);
+                    if (probe < 64 && st <= s) lo = probe;
+                }
+                ost = __shfl(excl, lo, 64);                            // (all lanes take part: outside the branch)
             }
-            const uint32_t ost = __shfl(excl, lo, 64);               // (all lanes take part: outside the branch)
+            BIN_USTAMP(1);
             if (s < total) {
                 const uint32_t kk = s - ost;
                 const uint2 orc = rcs[k * 64 + lo];
@@ -261,31 +331,39 @@ __device__ __forceinline__ void for_each_instance(unsigned bid, unsigned nblocks
                 if (col >= wd) { row++; col -= wd; }
                 const uint32_t ty = y0 + row, tx = x0 + col;
                 bool keep = true;
+                BIN_USTAMP(2);
                 if (cull) {
                     const float4 e0 = stage[2 * (k * 64 + lo)], e1 = stage[2 * (k * 64 + lo) + 1];   // (x, y, qa, qb), (qc, need, sy, sx)
                     keep = egs_ellipse_hits_prepped(e0, e1, tx * EGS_TILE, min(tx * EGS_TILE + EGS_TILE - 1, (uint32_t)W - 1),
                                                     ty * EGS_TILE, min(ty * EGS_TILE + EGS_TILE - 1, (uint32_t)H - 1));
                 }
+                BIN_USTAMP(3);
                 if (keep) body(ty * (uint32_t)gx + tx, (bid + nblocks * (g0 + (unsigned)k)) * 64u + (unsigned)lo, need_depth ? dbs[k * 64 + lo] : 0u);
             }
+            BIN_USTAMP(4);
         }
     }
 }
 
 extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
 
+
 __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, int gpr, const uint32_t* __restrict__ tiles_touched,
                                                     const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
-                                                    int n_tiles, uint32_t nblocks, int cull, int W, int H,
+                                                    int n_tiles, uint32_t nblocks, int cull, int use_map, int W, int H,
                                                     uint32_t* __restrict__ table, uint32_t stride, uint32_t* __restrict__ chunk_sum) {
     const unsigned bid = bin_logical_block(nblocks);
     if (bid >= nblocks) return;
     uint32_t* hist = dyn_lds;
     uint32_t* round_lds = dyn_lds + ((n_tiles + 3) & ~3);
+    const bool need_depth = false; (void)need_depth;                 // (BIN_STAMP: only the count pass is stamped)
+    BIN_STAMP(0);
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) hist[t] = 0;            // (the first round's barrier orders this)
-    for_each_instance(bid, nblocks, gpr, P, tiles_touched, rect, rec, gx, false, cull != 0, W, H, round_lds,
+    for_each_instance(bid, nblocks, gpr, P, tiles_touched, rect, rec, gx, false, cull != 0, use_map != 0, W, H, round_lds,
                       [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); });
+    BIN_STAMP(3);
     __syncthreads();
+    BIN_STAMP(4);
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) table[(size_t)t * stride + bid] = hist[t];    // tile-major
     // This workgroup's share of every scan chunk of the table (2048 entries = 2048 / stride whole rows), added to one of
     // EGS_BIN_GROUPS partial accumulators: the scan then needs no reduction pass of its own (one launch less; the atomics return nothing)
@@ -296,11 +374,17 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, int gpr, c
         for (int t = c * rpc; t < min((c + 1) * rpc, n_tiles); t++) sum += hist[t];
         if (sum) atomicAdd(&sums[c], sum);
     }
+    BIN_STAMP(5);
 }
+
+#ifdef EGS_BIN_TIMING
+extern "C" int egs_debug_bin_stamps(unsigned long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(egs_bin_stamps), sizeof(egs_bin_stamps)); }
+extern "C" int egs_debug_bin_unit_stamps(unsigned long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(egs_bin_unit_stamps), sizeof(egs_bin_unit_stamps)); }
+#endif
 
 __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, int gpr, const uint32_t* __restrict__ tiles_touched,
                                                       const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
-                                                      int n_tiles, uint32_t nblocks, int cull, int W, int H,
+                                                      int n_tiles, uint32_t nblocks, int cull, int use_map, int W, int H,
                                                       const uint32_t* __restrict__ table_scanned, uint32_t stride,
                                                       uint32_t cap, uint64_t* __restrict__ pairs) {
     const unsigned bid = bin_logical_block(nblocks);
@@ -308,7 +392,7 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, int gpr,
     uint32_t* cursor = dyn_lds;
     uint32_t* round_lds = dyn_lds + ((n_tiles + 3) & ~3);
     for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) cursor[t] = table_scanned[(size_t)t * stride + bid];
-    for_each_instance(bid, nblocks, gpr, P, tiles_touched, rect, rec, gx, true, cull != 0, W, H, round_lds, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
+    for_each_instance(bid, nblocks, gpr, P, tiles_touched, rect, rec, gx, true, cull != 0, use_map != 0, W, H, round_lds, [&](uint32_t tile, uint32_t idx, uint32_t dbits) {
         const uint32_t pos = atomicAdd(&cursor[tile], 1u);
         if (pos < cap) pairs[pos] = ((uint64_t)dbits << 32) | idx;      // cap < R only in a speculative launch that will be redone
     });
@@ -688,14 +772,16 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     // per-tile counters, then (16-byte aligned) the round's set-up block; fewer groups per round, then no culling, when
     // the counters leave too little of the 160 KiB (beyond ~28k tiles)
     const size_t counters = (size_t)((n_tiles + 3) & ~3) * sizeof(uint32_t), room = 160 * 1024 - counters;
-    auto fits = [&](int groups, bool with_cull) { return bin_round_words(groups, with_cull) * sizeof(uint32_t) <= room; };
+    // the slot walk's owner map (16 KiB at 16 groups) is used where it costs neither groups per round nor the culling: up to ~21k tiles
+    const bool use_map = bin_round_words(EGS_BIN_WAVES, cull != 0, true) * sizeof(uint32_t) <= room;
+    auto fits = [&](int groups, bool with_cull) { return bin_round_words(groups, with_cull, use_map) * sizeof(uint32_t) <= room; };
     int gpr = EGS_BIN_WAVES;
     if (cull) {
         while (gpr > 4 && !fits(gpr, true)) gpr >>= 1;
         if (!fits(gpr, true)) { cull = 0; gpr = EGS_BIN_WAVES; }
     }
     if (!cull) while (gpr > 1 && !fits(gpr, false)) gpr >>= 1;
-    const size_t lds = counters + bin_round_words(gpr, cull != 0) * sizeof(uint32_t);
+    const size_t lds = counters + bin_round_words(gpr, cull != 0, use_map) * sizeof(uint32_t);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -708,12 +794,12 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
         hipError_t e0 = egs_launch_zero_u32(b.chunk_sum, (size_t)EGS_BIN_GROUPS * n_chunks, s);
         if (e0 != hipSuccess) return e0;
     }
-    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, W, H,
+    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, use_map ? 1 : 0, W, H,
                        b.table, stride, b.chunk_sum);
     EGS_DBG(s);
     hipLaunchKernelGGL(k_table_scan, dim3(n_chunks), dim3(EGS_SCAN_THREADS), 0, s, b.table, (size_t)n_tiles * stride, stride, nblocks, b.chunk_sum, n_chunks, b.total);
     hipLaunchKernelGGL(k_bin_scatter, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
-                       cull, W, H, b.table, stride, R, b.pairs);
+                       cull, use_map ? 1 : 0, W, H, b.table, stride, R, b.pairs);
     egs_prof_stop(EGS_K_DUPLICATE, s);
     EGS_DBG(s);
     int index_bits = 0; while (((unsigned)(P - 1) >> index_bits) != 0) index_bits++;
