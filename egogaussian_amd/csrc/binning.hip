@@ -535,6 +535,13 @@ __device__ __forceinline__ void block_min_max(uint32_t& mn, uint32_t& mx, uint32
     __syncthreads();
 }
 
+#ifdef EGS_BIN_TIMING
+__device__ unsigned long long egs_sort_stamps[2048 * 8];
+#define SORT_STAMP(ph) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 2048) egs_sort_stamps[blockIdx.x * 8 + (ph)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int egs_debug_sort_stamps(unsigned long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(egs_sort_stamps), sizeof(egs_sort_stamps)); }
+#else
+#define SORT_STAMP(ph)
+#endif
 template <bool RANK_ATOMIC, int TS_WAVES, int TS_CAP, uint32_t N_MIN>
 __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32_t stride, const uint32_t* __restrict__ table_scanned,
                                                     const uint64_t* __restrict__ total, uint64_t* __restrict__ running_max,
@@ -549,6 +556,7 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
     __shared__ uint32_t cnt[TS_WAVES][256];
     __shared__ uint32_t lds8[2 * TS_WAVES];
     const int tile = blockIdx.x;
+    SORT_STAMP(0);
     const uint32_t beg = table_scanned[(size_t)tile * stride];
     const uint32_t end = tile + 1 < n_tiles ? table_scanned[(size_t)(tile + 1) * stride] : (uint32_t)*total;
     const uint32_t n = end > R ? 0u : end - beg;                     // end > capacity: speculative launch that overflowed
@@ -580,7 +588,9 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
             key[r] = ok ? pairs[beg + i] : ~0ull;
             if (ok) { const uint32_t dw = (uint32_t)(key[r] >> 32); dmin = min(dmin, dw); dmax = max(dmax, dw); }
         }
+        SORT_STAMP(1);
         block_min_max<TS_WAVES>(dmin, dmax, lds8);
+        SORT_STAMP(2);
         const int depth_passes = (32 - __clz((int)(dmax - dmin)) + TS_DBITS - 1) / TS_DBITS;     // 0 when every depth is equal
         const int npass = index_passes + depth_passes;
         // Barriers per pass: 4.  Every wave clears ITS OWN counters (nobody else touches them between the barrier after the
@@ -602,8 +612,10 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
                     rank[r] = wave_digit_rank<RANK_ATOMIC, true>(cnt[w], ((uint32_t)(key[r] >> 32) - dmin) >> sh, i < n, lane, lt);
                 }
             }
+            SORT_STAMP(3);
             __syncthreads();
             digit_bases_packed<TS_WAVES>(cnt, lds8);
+            SORT_STAMP(4);
 #pragma unroll
             for (int r = 0; r < TS_ITEMS; r++) {
                 const uint32_t i = wbeg + r * 64 + lane;
@@ -613,6 +625,7 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
                 }
             }
             __syncthreads();
+            SORT_STAMP(5);
             bool big = false;
 #pragma unroll
             for (int r = 0; r < TS_ITEMS; r++) {
@@ -628,6 +641,7 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
                     point_list[beg + bs + smaller] = (uint32_t)k;
                 }
             }
+            SORT_STAMP(6);
             if (!__syncthreads_or(big ? 1 : 0)) return;
             for (int k = lane; k < 256; k += 64) cnt[w][k] = 0;             // an overfull bucket: start over, digit by digit (keys are still in registers)
         }

@@ -38,3 +38,13 @@ for r in range(8):
     if u[r, 0] and u[r, 4]:
         nxt = u[r + 1, 0] - u[r, 4] if r + 1 < 8 and u[r + 1, 0] else -1
         print("   ", [int(u[r, k + 1] - u[r, k]) for k in range(4)], int(nxt))
+st = (C.c_ulonglong * (2048 * 8))()
+raw.egs_debug_sort_stamps(st)
+st = np.array(st[:], dtype=np.int64).reshape(2048, 8)
+st = st[(st[:, :7] > 0).all(1)]
+print(f"k_tile_sort, wave 0 of {len(st)} tiles that took the one-pass path (cycles): ")
+for k, nm in enumerate(["ranges + load keys", "min / max over the workgroup (2 barriers)", "rank pass (LDS atomics)", "barrier + digit bases", "scatter to LDS + barrier",
+                        "in-bucket comparison + point_list stores"]):
+    d = (st[:, k + 1] - st[:, k]).astype(float)
+    print(f"  {nm:46s} mean {d.mean():7.0f}  p10 {np.percentile(d, 10):7.0f}  p90 {np.percentile(d, 90):7.0f}  max {d.max():7.0f}")
+print(f"  total mean {(st[:, 6] - st[:, 0]).mean():.0f} max {(st[:, 6] - st[:, 0]).max()}")
