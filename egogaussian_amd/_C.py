@@ -178,7 +178,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             pinned = _pinned_counts[key] = torch.empty((max(nb, 4096),), dtype=torch.int32, pin_memory=True)
         binning = torch.empty((L.egs_binning_bytes(P, cap, W, H),), device=dev, dtype=torch.uint8)
         capturing = torch.cuda.is_current_stream_capturing()
-        place = placement_buffer(dev, W, H)
+        place = None if os.environ.get("EGS_NO_PLACEMENT") else placement_buffer(dev, W, H)      # (switch for A/B measurements)
         rot_st, _rot_keep = _object_rotation_struct(object_rotation, dev, P)
         rot_arg = C.byref(rot_st) if rot_st is not None else None
         if capturing:
