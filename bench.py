@@ -36,6 +36,8 @@ import socket
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL's device-buffer exchange needs dmabuf IPC (egogaussian_amd/dist.py); read when HSA loads
+
 import numpy as np
 import torch
 
@@ -86,6 +88,136 @@ def stamped(path, key, current_hash):
     return (ent, None) if ent else (None, f"{os.path.basename(path)} has no entry for {key}")
 
 
+def tile_list_stats(_C, img, W, H):
+    """Lengths of the per-tile instance lists the blend kernels walk, pixel-splat pairs Q and (wave, splat) visits of the last forward."""
+    iv = _C.image_views(img, W, H)
+    r = iv["ranges"].long()
+    ln = (r[:, 1] - r[:, 0]).float()
+    return {"tile_list_len_mean": round(float(ln.mean().item()), 1), "tile_list_len_max": int(ln.max().item()),
+            "pairs_Q": int(iv["quad_pairs"].long().sum().item()), "visits": int(iv["quad_visits"].long().sum().item())}
+
+
+def stage_table(stages, N, R_kept, npix, sh_coeffs=1):
+    """{stage: (total ms, launches)} -> {stage: ms per launch, algorithmic MB, GB/s, fraction of the HBM roofline}"""
+    rows = {}
+    for name, (ms, n) in stages.items():
+        if n == 0:
+            continue
+        per = ms / n
+        ab = algorithmic_bytes(name, N, R_kept, npix, sh_coeffs)
+        rows[name] = {"ms_per_launch": round(per, 4), "launches": n, "alg_MB": round(ab / 1e6, 2),
+                      "alg_GBps": round(ab / (per * 1e-3) / 1e9, 1), "frac_hbm": round(ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return rows
+
+
+def config_leg(dev, N, H, W, forward_only, iters=30, log_scale_shift=0.0, scene=None, what=""):
+    """One of BASELINE.json's other configurations on this GPU (parity cases elsewhere; here their timings): the rasterizer alone on
+    S(N, H, W, seed 0), forward only (config 2) or forward + backward with seeded upstream gradients on colour, depth and alpha
+    (config 5).  Per-stage durations from HIP events the library records around each stage on the launch stream, over `iters` eager
+    calls; forward-only additionally replayed back to back from a hipGraph (frames/s).  `log_scale_shift`: ln of a factor on every
+    splat's extent (the footprint legs)."""
+    from egogaussian_amd import lib as egs_lib, _C
+    from egogaussian_amd.scene_synth import make_scene, make_camera, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    if scene is None:
+        scene = make_scene(N, H, W, seed=0)
+    if log_scale_shift:
+        scene = dict(scene); scene["log_scale"] = scene["log_scale"] + np.float32(log_scale_shift)
+    pc = SynthGaussians(scene, device=dev, requires_grad=not forward_only)
+    cams = [make_camera(k, H, W, device=dev) for k in range(4)]
+    bg = torch.zeros(3, device=dev)
+    g = torch.Generator().manual_seed(1)
+    up = [torch.rand(s_, generator=g).to(dev) for s_ in ((3, H, W), (1, H, W), (1, H, W))]
+
+    def one(k):
+        if forward_only:
+            with torch.no_grad():
+                return render(cams[k % 4], pc, Pipe, bg)
+        out = render(cams[k % 4], pc, Pipe, bg)
+        ((out["render"] * up[0]).sum() + (out["depth"] * up[1]).sum() + (out["alpha"] * up[2]).sum()).backward()
+        for p_ in pc.parameters():
+            p_.grad = None
+        return out
+    for k in range(4):
+        one(k)
+    torch.cuda.synchronize()
+    egs_lib.profile_begin(16 * (iters + 4))
+    t0 = time.perf_counter()
+    for k in range(iters):
+        one(k)
+    torch.cuda.synchronize()
+    wall_ms = 1e3 * (time.perf_counter() - t0) / iters
+    stages = egs_lib.profile_end()
+    with torch.no_grad():
+        render(cams[0], pc, Pipe, bg)
+        torch.cuda.synchronize()
+        R = int(_C.stats["num_rendered"]); R_kept = int(_C.stats["total_view"].item())
+        lists = tile_list_stats(_C, _C.stats["image_buffer"], W, H)
+    rows = stage_table(stages, N, R_kept, H * W)
+    op_ms = sum(r["ms_per_launch"] for r in rows.values())
+    alg = sum(r["alg_MB"] for r in rows.values())
+    leg = {"workload": f"S({N},{H},{W},seed0){what}: rasterizer " + ("forward only, no gradient" if forward_only else
+                       "forward + backward, seeded upstream gradients on colour, depth and alpha"),
+           "gaussians": N, "image": [H, W], "instances_R": R, "instances_after_tile_culling": R_kept, **lists,
+           "lanes_kept_per_visit": round(lists["pairs_Q"] / max(lists["visits"], 1), 2),
+           "op_ms": round(op_ms, 4), "op_timing": f"sum of the per-stage means: HIP events recorded by the library on the launch stream over {iters} eager calls",
+           "eager_wall_ms_per_call": round(wall_ms, 4), "alg_MB": round(alg, 1), "alg_GBps": round(alg / op_ms, 1),
+           "frac_hbm": round(alg / op_ms / HBM_PEAK_GBS, 4), "stages": rows}
+    if forward_only:
+        per, replays = 20, 10
+        with torch.no_grad():
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(per):
+                    render(cams[0], pc, Pipe, bg)
+            gr.replay(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(replays):
+                gr.replay()
+            e1.record(); torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / (per * replays)
+        leg.update({"frames_per_s": round(1e6 / us, 1), "us_per_frame": round(us, 2),
+                    "launch": f"a hipGraph of {per} forwards replayed {replays} times back to back",
+                    "alg_GBps_replayed": round(alg * 1e3 / us, 1), "frac_hbm_replayed": round(alg * 1e3 / us / HBM_PEAK_GBS, 4)})
+    del pc
+    torch.cuda.empty_cache()
+    return leg
+
+
+def footprint_legs(dev, train_iters=30000):
+    """Heavier footprints than S(500k) (67 pairs per pixel, 918 instances per tile): the same scene with every splat three times
+    larger (saturating pixels, long lists), and the model the reference's full schedule ends with on the synthetic scene -- 100k
+    Gaussians initialised from simple_knn distances, densified / pruned every 100 iterations from 500 to 15 000, opacity reset every
+    3 000 (examples/train_synth.py; profiles/r2_train_synth_30k.log): its arrays end with runs of clones and splits that are all on
+    screen.  Rasterizer forward + backward with colour, depth and alpha gradients, per-stage timings as in config_leg."""
+    out = {}
+    for name, shift in (("S500k_scale_x2", math.log(2.0)), ("S500k_scale_x3", math.log(3.0))):
+        try:
+            out[name] = config_leg(dev, 500_000, 540, 960, False, iters=20, log_scale_shift=shift,
+                                   what=f", every splat {math.exp(shift):.0f}x larger")
+        except Exception as exc:
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        import train_synth
+        pc = train_synth.main(["--gaussians", "100000", "--height", "540", "--width", "960", "--iters", str(train_iters), "--knn-init",
+                               "--densify-from", "500", "--densify-until", str(min(15000, train_iters)), "--densify-interval", "100",
+                               "--opacity-reset-interval", "3000", "--frames", "24", "--report-every", str(max(train_iters // 6, 1))])
+        n = int(getattr(pc, "n_active", pc._xyz.shape[0]))
+        with torch.no_grad():
+            scene = dict(xyz=pc._xyz[:n].cpu().numpy(), log_scale=pc._scaling[:n].cpu().numpy(), quat=pc._rotation[:n].cpu().numpy(),
+                         opacity_logit=pc._opacity[:n].cpu().numpy(),
+                         features=torch.cat((pc._features_dc[:n], pc._features_rest[:n]), 1).cpu().numpy())
+        del pc
+        torch.cuda.empty_cache()
+        out["densified_model"] = config_leg(dev, n, 540, 960, False, iters=20, scene=scene,
+                                            what=f" replaced by the {n}-Gaussian model examples/train_synth.py ends with after {train_iters} iterations of the reference's schedule")
+    except Exception as exc:
+        out["densified_model"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
 def object_rotation(k, device):
     """Accumulated object rotation of frame k of the synthetic fine_all sequence (the object turns while the camera orbits)."""
     from egogaussian_amd.scene_synth import N_FRAMES
@@ -128,6 +260,12 @@ def main():
                     help="wall-clock milliseconds of forward-only renders (no training) right before the warm-up steps: clock spin-up; 0 = none")
     ap.add_argument("--steps-per-replay", type=int, default=5,
                     help="training steps captured into one hipGraph (each on its own frame); lowered to a divisor of --steps when needed; 1 = one launch per step")
+    ap.add_argument("--no-force-dist", action="store_true",
+                    help="N = 1 only: do not create the one-rank RCCL group (by default the single-GPU run initialises RCCL with device_id, and its "
+                         "barriers and scalar all-reduces are real collectives -- the same code path as N > 1)")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the config B (100k forward-only) and config D (1M @ 1080p op-only) legs of the default run")
+    ap.add_argument("--footprints", action="store_true", help="also measure the heavier-footprint legs (scale x3 scene; densified model): profiles/r3_footprint_sweep.md")
+    ap.add_argument("--teacher-seed", type=int, default=0, help="seed of the teacher scene S(N,H,W,seed)")
     ap.add_argument("--verify-ranks", action="store_true", help="add per-rank frame lists, start-of-run parameter checksums and loss sums to the JSON line")
     args = ap.parse_args()
 
@@ -142,7 +280,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    egs_dist.init(os.environ.get("EGS_BENCH_BACKEND", "nccl"), dev)        # "nccl" is RCCL on ROCm
+    backend = os.environ.get("EGS_BENCH_BACKEND", "nccl")                  # "nccl" is RCCL on ROCm
+    collective_error = None
+    try:
+        egs_dist.init(backend, dev, force=(world == 1 and not args.no_force_dist))
+    except Exception as exc:                                               # N = 1: the measurement does not depend on the group; say so and go on
+        if world > 1:
+            raise
+        collective_error = f"{type(exc).__name__}: {exc}"
 
     from egogaussian_amd import lib as egs_lib, _C
     from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe, N_FRAMES
@@ -155,7 +300,7 @@ def main():
 
     N, H, W = args.gaussians, args.height, args.width
     D = args.sh_degree
-    teacher = make_scene(N, H, W, seed=0, sh_degree=D)
+    teacher = make_scene(N, H, W, seed=args.teacher_seed, sh_degree=D)
     student = perturb_student(teacher)
     is_object = (np.random.default_rng(5).uniform(size=(N, 1)) < 0.3).astype(np.float32)      # fine_all leg: 30 % object Gaussians
     bg = torch.zeros(3, device=dev)
@@ -277,9 +422,9 @@ def main():
         for i in range(0, args.steps, spr):                         # EXACTLY args.steps training steps (spr per launch)
             step(n_warm + i)
         torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0                          # this rank's K steps are complete; the MAX over ranks is taken below
         egs_dist.barrier()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
         stages = egs_lib.profile_end()
         stage_timing = "HIP events recorded by the library on the launch stream inside the timed region"
         overflow = None
@@ -305,15 +450,18 @@ def main():
         # instances that survive tile culling (what the sort and the blend kernels process), pixel-splat pairs Q and (wave, splat)
         # visits of the forward blend: sampled on four frames
         kept = rect = pairs = visits = 0
+        list_mean, list_max = [], []
         with torch.no_grad():
             for i in range(0, n_used, max(1, n_used // 4)):
                 render(cams[i], pc, Pipe, bg, **rkw(rot[i] if dynamic else None))
                 kept += int(_C.stats["total_view"].item()); rect += _C.stats["num_rendered"]
-                iv = _C.image_views(_C.stats["image_buffer"], W, H)
-                pairs += int(iv["quad_pairs"].sum().item()); visits += int(iv["quad_visits"].sum().item())
+                ls = tile_list_stats(_C, _C.stats["image_buffer"], W, H)
+                pairs += ls["pairs_Q"]; visits += ls["visits"]
+                list_mean.append(ls["tile_list_len_mean"]); list_max.append(ls["tile_list_len_max"])
         n_s = len(range(0, n_used, max(1, n_used // 4)))
         return dict(elapsed=elapsed, stages=stages, stage_timing=stage_timing, loss=loss_acc.item(), psnr_end=psnr_end, psnr_start=psnr_start,
                     R_mean=float(r_sum[0]) / max(r_sum[1], 1), kept_ratio=kept / max(rect, 1), pairs=pairs / n_s, visits=visits / n_s,
+                    list_mean=float(np.mean(list_mean)), list_max=int(max(list_max)),
                     use_graph=use_graph, checksum=checksum, overflow=overflow, pc=pc, cams=cams, spr=spr)
 
     def reduce_leg(r):
@@ -430,8 +578,10 @@ def main():
         "value": round(total_steps / red["elapsed_max"], 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * red["elapsed_max"] / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"S({N},{H},{W},seed0) teacher/student, 300-frame orbit, 1 frame per GPU per step; step = " + step_text[head_name],
+        "collective": egs_dist.collective_name(), **({"collective_error": collective_error} if collective_error else {}),
+        "config": {"workload": f"S({N},{H},{W},seed{args.teacher_seed}) teacher/student, 300-frame orbit, 1 frame per GPU per step; step = " + step_text[head_name],
                    "gaussians": N, "image": [H, W], "sh_degree": D, "instances_R": int(R_mean), "instances_after_tile_culling": int(R_kept),
+                   "tile_list_len_mean": round(head["list_mean"], 1), "tile_list_len_max": head["list_max"],
                    "sort_passes_max": passes,
                    "parallelism": f"frames sharded over {world} GPU(s), scalar all-reduce only",
                    "launch": (f"one hipGraph replay per {head['spr']} steps ({head['spr']} complete iterations, each on its own frame, captured back to back)"
@@ -486,8 +636,23 @@ def main():
                                             "launch": j["config"]["launch"]}
         except Exception as exc:
             out["reference_shaped_step"] = {"error": f"{type(exc).__name__}: {exc}"}
-    print(json.dumps(out))
+    if world == 1 and not args.no_config_legs and not (args.op_only or args.torch_host_ops or args.no_graph or args.dynamic or D > 0):
+        # BASELINE.json configs 2 and 5 on the same GPU, in this process (the training legs' tensors are released first)
+        legs.clear(); head = None
+        torch.cuda.empty_cache()
+        for name, kw in (("config_B_forward_only", dict(N=100_000, H=540, W=960, forward_only=True, iters=40)),
+                         ("config_D_op_only", dict(N=1_000_000, H=1080, W=1920, forward_only=False, iters=20))):
+            try:
+                out[name] = config_leg(dev, **kw)
+                out[name]["reference"] = ("/root/reference/trainers/eval_metric.py:107 (no-grad render), BASELINE.json config 2" if kw["forward_only"] else
+                                          "/root/reference/gaussian_renderer/__init__.py:90-98 with depth + alpha gradients, BASELINE.json config 5")
+            except Exception as exc:
+                out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+    if world == 1 and args.footprints:
+        out["footprints"] = footprint_legs(dev)
     egs_dist.shutdown()
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)                                  # the ONE line of stdout, and the last thing written to it
 
 
 if __name__ == "__main__":

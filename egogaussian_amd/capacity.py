@@ -101,6 +101,7 @@ class CapacityGaussians(SynthGaussians):
         for a in ("_is_object", "_generation", "max_radii2D", "xyz_gradient_accum", "denom"):
             setattr(self, a, bigger(getattr(self, a)))
         self.capacity = int(capacity)
+        self.model_version = getattr(self, "model_version", 0) + 1     # the arrays a captured step points at are gone: graph.py checks this
         if opt is not None and hasattr(opt, "active_rows"):
             opt.active_rows = (self.active_count, self.capacity)
         return self.capacity

@@ -140,28 +140,39 @@ __global__ __launch_bounds__(256) void k_knn_query(int N, const float* __restric
     const float4 q = sorted[t];
     const uint32_t self = __float_as_uint(q.w);
     int cx, cy, cz; knn_cell_of(g, q.x, q.y, q.z, cx, cy, cz);
-    float b0, b1, b2;
+    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;                    // the three smallest distances so far: kept across radii
     const int rmax = max(max(g.nx, g.ny), g.nz);
-    for (int r = 1;; r++) {
-        b0 = b1 = b2 = FLT_MAX;
+    auto scan = [&](uint32_t s, uint32_t e) {
+        for (uint32_t k = s; k < e; k++) {
+            const float4 p = sorted[k];
+            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+            float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            d = (__float_as_uint(p.w) == self || !(d <= FLT_MAX)) ? FLT_MAX : d;
+            const float n2 = fminf(b2, fmaxf(b1, d));
+            const float n1 = fminf(b1, fmaxf(b0, d));
+            b0 = fminf(b0, d); b1 = n1; b2 = n2;
+        }
+    };
+    // Radius r visits only the SHELL of cells at Chebyshev distance r from the query's cell (r = 0: the cell itself); an isolated
+    // point therefore costs O(r^3) cell visits in total, not O(r^4).
+    for (int r = 0;; r++) {
         const int z0 = max(cz - r, 0), z1 = min(cz + r, g.nz - 1), y0 = max(cy - r, 0), y1 = min(cy + r, g.ny - 1);
         const int x0 = max(cx - r, 0), x1 = min(cx + r, g.nx - 1);
         for (int z = z0; z <= z1; z++)
             for (int y = y0; y <= y1; y++) {
                 const uint32_t row = (uint32_t)((z * g.ny + y) * g.nx);
-                const uint32_t s = start[row + x0], e = start[row + x1 + 1];      // cells x0..x1 of a row are contiguous in cell order
-                for (uint32_t k = s; k < e; k++) {
-                    const float4 p = sorted[k];
-                    const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-                    float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    d = (__float_as_uint(p.w) == self || !(d <= FLT_MAX)) ? FLT_MAX : d;
-                    const float n2 = fminf(b2, fmaxf(b1, d));
-                    const float n1 = fminf(b1, fmaxf(b0, d));
-                    b0 = fminf(b0, d); b1 = n1; b2 = n2;
+                if (abs(z - cz) == r || abs(y - cy) == r) {
+                    scan(start[row + x0], start[row + x1 + 1]);                // a face row: cells x0..x1 are contiguous in cell order
+                } else {                                                       // an inner row: its two end cells
+                    if (cx - r >= 0) scan(start[row + cx - r], start[row + cx - r + 1]);
+                    if (cx + r <= g.nx - 1) scan(start[row + cx + r], start[row + cx + r + 1]);
                 }
             }
-        const float reach = (float)r * g.cell * 0.9999f;
-        if (b2 <= reach * reach || r >= rmax) break;
+        // Every point nearer than (r - 2 e) cells is inside the cube just completed, e = the rounding error of a cell coordinate:
+        // floorf((x - min) * inv_cell) is off by at most ~index * 2^-22 <= 2.5e-4 cells at index 1024 (the longest axis has at most
+        // 1025 cells), for the query's own cell and for the neighbour's.  1e-3 covers both and the product below.
+        const float reach = ((float)r - 1e-3f) * g.cell;
+        if ((r >= 1 && b2 <= reach * reach) || r >= rmax) break;
     }
     out[self] = (b0 + b1 + b2) / 3.0f;
 }

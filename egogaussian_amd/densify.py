@@ -138,6 +138,9 @@ def _apply_in_place(gaussians, plan, reset_stats, z=None, curr_gen=None):
             getattr(gaussians, _ATTR[k]).detach()[:n_new].copy_(new[k])
         gaussians._generation[:n_new].copy_(plan.ints(gaussians._generation[:n_old], clone_value=curr_gen))
         gaussians._is_object[:n_new].copy_(plan.ints(gaussians._is_object[:n_old]))
+        if n_new < n_old:                                       # vacated rows hold no Gaussian: their tags must not be counted by anyone
+            gaussians._generation[n_new:n_old].zero_()
+            gaussians._is_object[n_new:n_old].zero_()
         for name in ("xyz_gradient_accum", "denom", "max_radii2D"):
             t = getattr(gaussians, name)
             if reset_stats:
@@ -228,7 +231,8 @@ def densify_and_prune(gaussians, max_grad, min_opacity, extent, max_screen_size,
     if in_place:
         if not _apply_in_place(gaussians, plan, reset_stats=bool(clone or split), z=z, curr_gen=curr_gen):
             gaussians.grow(max(int(plan.n_new * 1.5), plan.n_new + 1024))        # new arrays: a captured step must be captured again
-            assert _apply_in_place(gaussians, plan, reset_stats=bool(clone or split), z=z, curr_gen=curr_gen)
+            if not _apply_in_place(gaussians, plan, reset_stats=bool(clone or split), z=z, curr_gen=curr_gen):
+                raise RuntimeError(f"densify_and_prune: {plan.n_new} Gaussians do not fit the capacity {gaussians.capacity} after grow()")
         return P, plan.n_new
     _apply(gaussians, plan, reset_stats=bool(clone or split), z=z, curr_gen=curr_gen)
     return P, plan.n_new

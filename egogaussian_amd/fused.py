@@ -95,22 +95,30 @@ def covariance_and_opacity(log_scaling, scaling_modifier, rotation, opacity_raw)
     return _Cov3D.apply(log_scaling, rotation, None, None, scaling_modifier, 1.0, True, opacity_raw)
 
 
-def object_selection(is_object, which_object, n):
+def object_selection(is_object, which_object, n, n_live=None):
     """(selected uint8[N] or None, row-0 gradient multiplier: python float or float32[1] device tensor) for the rows the reference's
     build_covariance_from_scaling_rotation_w_rot rotates -- including its [N,1]-index quirk (covariance.py): Gaussian 0 is rotated
     too whenever any Gaussian is selected, and its gradient is multiplied by (count + [0 selected]).  Evaluated on the device, no
-    host read.  The result depends only on (is_object, which_object): callers may keep it across steps."""
+    host read.  The result depends only on (is_object, which_object, n_live): callers may keep it across steps.
+    n_live: a capacity-sized model's live row count -- rows beyond it are not Gaussians: never selected, never counted (the
+    reference's model has exactly n_live rows)."""
     sel, mult = None, 1.0
+    if n_live is not None and n_live < n:
+        n_eff = int(n_live)
+    else:
+        n_eff = n
     if which_object is not None and is_object is not None:
         sel = (is_object.reshape(-1) == which_object)
-        if is_object.dim() == 2 and n > 0:
+        if n_eff < n:
+            sel = sel.clone(); sel[n_eff:] = False
+        if is_object.dim() == 2 and n_eff > 0:
             cnt = sel.sum()
             mult = (cnt + sel[0]).to(torch.float32).reshape(1)
             first = torch.logical_or(sel[0:1], (cnt > 0).reshape(1))
             sel = sel.clone(); sel[0:1] = first
         sel = sel.to(torch.uint8).contiguous()
-    elif is_object is not None and is_object.dim() == 2 and n > 0:
-        mult = float(n + 1)
+    elif is_object is not None and is_object.dim() == 2 and n_eff > 0:
+        mult = float(n_eff + 1)
     return sel, mult
 
 

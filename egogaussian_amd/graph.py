@@ -200,6 +200,7 @@ class GraphedTrainStep:
             self.capacity = max(int(capacity), 1)
         _C.set_capacity_hint(self.capacity, dev)
         self.P = self.pc.get_xyz.shape[0]
+        self._model_version = getattr(self.pc, "model_version", 0)
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         # capture_begin/capture_end directly: the torch.cuda.graph context manager also runs gc.collect() and
@@ -253,6 +254,9 @@ class GraphedTrainStep:
                 self.accum_R.copy_(accum_R, non_blocking=True)
             if self.gated and gate is not None:
                 self.gate.copy_(gate, non_blocking=True)
+        if getattr(self.pc, "model_version", 0) != self._model_version:
+            raise RuntimeError("GraphedTrainStep: the model reallocated its arrays (CapacityGaussians.grow) after this step was captured; "
+                               "the captured launches point at freed memory -- call recapture() first")
         self.opt.sync_lr()                                           # a fill per group whose learning rate was edited since the last call
         self.graph.replay()
         self._calls += 1

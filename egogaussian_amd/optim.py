@@ -28,7 +28,8 @@ class AdamSink:
         """Called once the backward that carries this sink has been enqueued: the next optimizer.step() leaves the owned leaves
         alone even if a gradient reached them (keep_grads)."""
         if self._opt is not None:
-            self._opt._sunk.update(id(p) for p in self._params)
+            for p in self._params:
+                self._opt._sunk[p] = bool(self.keep_grads)
 
     def check(self, means3D, scales, rotations, sh, sh_rest, own_cov, colors):
         """Called by _C.rasterize_gaussians_backward with the arrays it is about to pass: the owned leaves must be those arrays."""
@@ -55,7 +56,9 @@ class FusedAdam(torch.optim.Optimizer):
         self.guard = None                 # _C.StepGuard of a captured step: its overflow word makes step() a no-op for a clipped frame
         self.active_rows = None           # (int32[1] device tensor, capacity rows): only the live rows of a capacity-sized model are stepped
         self._coef = {}                   # device -> float32[12] scratch of the fused path (make_sink)
-        self._sunk = set()                # id(p) of parameters a rasterizer backward stepped since the last step()
+        # parameters a rasterizer backward stepped since the last step() -> whether that backward also wrote their gradient
+        # (keep_grads); weak keys: an entry dies with a parameter that densification replaced, its id cannot be reused by another
+        self._sunk = WeakIdKeyDictionary()
 
     def load_state_dict(self, state_dict):
         """The device-side step counters and learning rates are derived state: dropped here and re-seeded from the loaded
@@ -85,11 +88,14 @@ class FusedAdam(torch.optim.Optimizer):
         return st["exp_avg"], st["exp_avg_sq"], st["step"], lr_t
 
     def make_sink(self, means3D=None, opacities=None, scales=None, rotations=None, sh=None, sh_rest=None, cov3D_given=False,
-                  colors_given=False):
+                  colors_given=False, colors_need_grad=False):
         """An AdamSink for the tensors ONE rasterizer call is about to receive, or None when none of them can be fused.  A tensor
         is fused when it IS a parameter of this optimizer (the raw leaf, not an activation of it) that requires grad, and the
         library's conditions hold (include/egs_raster.h).  The caller vouches that this rasterizer call is the ONLY consumer of
-        those leaves in the backward to come: their gradient is consumed in place, `p.grad` stays None and step() skips them.
+        those leaves in the backward to come: their gradient is consumed in place, `p.grad` stays None and step() skips them
+        (step() raises if a gradient reached such a leaf through a second path after all).  The one second path render() itself
+        can create is excluded here: colours computed in Python from the positions (`convert_SHs_python`, an `override_color` that
+        depends on xyz) arrive as `colors_precomp` that requires grad (`colors_need_grad`) -- the positions are then left to step().
         All leaves of one sink share betas / eps (one param-group configuration), as the reference's optimizer does."""
         if not self.capturable:
             return None
@@ -105,7 +111,7 @@ class FusedAdam(torch.optim.Optimizer):
         sh_split16 = sh_dc and has_rest and sh_rest.dim() == 3 and sh_rest.shape[1] == 15 and sh_rest.is_contiguous() and \
             sh.data_ptr() % 16 == 0 and sh_rest.data_ptr() % 16 == 0
         colour_ok = not colors_given and (sh_single or sh_split16)
-        want = {_lib.SINK_MEANS3D: (means3D, 3, colors_given or sh_single or sh_split16), _lib.SINK_OPACITY: (opacities, 1, True),
+        want = {_lib.SINK_MEANS3D: (means3D, 3, (colors_given and not colors_need_grad) or sh_single or sh_split16), _lib.SINK_OPACITY: (opacities, 1, True),
                 _lib.SINK_SCALES: (scales, 3, not cov3D_given), _lib.SINK_ROTATIONS: (rotations, 4, not cov3D_given),
                 _lib.SINK_SH: (sh, 3, colour_ok), _lib.SINK_SH_REST: (sh_rest if has_rest else None, 45, colour_ok and sh_split16)}
         struct, owned, ptrs, keep, cfg, params = _lib.AdamSink(), set(), {}, [], None, []
@@ -169,10 +175,16 @@ class FusedAdam(torch.optim.Optimizer):
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
         by_cfg = {}
-        sunk, self._sunk = self._sunk, set()
+        sunk, self._sunk = self._sunk, WeakIdKeyDictionary()
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
-                if p.grad is None or id(p) in sunk:                  # (sunk: a rasterizer backward took this step already, make_sink)
+                if p in sunk:                                        # a rasterizer backward took this step already (make_sink)
+                    if p.grad is not None and not sunk[p]:
+                        raise RuntimeError("FusedAdam: a parameter whose Adam step was taken inside the rasterizer backward also received a gradient "
+                                           "through another path of the loss; that gradient would be lost.  Render without optimizer= (or "
+                                           "GraphedTrainStep(fuse_optimizer=False)) when the rasterizer is not the parameter's only consumer")
+                    continue
+                if p.grad is None:
                     continue
                 self._capturable_state(p, group)
                 st = self.state[p]
@@ -201,7 +213,9 @@ class FusedAdam(torch.optim.Optimizer):
             arr = lambda k: (C.c_void_p * n)(*[t[k].data_ptr() for t in items])
             NN = (C.c_int64 * n)(*[t[0].numel() for t in items])
             RF = (C.c_int32 * n)(*[t[7] for t in items])
-            skip = None if self.guard is None else C.c_void_p(self.guard.overflow.data_ptr())
+            # the guard's overflow word is written by CAPTURED forwards only (egs_forward_enqueue); an eager step() follows an eager
+            # render, which is never clipped, and must not be voided by what the last replay left in that word
+            skip = None if (self.guard is None or not torch.cuda.is_current_stream_capturing()) else C.c_void_p(self.guard.overflow.data_ptr())
             rows = None if self.active_rows is None else C.c_void_p(self.active_rows[0].data_ptr())
             with torch.cuda.device(dev):                             # the kernel itself advances the counters and writes st["step"]
                 _lib.check(L.egs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), NN, arr(4), arr(5), arr(6), float(betas[0]),

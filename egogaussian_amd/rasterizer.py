@@ -46,7 +46,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         # optimizer (extension): a FusedAdam(capturable=True) whose leaves among THIS call's inputs take their step inside the backward
         ctx.sink = None if (optimizer is None or not any(ctx.needs_input_grad)) else optimizer.make_sink(
             means3D=means3D, opacities=opacities, scales=scales, rotations=rotations, sh=sh, sh_rest=sh_rest,
-            cov3D_given=cov3Ds_precomp.numel() != 0, colors_given=colors_precomp.numel() != 0)
+            cov3D_given=cov3Ds_precomp.numel() != 0, colors_given=colors_precomp.numel() != 0,
+            colors_need_grad=bool(colors_precomp.numel() != 0 and ctx.needs_input_grad[3]))
         if sh_rest is None:
             sh_rest = torch.empty(0, device=means3D.device, dtype=torch.float32)
         num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(

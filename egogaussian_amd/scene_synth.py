@@ -222,9 +222,10 @@ class SynthGaussians:
     def _object_selection(self, which_object):
         """fused.object_selection for this model, kept until `_is_object` is replaced or edited (it depends on nothing else)."""
         from . import fused
-        key = (which_object, self._is_object.data_ptr(), self._is_object._version, tuple(self._is_object.shape))
+        n_live = getattr(self, "n_active", None)                # capacity-sized model: only the live rows are Gaussians
+        key = (which_object, self._is_object.data_ptr(), self._is_object._version, tuple(self._is_object.shape), n_live)
         if getattr(self, "_sel_key", None) != key:
-            self._sel_cache = fused.object_selection(self._is_object, which_object, self._xyz.shape[0])
+            self._sel_cache = fused.object_selection(self._is_object, which_object, self._xyz.shape[0], n_live)
             self._sel_key = key
         return self._sel_cache
 
@@ -246,7 +247,7 @@ class SynthGaussians:
             from . import fused
             return fused.rotated_covariance_from_scaling_rotation(
                 self.get_scaling, scaling_modifier, self._rotation, accum_R, self._is_object, which_object,
-                None if tom is None else tom.rot_matrix())
+                None if tom is None else tom.rot_matrix(), selection=self._object_selection(which_object))
         return self._cov.rotated_covariance_from_scaling_rotation(
             self.get_scaling, scaling_modifier, self._rotation, accum_R, self._is_object, which_object,
             None if tom is None else tom.rot_L)

@@ -79,3 +79,19 @@ def test_counter_files_are_tied_to_the_kernel_sources():
         ent, why = bench.stamped(p, "1@1x1", h)
         assert ent is None and "no entry" in why
         assert bench.stamped(os.path.join(d, "absent.json"), "k", h) == (None, "absent.json absent")
+
+
+def test_rccl_environment_is_stated_and_checked(monkeypatch):
+    """The one place the multi-process GPU environment is stated: dist.REQUIRED_ENV; a wrong value is refused, a missing one is set
+    while no HIP context exists (nothing has read it yet)."""
+    from egogaussian_amd import dist as d
+    import pytest
+    assert d.REQUIRED_ENV == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    with pytest.raises(RuntimeError, match="HSA_ENABLE_IPC_MODE_LEGACY=0"):
+        d.require_env("nccl")
+    d.require_env("gloo")                                         # gloo needs nothing
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY")
+    d.require_env("nccl")
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert d.collective_name() == "none"

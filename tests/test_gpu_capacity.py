@@ -235,3 +235,96 @@ def test_capacity_grows_when_densification_outruns_it():
     for _ in range(15):
         step(cam, gt)
     assert float(step(cam, gt)) < l0 and step.ok()
+
+
+@pytest.mark.parametrize("path", ["rasterizer", "producer"])
+@pytest.mark.parametrize("which_object", [1, None])
+def test_capacity_model_with_rot_cov_matches_plain_model(which_object, path):
+    """The fine_all call shape on a capacity-sized model: the object selection -- including the reference's [N,1]-index quirk, whose
+    row-0 gradient multiplier is (number of selected Gaussians [+ 1]) or N + 1 -- counts LIVE rows only, whatever tags the dead rows
+    still hold (an in-place prune leaves the vacated rows behind the live count).  Image bit-identical to the plain model's, the
+    gradients of Gaussian 0 (where the multiplier lands) and of every other row equal."""
+    from egogaussian_amd.capacity import CapacityGaussians
+    from egogaussian_amd.scene_synth import make_camera, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    H, W, n, cap = 96, 160, 4000, 6000
+    sc = _scene(n, H, W)
+    cam, bg = make_camera(2, H, W, device=DEV), torch.tensor([0.05, 0.1, 0.15], device=DEV)
+    tags = (torch.rand(n, 1, generator=torch.Generator().manual_seed(11)) < 0.3).float()
+    th = 0.3
+    accum_R = torch.tensor([[math.cos(th), -math.sin(th), 0.0], [math.sin(th), math.cos(th), 0.0], [0.0, 0.0, 1.0]], device=DEV)
+    plain, capm = SynthGaussians(sc, device=DEV), CapacityGaussians(sc, cap, device=DEV)
+    plain._is_object = tags.to(DEV)
+    capm._is_object[:n] = tags.to(DEV)
+    capm._is_object[n:] = 1.0                                      # stale tags behind the live count
+    outs = []
+    for pc in (plain, capm):
+        pc.rotate_in_rasterizer = path == "rasterizer"
+        o = render(cam, pc, Pipe, bg, rot_cov=True, accum_R=accum_R, which_object=which_object, during_training=False)
+        (o["render"].sum() + 0.5 * o["alpha"].sum()).backward()
+        outs.append(o)
+    a, b = outs
+    assert torch.equal(a["render"], b["render"]) and torch.equal(a["radii"], b["radii"][:n])
+    for pa, pb in ((plain._scaling, capm._scaling), (plain._rotation, capm._rotation), (plain._xyz, capm._xyz), (plain._opacity, capm._opacity)):
+        assert float(pb.grad[n:].abs().sum()) == 0.0
+        scale = float(pa.grad.abs().max())
+        assert float((pa.grad - pb.grad[:n]).abs().max()) <= 2e-5 * scale, (float((pa.grad - pb.grad[:n]).abs().max()), scale)
+    # the multiplier really is in play on row 0 (otherwise the comparison above would prove nothing)
+    assert float(plain._scaling.grad[0].abs().max()) > 0
+
+
+def test_replay_after_grow_without_recapture_is_refused():
+    """CapacityGaussians.grow() frees the arrays a captured step points at; replaying that step must raise, not touch freed memory."""
+    from egogaussian_amd.capacity import CapacityGaussians
+    from egogaussian_amd.graph import GraphedTrainStep
+    from egogaussian_amd.scene_synth import make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    H, W, n = 64, 96, 2000
+    teacher = _scene(n, H, W)
+    cam, bg = make_camera(0, H, W, device=DEV), torch.zeros(3, device=DEV)
+    with torch.no_grad():
+        gt = render(cam, SynthGaussians(teacher, device=DEV, requires_grad=False), Pipe, bg)["render"].clone()
+    pc = CapacityGaussians(perturb_student(teacher), n + 100, device=DEV)
+    pc.training_setup(capturable=True)
+    step = GraphedTrainStep(pc, pc.optimizer, bg, 0.2).capture(cam, gt, warmup=2, capacity_margin=3.0)
+    step(cam, gt)
+    pc.grow(2 * n)
+    with pytest.raises(RuntimeError, match="recapture"):
+        step(cam, gt)
+    step.recapture(warmup=1)
+    step(cam, gt)
+    torch.cuda.synchronize()
+    assert step.ok()
+    # an eager optimizer step after replays is never voided by the guard word the last replay left behind
+    step.guard.overflow[0] = 1
+    before = pc._xyz.detach()[:n].clone()
+    pc.optimizer.zero_grad(set_to_none=True)
+    out = render(cam, pc, Pipe, bg)
+    out["render"].sum().backward()
+    pc.optimizer.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(pc._xyz.detach()[:n], before)
+
+
+def test_second_gradient_path_into_a_fused_leaf_is_refused():
+    """convert_SHs_python computes the colours from the positions in Python: the positions then receive gradient through the colour
+    path as well, so the rasterizer backward may not take their Adam step (optim.FusedAdam.make_sink leaves them to step())."""
+    from egogaussian_amd.scene_synth import make_camera, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.optim import FusedAdam
+    H, W, n = 64, 96, 2000
+    pc = SynthGaussians(_scene(n, H, W), device=DEV)
+    cam, bg = make_camera(0, H, W, device=DEV), torch.zeros(3, device=DEV)
+    opt = FusedAdam([{"params": [pc._xyz], "lr": 1e-3}, {"params": [pc._features_dc], "lr": 1e-3}, {"params": [pc._opacity], "lr": 1e-3},
+                     {"params": [pc._scaling], "lr": 1e-3}, {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15, capturable=True)
+
+    class PyPipe(Pipe):
+        convert_SHs_python = True
+    out = render(cam, pc, PyPipe, bg, optimizer=opt)
+    out["render"].sum().backward()
+    assert pc._xyz.grad is not None                                 # left to step(): the colour path's share is in it
+    assert pc._opacity.grad is None and pc._scaling.grad is None     # these were stepped inside the backward
+    x0 = pc._xyz.detach().clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(pc._xyz.detach(), x0)
