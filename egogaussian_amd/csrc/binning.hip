@@ -552,9 +552,12 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
                                                     uint2* __restrict__ ranges) {
     constexpr int TS_THREADS = 64 * TS_WAVES, TS_ITEMS = TS_CAP / TS_THREADS;
     static_assert(TS_CAP * 2 >= TS_WAVES * TS_DIGITS, "the oversize path keeps its counters in the exchange buffer");
+    constexpr int TS_NB = TS_CAP / 4;                                  // depth buckets of the one-pass path (512 for 2 048 keys)
+    static_assert(2 * TS_NB >= TS_WAVES * 256 && TS_NB % 256 == 0, "the digit counters of the fallback passes live in the bucket arrays");
     __shared__ uint64_t xbuf[TS_CAP];
-    __shared__ uint32_t cnt[TS_WAVES][256];
+    __shared__ uint32_t bkt[2 * TS_NB];                                // one-pass path: bucket cursors [TS_NB], bucket starts [TS_NB]; fallback: cnt[TS_WAVES][256]
     __shared__ uint32_t lds8[2 * TS_WAVES];
+    uint32_t (*cnt)[256] = reinterpret_cast<uint32_t (*)[256]>(bkt);
     const int tile = blockIdx.x;
     SORT_STAMP(0);
     const uint32_t beg = table_scanned[(size_t)tile * stride];
@@ -589,40 +592,53 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
             if (ok) { const uint32_t dw = (uint32_t)(key[r] >> 32); dmin = min(dmin, dw); dmax = max(dmax, dw); }
         }
         SORT_STAMP(1);
+        for (int k = threadIdx.x; k < TS_NB; k += TS_THREADS) bkt[k] = 0;     // (block_min_max's first barrier orders this before the counting)
         block_min_max<TS_WAVES>(dmin, dmax, lds8);
         SORT_STAMP(2);
         const int depth_passes = (32 - __clz((int)(dmax - dmin)) + TS_DBITS - 1) / TS_DBITS;     // 0 when every depth is equal
         const int npass = index_passes + depth_passes;
-        // Barriers per pass: 4.  Every wave clears ITS OWN counters (nobody else touches them between the barrier after the
-        // scatter and the one after the ranking), so clearing needs no workgroup barrier.
-        for (int k = lane; k < 256; k += 64) cnt[w][k] = 0;
-        if (depth_passes >= 2) {
-            // ---- one pass on the TOP nine bits of (depth - tile minimum), then every key counts the smaller keys of its own bucket ----
-            // The top digit spreads a tile's instances over up to 512 buckets in depth order (a couple of keys each unless the depths
-            // cluster); inside a bucket the full 64-bit (depth, index) keys are compared directly, which also settles depth ties.  One
-            // ranking pass + a short loop instead of three passes (-7 us per frame at config C).  A bucket of more than TS_BUCKET_MAX keys
-            // (depths piled up in one 1/512 of the range) sends the tile to the digit-by-digit passes below.
-            const int sh = (32 - __clz((int)(dmax - dmin))) - TS_DBITS;
-            uint32_t rank[TS_ITEMS];
+        if (dmax > dmin) {
+            // ---- one pass: TS_NB buckets LINEAR in the depth value, then every key counts the smaller keys of its own bucket ----
+            // bucket(z) = floor((z - zmin) * TS_NB / (zmax - zmin)) is non-decreasing in z (IEEE subtraction, multiplication and the
+            // conversion are monotonic) and depths are positive floats, which order like their bit patterns: a valid first digit.
+            // It spreads a tile's instances evenly whatever the exponent range -- the top nine bits of the pattern (rounds 1-2) put a
+            // quarter of a [2, 10] depth range into a sixteenth of the buckets.  Where a key lands INSIDE its bucket does not matter:
+            // its final position is the bucket's start + the number of smaller (depth, index) keys in the bucket, which also settles
+            // depth ties.  So a bucket needs ONE shared counter -- no per-wave stable ranks, no per-wave digit bases.  A bucket of
+            // more than TS_BUCKET_MAX keys (depths piled up) sends the tile to the digit-by-digit passes below.
+            const float zmin = __uint_as_float(dmin), zscale = (float)TS_NB / (__uint_as_float(dmax) - zmin);
+            auto bucket = [&](uint64_t kv) -> uint32_t {
+                const float f = (__uint_as_float((uint32_t)(kv >> 32)) - zmin) * zscale;
+                return (uint32_t)fminf(fmaxf(f, 0.f), (float)(TS_NB - 1));          // (NaN -> 0)
+            };
+            uint32_t dg[TS_ITEMS];
 #pragma unroll
             for (int r = 0; r < TS_ITEMS; r++) {
-                rank[r] = 0;
-                if (r * 64u < chunk) {
-                    const uint32_t i = wbeg + r * 64 + lane;
-                    rank[r] = wave_digit_rank<RANK_ATOMIC, true>(cnt[w], ((uint32_t)(key[r] >> 32) - dmin) >> sh, i < n, lane, lt);
-                }
+                const uint32_t i = wbeg + r * 64 + lane;
+                dg[r] = bucket(key[r]);
+                if (r * 64u < chunk && i < n) atomicAdd(&bkt[dg[r]], 1u);
             }
             SORT_STAMP(3);
             __syncthreads();
-            digit_bases_packed<TS_WAVES>(cnt, lds8);
+            {   // exclusive scan of the bucket counts: the first 256 threads take TS_NB / 256 consecutive buckets each
+                constexpr int PER = TS_NB / 256;
+                uint32_t c[PER], sum = 0;
+                if (threadIdx.x < 256) {
+#pragma unroll
+                    for (int k = 0; k < PER; k++) { c[k] = bkt[threadIdx.x * PER + k]; sum += c[k]; }
+                }
+                uint32_t base = scan_first_256(sum, lds8);
+                if (threadIdx.x < 256) {
+#pragma unroll
+                    for (int k = 0; k < PER; k++) { bkt[threadIdx.x * PER + k] = base; bkt[TS_NB + threadIdx.x * PER + k] = base; base += c[k]; }
+                }
+                __syncthreads();
+            }
             SORT_STAMP(4);
 #pragma unroll
             for (int r = 0; r < TS_ITEMS; r++) {
                 const uint32_t i = wbeg + r * 64 + lane;
-                if (r * 64u < chunk && i < n) {
-                    const uint32_t d = ((uint32_t)(key[r] >> 32) - dmin) >> sh;
-                    xbuf[((cnt[w][d >> 1] >> (16u * (d & 1u))) & 0xffffu) + rank[r]] = key[r];
-                }
+                if (r * 64u < chunk && i < n) xbuf[atomicAdd(&bkt[dg[r]], 1u)] = key[r];
             }
             __syncthreads();
             SORT_STAMP(5);
@@ -632,9 +648,8 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
                 const uint32_t i = wbeg + r * 64 + lane;
                 if (r * 64u < chunk && i < n) {
                     const uint64_t k = xbuf[i];
-                    const uint32_t d = ((uint32_t)(k >> 32) - dmin) >> sh;
-                    const uint32_t bs = (cnt[0][d >> 1] >> (16u * (d & 1u))) & 0xffffu;           // wave 0's base = start of the bucket
-                    const uint32_t be = d + 1 < TS_DIGITS ? (cnt[0][(d + 1) >> 1] >> (16u * ((d + 1) & 1u))) & 0xffffu : n;
+                    const uint32_t d = bucket(k);
+                    const uint32_t bs = bkt[TS_NB + d], be = d + 1 < TS_NB ? bkt[TS_NB + d + 1] : n;
                     if (be - bs > TS_BUCKET_MAX) { big = true; continue; }
                     uint32_t smaller = 0;
                     for (uint32_t q = bs; q < be; q++) smaller += xbuf[q] < k ? 1u : 0u;
@@ -643,8 +658,12 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
             }
             SORT_STAMP(6);
             if (!__syncthreads_or(big ? 1 : 0)) return;
-            for (int k = lane; k < 256; k += 64) cnt[w][k] = 0;             // an overfull bucket: start over, digit by digit (keys are still in registers)
+        } else {
+            __syncthreads();
         }
+        // Barriers per pass: 4.  Every wave clears ITS OWN counters (nobody else touches them between the barrier after the
+        // scatter and the one after the ranking), so clearing needs no workgroup barrier.  (The bucket arrays become the counters.)
+        for (int k = lane; k < 256; k += 64) cnt[w][k] = 0;
         for (int phase = depth_passes ? 0 : 1; phase < 2; phase++) {
             for (int p = phase == 0 ? index_passes : 0; p < npass; p++) {
                 uint32_t rank[TS_ITEMS];
