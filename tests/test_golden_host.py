@@ -247,3 +247,156 @@ def test_rot_cov_render_through_hip_matches_reference_end_to_end(path):
                         (pc._opacity, "g_opacity"), (out["viewspace_points"], "g_viewspace")):
             assert close(p.grad, g[k + name]), (f, name)
             p.grad = None
+
+
+# ---- the object-pose training step, override_color, convert_SHs_python -- fixture boundary_train.npz (make_golden_training.py) ----
+def _model_from_train(g, k, device="cpu", fused=True, sh_degree=0):
+    from egogaussian_amd.scene_synth import SynthGaussians
+    scene = dict(xyz=g[k + "xyz"], features=g[k + "features"], log_scale=g[k + "log_scale"], quat=g[k + "quat"], opacity_logit=g[k + "opacity_logit"])
+    pc = SynthGaussians(scene, device=device, fused=fused, sh_degree=sh_degree)
+    pc._is_object = torch.tensor(g[k + "is_object"], device=device)
+    return pc
+
+
+def _cam_from_train(g, k, device="cpu"):
+    from egogaussian_amd.scene_synth import SynthCamera
+    return SynthCamera(g[k + "wvt"].T, int(g["H"]), int(g["W"]), float(g["fov"][0]), float(g["fov"][1]), device=device)
+
+
+def _object_move(g, device="cpu"):
+    from egogaussian_amd.geometry import ObjectMove
+    tom = ObjectMove().to(device)
+    with torch.no_grad():
+        tom.obj_rotation_6d.copy_(torch.tensor(g["pose_rot6d"], device=device))
+    return tom
+
+
+def test_object_move_matches_reference_geometry_utils():
+    """geometry.ObjectMove / rot6d_to_matrix against what the reference's utils/geometry_utils.py produced: the trainable rotation's
+    matrix enters the captured covariance, and its gradient is in the fixture."""
+    from egogaussian_amd.geometry import rot6d_to_matrix, matrix_to_rot6d
+    g = load("boundary_train.npz")
+    tom = _object_move(g)
+    M = tom.rot_matrix()
+    assert M.shape == (3, 3) and torch.allclose(M @ M.t(), torch.eye(3), atol=1e-6) and abs(float(torch.det(M.detach())) - 1.0) < 1e-5
+    assert torch.allclose(matrix_to_rot6d(M), M[:, :2]) and torch.allclose(rot6d_to_matrix(matrix_to_rot6d(M)), M, atol=1e-6)
+    L = torch.randn(7, 3, 3, generator=torch.Generator().manual_seed(0))
+    assert torch.allclose(tom.rot_L(L), M @ L)
+    pts = torch.randn(5, 3, generator=torch.Generator().manual_seed(1))
+    assert torch.allclose(tom(pts), pts @ M.t())                      # (translation is zero in the fixture)
+
+
+def test_training_call_shapes_hand_the_rasterizer_what_the_reference_does():
+    """CPU (PyTorch mirror): the arguments render() gives the rasterizer for the three call shapes of boundary_train.npz equal the
+    reference's -- the trainable-rotation covariance (scene/gaussian_model.py:55-56 through trainable_object_move.rot_L), the
+    override colours, the Python-evaluated SH colours -- and the C oracle reproduces the captured images from them."""
+    from oracle.oracle import Oracle
+    from egogaussian_amd.sh import eval_sh
+    g = load("boundary_train.npz")
+    H, W = int(g["H"]), int(g["W"])
+    tan = (math.tan(float(g["fov"][0]) / 2), math.tan(float(g["fov"][1]) / 2))
+    # pose: covariance with the trainable rotation on top of accum_R, [N,1]-index quirk included
+    pc = _model_from_train(g, "pose_", fused=False)
+    pc.trainable_object_move = _object_move(g)
+    cov = pc.get_rotated_covariance(T(g["pose_accum_R"]), 1, True, 1.0)
+    assert np.allclose(cov.detach().numpy(), g["pose_arg_cov3D_precomp"], rtol=2e-5, atol=1e-9)
+    cov_frozen = pc.get_rotated_covariance(T(g["pose_accum_R"]), 1, False, 1.0)
+    assert not np.allclose(cov_frozen.detach().numpy(), g["pose_arg_cov3D_precomp"], rtol=1e-3)      # the trainable rotation IS in play
+    assert bool(g["pose_arg_cov3D_precomp_rg"]) and bool(g["pose_arg_scales_absent"]) and bool(g["pose_arg_colors_precomp_absent"])
+    # override_color: passed through as colors_precomp, no SH
+    assert np.array_equal(g["override_arg_colors_precomp"], g["override_override_color"]) and bool(g["override_arg_shs_absent"])
+    # convert_SHs_python: clamp_min(eval_sh(deg, features^T, normalised xyz - campos) + 0.5, 0)   (gaussian_renderer/__init__.py:78-84)
+    pcs = _model_from_train(g, "shs_python_", fused=False, sh_degree=2)
+    cam = _cam_from_train(g, "shs_python_")
+    feats = pcs.get_features
+    dirs = pcs.get_xyz - cam.camera_center.repeat(feats.shape[0], 1)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    cols = torch.clamp_min(eval_sh(2, feats.transpose(1, 2).view(-1, 3, 9), dirs) + 0.5, 0.0)
+    assert int(g["shs_python_arg_sh_degree"]) == 2 and bool(g["shs_python_arg_shs_absent"])
+    assert np.allclose(cols.detach().numpy(), g["shs_python_arg_colors_precomp"], rtol=1e-5, atol=1e-6)
+    for k, bgk in (("pose_", None), ("override_", "override_bg"), ("shs_python_", "shs_python_bg")):
+        kw = dict(colors_precomp=g[k + "arg_colors_precomp"]) if not bool(g[k + "arg_colors_precomp_absent"]) else dict(shs=g[k + "arg_shs"])
+        st = Oracle(np.float32).forward(means3D=g[k + "arg_means3D"], opacities=g[k + "arg_opacities"], cov3D_precomp=g[k + "arg_cov3D_precomp"],
+                                        viewmatrix=g[k + "wvt"], projmatrix=g[k + "full"], campos=g[k + "center"],
+                                        bg=np.zeros(3, np.float32) if bgk is None else g[bgk], image_height=H, image_width=W, tanfovx=tan[0], tanfovy=tan[1], **kw)
+        assert np.array_equal(st["radii"], g[k + "radii"]), k
+        for name, key in (("color", "render"), ("depth", "depth"), ("alpha", "alpha")):
+            assert np.abs(st[name] - g[k + key]).max() < 2e-5 * max(1.0, np.abs(g[k + key]).max()), (k, name)
+
+
+def _pose_loss(image, alpha, g, dev, fused_loss):
+    """The object-pose stages' loss (/root/reference/trainers/fine_obj.py:136-149) with both hand-mask hooks."""
+    from egogaussian_amd.losses import l1_loss, l2_loss, ssim
+    hand, obj = torch.tensor(g["pose_hand"], device=dev), torch.tensor(g["pose_obj_mask"], device=dev)
+    gt = torch.tensor(g["pose_gt"], device=dev) * obj
+    lam, l1a, l2a = [float(x) for x in g["pose_lambdas"]]
+    alpha.register_hook(lambda grad: grad * (1 - hand))
+    if fused_loss:
+        from egogaussian_amd.fused import l1_ssim_loss
+        img_loss = l1_ssim_loss(image, gt, lam, grad_gate=(1 - hand)[0])          # the hook on the image, inside the fused loss's backward
+    else:
+        image.register_hook(lambda grad: grad * (1 - hand))
+        img_loss = (1.0 - lam) * l1_loss(gt, image) + lam * (1.0 - ssim(gt, image))
+    return img_loss + l1a * l1_loss(obj, alpha) + l2a * l2_loss(obj, alpha)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused_loss", [False, True], ids=["torch-loss", "hip-loss"])
+@pytest.mark.parametrize("path", ["rasterizer", "producer", "torch"])
+def test_pose_training_step_through_hip_matches_reference_end_to_end(path, fused_loss):
+    """GPU: the training step of the object-pose stages -- render(rot_cov=True, accum_R, which_object=1, during_training=True) with
+    gaussians.trainable_object_move set, hand-mask hooks on image AND alpha, image + L1 + L2 alpha losses -- reproduces the image,
+    the alpha map, the loss, every parameter gradient and d loss / d obj_rotation_6d that the reference's render() + GaussianModel +
+    ObjectMove produced.  `rasterizer`: the model prefers the in-rasterizer object rotation, which cannot return the rotation's
+    gradient, so it must fall back to the covariance producer by itself; `producer`: cov3d.hip; `torch`: the PyTorch mirror."""
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.scene_synth import Pipe
+    g = load("boundary_train.npz")
+    dev = "cuda:0"
+    pc = _model_from_train(g, "pose_", dev, fused=path != "torch")
+    pc.rotate_in_rasterizer = path == "rasterizer"
+    pc.trainable_object_move = tom = _object_move(g, dev)
+    cam = _cam_from_train(g, "pose_", dev)
+    out = render(cam, pc, Pipe, torch.zeros(3, device=dev), rot_cov=True, accum_R=torch.tensor(g["pose_accum_R"], device=dev), which_object=1,
+                 during_training=True)
+    loss = _pose_loss(out["render"], out["alpha"], g, dev, fused_loss)
+    loss.backward()
+    close = lambda a, b, tol=1e-4: np.abs(a.detach().cpu().numpy() - b).max() <= tol * max(np.abs(b).max(), 1e-12)
+    assert np.array_equal(out["radii"].cpu().numpy(), g["pose_radii"])
+    assert close(out["render"], g["pose_render"]) and close(out["alpha"], g["pose_alpha"]) and close(out["depth"], g["pose_depth"])
+    assert abs(float(loss.detach()) - float(g["pose_loss"])) <= 1e-5 * abs(float(g["pose_loss"]))
+    for p, name in ((pc._xyz, "g_xyz"), (pc._features_dc, "g_features_dc"), (pc._scaling, "g_scaling"), (pc._rotation, "g_rotation"),
+                    (pc._opacity, "g_opacity"), (out["viewspace_points"], "g_viewspace")):
+        assert close(p.grad, g["pose_" + name], 2e-4), name
+    assert tom.obj_rotation_6d.grad is not None and float(np.abs(g["pose_g_rot6d"]).max()) > 0
+    assert close(tom.obj_rotation_6d.grad, g["pose_g_rot6d"], 2e-4)
+
+
+@pytest.mark.gpu
+def test_override_color_and_python_sh_through_hip_match_reference():
+    """GPU: render(override_color=c) and render() with pipe.convert_SHs_python (/root/reference/gaussian_renderer/__init__.py:75-87)
+    reproduce the reference's images and gradients -- to the override colours; to the features and, through the view directions of
+    the Python SH evaluation, to the positions."""
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.scene_synth import Pipe
+    g = load("boundary_train.npz")
+    dev = "cuda:0"
+    close = lambda a, b, tol=1e-4: np.abs(a.detach().cpu().numpy() - b).max() <= tol * max(np.abs(b).max(), 1e-12)
+    pc, cam = _model_from_train(g, "override_", dev), _cam_from_train(g, "override_", dev)
+    oc = torch.tensor(g["override_override_color"], device=dev, requires_grad=True)
+    out = render(cam, pc, Pipe, torch.tensor(g["override_bg"], device=dev), override_color=oc)
+    (out["render"] * torch.tensor(g["override_wc"], device=dev)).sum().backward()
+    assert np.array_equal(out["radii"].cpu().numpy(), g["override_radii"]) and close(out["render"], g["override_render"])
+    assert close(oc.grad, g["override_g_override_color"]) and close(pc._xyz.grad, g["override_g_xyz"]) and close(pc._opacity.grad, g["override_g_opacity"])
+    assert close(pc._scaling.grad, g["override_g_scaling"]) and close(pc._rotation.grad, g["override_g_rotation"])
+    assert pc._features_dc.grad is None and g["override_g_features_dc"].size == 0        # the colours bypass the features, in both
+
+    class PyPipe(Pipe):
+        convert_SHs_python = True
+    pc, cam = _model_from_train(g, "shs_python_", dev, sh_degree=2), _cam_from_train(g, "shs_python_", dev)
+    out = render(cam, pc, PyPipe, torch.tensor(g["shs_python_bg"], device=dev))
+    (out["render"] * torch.tensor(g["shs_python_wc"], device=dev)).sum().backward()
+    assert np.array_equal(out["radii"].cpu().numpy(), g["shs_python_radii"]) and close(out["render"], g["shs_python_render"])
+    for p, name in ((pc._xyz, "g_xyz"), (pc._features_dc, "g_features_dc"), (pc._features_rest, "g_features_rest"), (pc._scaling, "g_scaling"),
+                    (pc._rotation, "g_rotation"), (pc._opacity, "g_opacity")):
+        assert close(p.grad, g["shs_python_" + name], 2e-4), name
