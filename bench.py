@@ -260,6 +260,13 @@ def main():
                     help="wall-clock milliseconds of forward-only renders (no training) right before the warm-up steps: clock spin-up; 0 = none")
     ap.add_argument("--steps-per-replay", type=int, default=5,
                     help="training steps captured into one hipGraph (each on its own frame); lowered to a divisor of --steps when needed; 1 = one launch per step")
+    ap.add_argument("--item-every-step", action="store_true",
+                    help="with --no-graph: read loss.item() after every step, as /root/reference/trainers/train_static.py:112 does (a host "
+                         "synchronisation per iteration), and report the host time spent inside render() and loss.backward()")
+    ap.add_argument("--eager-fast", action="store_true",
+                    help="with --no-graph: the eager loop as a trainer on this package's fast paths runs it -- the Adam step of the parameters the "
+                         "render differentiates taken inside the rasterizer backward (render(optimizer=...)), the backward's preparation carried by "
+                         "the loss launch, autograd on the calling thread (torch.autograd.set_multithreading_enabled(False))")
     ap.add_argument("--no-force-dist", action="store_true",
                     help="N = 1 only: do not create the one-rank RCCL group (by default the single-GPU run initialises RCCL with device_id, and its "
                          "barriers and scalar all-reduces are real collectives -- the same code path as N > 1)")
@@ -289,6 +296,8 @@ def main():
             raise
         collective_error = f"{type(exc).__name__}: {exc}"
 
+    if args.eager_fast:
+        torch.autograd.set_multithreading_enabled(False)          # backward on the calling thread: no hand-off to the device thread per step
     from egogaussian_amd import lib as egs_lib, _C
     from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe, N_FRAMES
     from egogaussian_amd.renderer import render
@@ -329,8 +338,9 @@ def main():
         pc = SynthGaussians(student, device=dev, sh_degree=D, fused=not args.torch_host_ops)
         pc._is_object = torch.tensor(is_object, device=dev)
         use_graph = not (args.no_graph or args.torch_host_ops or args.op_only)
+        eager_fast = bool(args.eager_fast and args.no_graph and not (args.torch_host_ops or args.op_only))
         Adam = (lambda gr, **kw: torch.optim.Adam(gr, fused=True, **kw)) if args.torch_host_ops else \
-            (lambda gr, **kw: FusedAdam(gr, capturable=use_graph, **kw))
+            (lambda gr, **kw: FusedAdam(gr, capturable=use_graph or eager_fast, **kw))
         opt = Adam([                                                # /root/reference/scene/gaussian_model.py:180-198 defaults
             {"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3},
             *([{"params": [pc._features_rest], "lr": 2.5e-3 / 20.0}] if D > 0 else []),
@@ -349,9 +359,13 @@ def main():
         loss_acc = torch.zeros((), device=dev)
         r_sum = [0, 0]
 
+        host_t = [0.0, 0.0, 0]                                      # host seconds inside render() / loss.backward(), calls
+
         def eager_step(i):
             k = i % n_used
-            out = render(cams[k], pc, Pipe, bg, **rkw(rot[k] if dynamic else None))
+            th0 = time.perf_counter()
+            out = render(cams[k], pc, Pipe, bg, **({"optimizer": opt} if eager_fast else {}), **rkw(rot[k] if dynamic else None))
+            th1 = time.perf_counter()
             if args.op_only:
                 loss = (out["render"] * up_c).sum() + (out["depth"] * up_d).sum() + (out["alpha"] * up_a).sum()
             elif args.torch_host_ops:
@@ -361,13 +375,18 @@ def main():
                     img.register_hook(lambda grad: grad * gk)
                 loss = training_loss(img, gts[k])
             else:
-                loss = l1_ssim_loss(out["render"], gts[k], 0.2, grad_gate=gates[k] if dynamic else None)
+                loss = l1_ssim_loss(out["render"], gts[k], 0.2, grad_gate=gates[k] if dynamic else None, raster_prologue=eager_fast)
+            th2 = time.perf_counter()
             loss.backward()
+            th3 = time.perf_counter()
             if not args.op_only:
                 opt.step()
             opt.zero_grad(set_to_none=True)
+            if args.item_every_step:
+                loss.item()                                          # the reference logs the loss every iteration: one host synchronisation
             loss_acc.add_(loss.detach())
             r_sum[0] += _C.stats["num_rendered"]; r_sum[1] += 1
+            host_t[0] += th1 - th0; host_t[1] += th3 - th2; host_t[2] += 1
 
         psnr_start = eval_psnr()
         step, graphed = eager_step, None
@@ -409,7 +428,7 @@ def main():
             eager_step(i)
         for i in range(n_warm % spr if graphed is not None else 0, n_warm, spr):
             step(i)
-        loss_acc.zero_(); r_sum[:] = [0, 0]
+        loss_acc.zero_(); r_sum[:] = [0, 0]; host_t[:] = [0.0, 0.0, 0]
         if graphed is not None:
             graphed.loss_sum.zero_()
         # (the event pool of the stage timer is set up BEFORE the last synchronisation: nothing but the barrier sits between the
@@ -426,6 +445,7 @@ def main():
         egs_dist.barrier()
         torch.cuda.synchronize()
         stages = egs_lib.profile_end()
+        host_us = None if (graphed is not None or not host_t[2]) else (1e6 * host_t[0] / host_t[2], 1e6 * host_t[1] / host_t[2])
         stage_timing = "HIP events recorded by the library on the launch stream inside the timed region"
         overflow = None
         if graphed is not None:
@@ -462,7 +482,7 @@ def main():
         return dict(elapsed=elapsed, stages=stages, stage_timing=stage_timing, loss=loss_acc.item(), psnr_end=psnr_end, psnr_start=psnr_start,
                     R_mean=float(r_sum[0]) / max(r_sum[1], 1), kept_ratio=kept / max(rect, 1), pairs=pairs / n_s, visits=visits / n_s,
                     list_mean=float(np.mean(list_mean)), list_max=int(max(list_max)),
-                    use_graph=use_graph, checksum=checksum, overflow=overflow, pc=pc, cams=cams, spr=spr)
+                    use_graph=use_graph, checksum=checksum, overflow=overflow, pc=pc, cams=cams, spr=spr, host_us=host_us)
 
     def reduce_leg(r):
         """Scalars only (RCCL over xGMI): max-over-ranks time, sums of loss / PSNR / instance counts."""
@@ -592,6 +612,9 @@ def main():
         "psnr_db": round(red["psnr"], 3), "psnr_db_before": round(red["psnr_before"], 3),
         "psnr_views": "8 held-out views at half-frame phases across the orbit (never trained on)", "mean_loss": round(red["mean_loss"], 6),
         "rasterizer_ms_per_step": round(op_ms, 4),
+        **({"host_us_per_forward": round(head["host_us"][0], 1), "host_us_per_backward": round(head["host_us"][1], 1),
+            "host_us_note": "host time inside render() and inside loss.backward() per step (Python, ctypes, launches, the wait for the instance count), "
+                            "GPU not waited for"} if head.get("host_us") else {}),
         "roofline": roofline, "stages": stage_rows, "cpu_baseline": cpu,
     }
     if head_name == "static" and "dynamic" in legs:
@@ -636,6 +659,23 @@ def main():
                                             "launch": j["config"]["launch"]}
         except Exception as exc:
             out["reference_shaped_step"] = {"error": f"{type(exc).__name__}: {exc}"}
+        # Between the two: every kernel launched from Python (no hipGraph), but with this package's host ops -- raw parameters into the
+        # rasterizer, the fused loss, FusedAdam.step() -- and `loss.item()` read every iteration as the reference's loop does
+        # (/root/reference/trainers/train_static.py:112).  What a trainer gets from `import egogaussian_amd; egogaussian_amd.attach(gaussians)`
+        # plus this package's render() and loss, with its loop otherwise unchanged.
+        try:
+            leg = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-graph", "--item-every-step", "--eager-fast", "--steps", str(min(args.steps, 200)),
+                                  "--warmup", "20", "--no-cpu-baseline", "--gaussians", str(N), "--height", str(H), "--width", str(W)],
+                                 capture_output=True, text=True, timeout=600)
+            j = json.loads(leg.stdout.strip().splitlines()[-1])
+            out["eager_fused_step"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                                       "host_us_per_forward": j.get("host_us_per_forward"), "host_us_per_backward": j.get("host_us_per_backward"),
+                                       "rasterizer_ms_per_step": j["rasterizer_ms_per_step"], "psnr_db": j["psnr_db"],
+                                       "launch": "eager: every kernel launched from Python, loss.item() after every step (one host synchronisation per iteration); "
+                                                 "render(optimizer=FusedAdam): the Adam step inside the rasterizer backward; autograd on the calling thread",
+                                       "step": j["config"]["workload"].split("step = ")[-1]}
+        except Exception as exc:
+            out["eager_fused_step"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world == 1 and not args.no_config_legs and not (args.op_only or args.torch_host_ops or args.no_graph or args.dynamic or D > 0):
         # BASELINE.json configs 2 and 5 on the same GPU, in this process (the training legs' tensors are released first)
         legs.clear(); head = None

@@ -13,6 +13,7 @@ import os
 import torch
 
 from . import lib as _lib
+from . import _hip
 
 
 # Diagnostics of the most recent forward of this process (instance count, capacity, retries, the device-side total, the image
@@ -64,10 +65,51 @@ def last_instance_count(device=None, P=None):
 _placement = {}
 
 
+_NO_PLACEMENT = bool(os.environ.get("EGS_NO_PLACEMENT"))      # switch for A/B measurements (read once)
+_sizes = {}                      # (P, W, H, capacity) -> (geometry bytes, image bytes, binning bytes, offset of the device-side instance count)
+
+
+def _buffer_sizes(L, P, W, H, cap):
+    """Sizes of the three opaque buffers for this problem size, asked of the library once per (P, W, H, capacity)."""
+    key = (P, W, H, cap)
+    ent = _sizes.get(key)
+    if ent is None:
+        if len(_sizes) > 256:
+            _sizes.clear()
+        lay = _lib.BinningLayout()
+        L.egs_get_binning_layout(P, cap, W, H, C.byref(lay))
+        ent = _sizes[key] = (int(L.egs_geom_bytes(P)), int(L.egs_image_bytes(W, H)), int(L.egs_binning_bytes(P, cap, W, H)), int(lay.total))
+    return ent
+
+
+def _carve(dev, shapes):
+    """One float32 allocation, one contiguous view per shape (None -> None), every view starting on a 256-byte boundary: an
+    allocator call costs ~1.5 us of host time, the backward used to make eight."""
+    offs, tot = [], 0
+    for sh in shapes:
+        offs.append(tot)
+        if sh is not None:
+            n = 1
+            for d in sh:
+                n *= d
+            tot += (n + 63) & ~63
+    buf = torch.empty((max(tot, 1),), device=dev, dtype=torch.float32)
+    out = []
+    for sh, o in zip(shapes, offs):
+        if sh is None:
+            out.append(None); continue
+        n = 1
+        for d in sh:
+            n *= d
+        out.append(buf[o:o + n].view(sh))
+    return out
+
+
 def placement_buffer(dev, W, H):
     """The persistent placement buffer (include/egs_raster.h) of forwards at W x H on the current stream of `dev`: what the previous
     such forward's blend spent per quadrant, by which the next one places its tiles.  Zero-filled when created."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(W), int(H), torch.cuda.current_stream(dev).cuda_stream)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, int(W), int(H), _hip._raw_stream(idx))
     t = _placement.get(key)
     if t is None:
         # (never dropped: a captured hipGraph keeps the address; 40 KB per resolution and stream at 960x540)
@@ -117,8 +159,7 @@ def _f32c(t, name):
     return t.contiguous()
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = _hip.stream_of           # (device) -> c_void_p of its current stream
 
 
 def _opt(t):
@@ -158,27 +199,25 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         if sh is None or sh.shape[1] != 1 or sh_rest.shape[0] != P:
             raise RuntimeError("sh_rest goes with sh = the DC block [P, 1, 3]")
         M = 1 + sh_rest.shape[1]
-    with torch.cuda.device(dev):
-        opts = dict(device=dev, dtype=torch.float32)
-        out_color = torch.empty((3, H, W), **opts)
-        out_depth = torch.empty((1, H, W), **opts)
-        out_alpha = torch.empty((1, H, W), **opts)
+    with _hip.device_ctx(dev):
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        cap = _capacity_hint.get(key, 0)
+        gb, ib, bb, total_off = _buffer_sizes(L, P, W, H, cap)
+        planes = torch.empty((5, H, W), device=dev, dtype=torch.float32)       # colour, depth, alpha: one allocation, three contiguous views
+        out_color, out_depth, out_alpha = planes[0:3], planes[3:4], planes[4:5]
         radii = torch.empty((P,), device=dev, dtype=torch.int32)
-        geom = torch.empty((L.egs_geom_bytes(P),), device=dev, dtype=torch.uint8)
-        img = torch.empty((L.egs_image_bytes(W, H),), device=dev, dtype=torch.uint8)
+        state = torch.empty((gb + ib + bb,), device=dev, dtype=torch.uint8)    # the three opaque buffers (their sizes are multiples of 256 bytes)
+        geom, img, binning = state[:gb], state[gb:gb + ib], state[gb + ib:]
         R = C.c_int64(0)
         # The instance count R is data dependent.  Instead of stopping the GPU while the host reads it, the whole chain
         # is enqueued against a capacity guess (1.25 x the largest R seen on this device); only a too-small guess costs
         # a second binning + blend launch.
-        key = dev.index if dev.index is not None else torch.cuda.current_device()
-        cap = _capacity_hint.get(key, 0)
         nb = (P + 255) // 256
         pinned = _pinned_counts.get(key)
         if pinned is None or pinned.numel() < nb:
             pinned = _pinned_counts[key] = torch.empty((max(nb, 4096),), dtype=torch.int32, pin_memory=True)
-        binning = torch.empty((L.egs_binning_bytes(P, cap, W, H),), device=dev, dtype=torch.uint8)
         capturing = torch.cuda.is_current_stream_capturing()
-        place = None if os.environ.get("EGS_NO_PLACEMENT") else placement_buffer(dev, W, H)      # (switch for A/B measurements)
+        place = None if _NO_PLACEMENT else placement_buffer(dev, W, H)
         rot_st, _rot_keep = _object_rotation_struct(object_rotation, dev, P)
         rot_arg = C.byref(rot_st) if rot_st is not None else None
         if capturing:
@@ -191,7 +230,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), _ptr(background), W, H,
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
                 _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), None, _ptr(None if guard is None else guard.running_max),
-                _ptr(active_count), _ptr(None if guard is None else guard.overflow), _ptr(place), rot_arg, _stream()))
+                _ptr(active_count), _ptr(None if guard is None else guard.overflow), _ptr(place), rot_arg, _stream(dev)))
             R = C.c_int64(cap)                      # layout size; the true count is stats["total_view"] after a sync
             rc = 0
         else:
@@ -199,13 +238,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
                                _ptr(campos), _ptr(background), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                                _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img), _ptr(out_color), _ptr(out_depth),
-                               _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _ptr(active_count), _ptr(place), rot_arg, _stream(),
+                               _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _ptr(active_count), _ptr(place), rot_arg, _stream(dev),
                                int(bool(debug)))
         if rc == _lib.RETRY_LARGER:
             cap = int(R.value * 1.25) + 65536
-            binning = torch.empty((L.egs_binning_bytes(P, cap, W, H),), device=dev, dtype=torch.uint8)
+            total_off = _buffer_sizes(L, P, W, H, cap)[3]
+            binning = torch.empty((_buffer_sizes(L, P, W, H, cap)[2],), device=dev, dtype=torch.uint8)
             rc = L.egs_forward_render(P, cap, _ptr(background), W, H, _ptr(geom), _ptr(binning), _ptr(img), _ptr(out_color),
-                                      _ptr(out_depth), _ptr(out_alpha), _stream(), int(bool(debug)))
+                                      _ptr(out_depth), _ptr(out_alpha), _stream(dev), int(bool(debug)))
             stats["retries"] += 1
         _lib.check(rc)
         if P and not capturing:
@@ -215,9 +255,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     stats["P"] = P
     stats["image_buffer"] = img
     if cap > 0:                                     # device-side instance count of this forward (int64[1] view, for graph replays)
-        lay = _lib.BinningLayout()
-        L.egs_get_binning_layout(P, cap, W, H, C.byref(lay))
-        stats["total_view"] = binning[lay.total:lay.total + 8].view(torch.int64)
+        stats["total_view"] = binning[total_off:total_off + 8].view(torch.int64)
     return int(R.value), out_color, out_depth, out_alpha, radii, geom, binning, img
 
 
@@ -259,24 +297,31 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     g_alpha = _opt(_f32c(dL_dout_alpha, "dL_dout_alpha"))
     sh_rest = _opt(_f32c(sh_rest, "sh_rest"))
     M = 0 if sh is None else sh.shape[1] + (0 if sh_rest is None else sh_rest.shape[1])
-    with torch.cuda.device(dev):
+    with _hip.device_ctx(dev):
         e = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
         own_cov = cov3D_precomp is None
         owned = set() if sink is None or P == 0 else sink.check(means3D=means3D, scales=scales, rotations=rotations, sh=sh, sh_rest=sh_rest,
                                                                 own_cov=own_cov, colors=colors)
         keep = sink is not None and getattr(sink, "keep_grads", False)      # tests: the owned leaves' gradients are written as well
         fused = lambda leaf: leaf in owned and not keep
-        dmeans2D = e(P, 3)
-        dcolors = None if (owned and not keep and sh is not None and sh_rest is None and M == 1) else e(P, 3)      # scratch nobody reads in that case
-        dopacity = None if fused(_lib.SINK_OPACITY) else e(P, 1)
-        dmeans3D = None if fused(_lib.SINK_MEANS3D) else e(P, 3)
+        no_colors = bool(owned and not keep and sh is not None and sh_rest is None and M == 1)      # dcolors would be scratch nobody reads
+        need_m3d_arg = fused(_lib.SINK_MEANS3D) and sh_rest is not None
+        # every gradient array of this backward out of ONE allocation (contiguous views on 256-byte boundaries)
+        (dmeans2D, dcolors, dopacity, dmeans3D, dmeans3D_tmp, dcov3D, dsh, dsh_rest, dscales, drots) = _carve(dev, [
+            (P, 3), None if no_colors else (P, 3), None if fused(_lib.SINK_OPACITY) else (P, 1), None if fused(_lib.SINK_MEANS3D) else (P, 3),
+            (P, 3) if need_m3d_arg else None, None if own_cov else (P, 6),
+            None if (fused(_lib.SINK_SH) or sh is None) else tuple(sh.shape),
+            None if (fused(_lib.SINK_SH_REST) or sh_rest is None) else tuple(sh_rest.shape),
+            None if (fused(_lib.SINK_SCALES) or not own_cov) else (P, 3), None if (fused(_lib.SINK_ROTATIONS) or not own_cov) else (P, 4)])
         # (split harmonics: the positions' gradient is finished by the spherical-harmonics launch and travels there through this array)
-        dmeans3D_arg = e(P, 3) if (dmeans3D is None and sh_rest is not None) else dmeans3D
-        dcov3D = e(0, 6) if own_cov else e(P, 6)             # not produced when the library built the covariance itself
-        dsh = None if fused(_lib.SINK_SH) else (e(*sh.shape) if sh is not None else e(0, 0, 3))
-        dsh_rest = None if fused(_lib.SINK_SH_REST) else (e(*sh_rest.shape) if sh_rest is not None else None)
-        dscales = None if fused(_lib.SINK_SCALES) else (e(P, 3) if own_cov else e(0, 3))   # absent inputs get empty gradients (the autograd Function maps them to None)
-        drots = None if fused(_lib.SINK_ROTATIONS) else (e(P, 4) if own_cov else e(0, 4))
+        dmeans3D_arg = dmeans3D_tmp if need_m3d_arg else dmeans3D
+        if own_cov:
+            dcov3D = e(0, 6)                                 # not produced when the library built the covariance itself
+        if sh is None:
+            dsh = e(0, 0, 3)
+        if not own_cov:                                      # absent inputs get empty gradients (the autograd Function maps them to None)
+            dscales = None if fused(_lib.SINK_SCALES) else e(0, 3)
+            drots = None if fused(_lib.SINK_ROTATIONS) else e(0, 4)
         rot_st, _rot_keep = _object_rotation_struct(object_rotation, dev, P)
         if P != 0 and (owned or prologue_scratch is not None or rot_st is not None):
             scratch = prologue_scratch if prologue_scratch is not None else torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
@@ -288,7 +333,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(dopacity), _ptr(dmeans3D_arg), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
                 _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
                 C.byref(sink.struct) if owned else None, 1 if prologue_scratch is not None else 0,
-                C.byref(rot_st) if rot_st is not None else None, _ptr(scratch), _stream(), int(bool(debug))))
+                C.byref(rot_st) if rot_st is not None else None, _ptr(scratch), _stream(dev), int(bool(debug))))
             if owned:
                 sink.mark_stepped()
         elif P != 0:
@@ -300,7 +345,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(imageBuffer), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(dmeans2D), _ptr(dcolors),
                 _ptr(dopacity), _ptr(dmeans3D), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
                 _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
-                _ptr(scratch), _stream(), int(bool(debug))))
+                _ptr(scratch), _stream(dev), int(bool(debug))))
     if sh_rest is not None:
         return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots, dsh_rest
     return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots
@@ -323,9 +368,9 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     P = means3D.shape[0]
     present = torch.zeros((P,), device=means3D.device, dtype=torch.uint8)
     if P:
-        with torch.cuda.device(means3D.device):
+        with _hip.device_ctx(means3D.device):
             _lib.check(L.egs_mark_visible(P, _ptr(means3D), _ptr(_f32c(viewmatrix, "viewmatrix")),
-                                          _ptr(_f32c(projmatrix, "projmatrix")), _ptr(present), _stream()))
+                                          _ptr(_f32c(projmatrix, "projmatrix")), _ptr(present), _stream(means3D.device)))
     return present.bool()
 
 

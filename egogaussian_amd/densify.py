@@ -28,6 +28,7 @@ import torch
 from torch import nn
 
 from . import lib as _lib
+from . import _hip as _launch
 
 GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "label")
 _ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
@@ -39,7 +40,7 @@ def _p(t):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _launch.stream_of(torch.device("cuda", torch.cuda.current_device()))
 
 
 def _hip(t, name):

@@ -15,14 +15,14 @@ import ctypes as C
 import torch
 
 from . import lib as _lib
+from . import _hip
 
 
 def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = _hip.stream_of           # (device) -> c_void_p of its current stream
 
 
 def _need_hip(t, name):
@@ -42,9 +42,9 @@ class _Cov3D(torch.autograd.Function):
         cov = torch.empty((N, 6), device=scaling.device, dtype=torch.float32)
         o_raw = None if opacity_raw is None else _need_hip(opacity_raw, "opacity_raw")
         opacity = None if o_raw is None else torch.empty_like(o_raw)
-        with torch.cuda.device(scaling.device):
+        with _hip.device_ctx(scaling.device):
             _lib.check(L.egs_cov3d_forward(N, _p(scaling), int(bool(log_scaling)), float(modifier), _p(rotation), _p(Mc), _p(sel), _p(cov),
-                                           _p(o_raw), _p(opacity), _stream()))
+                                           _p(o_raw), _p(opacity), _stream(scaling.device)))
         empty = torch.empty(0, device=scaling.device)
         ctx.save_for_backward(scaling, rotation, Mc if Mc is not None else empty, sel if sel is not None else empty,
                               opacity if opacity is not None else empty)
@@ -70,9 +70,9 @@ class _Cov3D(torch.autograd.Function):
             o = opacity
             do = torch.zeros_like(o) if dopacity is None else dopacity.float().contiguous()
             do_raw = torch.empty_like(o)
-        with torch.cuda.device(scaling.device):
+        with _hip.device_ctx(scaling.device):
             _lib.check(L.egs_cov3d_backward(N, _p(scaling), ctx.log_scaling, ctx.modifier, _p(rotation), _p(Mc), _p(sel), ctx.row0_mult,
-                                            _p(ctx.mult_dev), _p(dcov), _p(ds), _p(dr), _p(dM), _p(dM_scratch), _p(o), _p(do), _p(do_raw), _stream()))
+                                            _p(ctx.mult_dev), _p(dcov), _p(ds), _p(dr), _p(dM), _p(dM_scratch), _p(o), _p(do), _p(do_raw), _stream(scaling.device)))
         return ds, dr, (None if dM is None else dM.view(3, 3)), None, None, None, None, do_raw
 
 
@@ -149,9 +149,9 @@ class _L1SSIM(torch.autograd.Function):
         partial = torch.empty(L.egs_l1_ssim_partial_count(Cc, H, W), device=dev)
         maps = torch.empty((3, Cc, H, W), device=dev)
         loss = torch.empty((), device=dev)
-        with torch.cuda.device(dev):
+        with _hip.device_ctx(dev):
             _lib.check(L.egs_l1_ssim_forward(Cc, H, W, _p(img), _p(gt), float(lambda_dssim), _p(partial), _p(maps[0]), _p(maps[1]),
-                                             _p(maps[2]), None if defer_value else _p(loss), None if defer_value else _p(running_sum), _stream()))
+                                             _p(maps[2]), None if defer_value else _p(loss), None if defer_value else _p(running_sum), _stream(dev)))
         ctx.save_for_backward(img, gt, maps, gate if gate is not None else torch.empty(0))
         ctx.lam, ctx.has_gate = float(lambda_dssim), gate is not None
         ctx.deferred = (partial, loss, running_sum) if defer_value else None
@@ -172,11 +172,11 @@ class _L1SSIM(torch.autograd.Function):
         if ctx.raster_node is not None:
             from .rasterizer import backward_prologue_of
             side = backward_prologue_of(ctx.raster_node)
-        with torch.cuda.device(img.device):
+        with _hip.device_ctx(img.device):
             d = ctx.deferred
             _lib.check(L.egs_l1_ssim_backward_ex(Cc, H, W, _p(img), _p(gt), ctx.lam, _p(g), _p(gate), _p(maps[0]), _p(maps[1]),
                                                  _p(maps[2]), _p(dimg), _p(d[0]) if d else None, _p(d[1]) if d else None,
-                                                 _p(d[2]) if d else None, C.byref(side) if side is not None else None, _stream()))
+                                                 _p(d[2]) if d else None, C.byref(side) if side is not None else None, _stream(img.device)))
         return dimg, None, None, None, None, None, None
 
 

@@ -11,6 +11,7 @@ import torch
 from torch.utils.weak import WeakIdKeyDictionary
 
 from . import lib as _lib
+from . import _hip
 
 
 class AdamSink:
@@ -56,15 +57,26 @@ class FusedAdam(torch.optim.Optimizer):
         self.guard = None                 # _C.StepGuard of a captured step: its overflow word makes step() a no-op for a clipped frame
         self.active_rows = None           # (int32[1] device tensor, capacity rows): only the live rows of a capacity-sized model are stepped
         self._coef = {}                   # device -> float32[12] scratch of the fused path (make_sink)
+        self._arrays = {}                 # (device, betas, eps) -> cached ctypes pointer arrays of the eager step()
+        self._sinks = {}                  # render call shape (tensor addresses) -> (AdamSink, [(parameter, its exp_avg)]) built for it
         # parameters a rasterizer backward stepped since the last step() -> whether that backward also wrote their gradient
         # (keep_grads); weak keys: an entry dies with a parameter that densification replaced, its id cannot be reused by another
         self._sunk = WeakIdKeyDictionary()
+
+    def zero_grad(self, set_to_none=True):
+        """torch's zero_grad walks foreach / profiler machinery (~27 us for six parameters); dropping the gradients is a loop."""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group["params"]:
+                p.grad = None
 
     def load_state_dict(self, state_dict):
         """The device-side step counters and learning rates are derived state: dropped here and re-seeded from the loaded
         state["step"] / param_groups at the next step()."""
         super().load_state_dict(state_dict)
         self._aux = WeakIdKeyDictionary()
+        self._sinks = {}; self._arrays = {}
 
     def _aux_of(self, p):
         a = self._aux.get(p)
@@ -99,6 +111,17 @@ class FusedAdam(torch.optim.Optimizer):
         All leaves of one sink share betas / eps (one param-group configuration), as the reference's optimizer does."""
         if not self.capturable:
             return None
+        # The sink of one render call shape is the same object every iteration while the tensors stay (their addresses, requires_grad
+        # and the optimizer's state tensors): built once, found again by the addresses -- densification replaces the tensors and so
+        # the key.  (Building it walks the parameter groups and fills a ctypes structure: ~25 us per eager step.)
+        ck = tuple((0, False) if t is None else (t.data_ptr(), bool(t.requires_grad)) for t in (means3D, opacities, scales, rotations, sh, sh_rest)) + \
+            (bool(cov3D_given), bool(colors_given), bool(colors_need_grad), None if means3D is None else means3D.shape[0],
+             None if self.active_rows is None else self.active_rows[0].data_ptr())
+        hit = self._sinks.get(ck)
+        if hit is not None and all(self.state.get(p, {}).get("exp_avg") is m for p, m in hit[1]):
+            if not torch.cuda.is_current_stream_capturing():
+                self.sync_lr()
+            return hit[0]
         by_ptr = {}
         for group in self.param_groups:
             for p in group["params"]:
@@ -155,6 +178,9 @@ class FusedAdam(torch.optim.Optimizer):
             self.sync_lr()
         sink = AdamSink(struct, owned, ptrs, keep + [coef], self, params)
         sink.split16 = bool(sh_split16)
+        if len(self._sinks) >= 8:
+            self._sinks.clear()
+        self._sinks[ck] = (sink, [(p, self.state[p]["exp_avg"]) for p in params])
         return sink
 
     def sync_lr(self):
@@ -217,10 +243,10 @@ class FusedAdam(torch.optim.Optimizer):
             # render, which is never clipped, and must not be voided by what the last replay left in that word
             skip = None if (self.guard is None or not torch.cuda.is_current_stream_capturing()) else C.c_void_p(self.guard.overflow.data_ptr())
             rows = None if self.active_rows is None else C.c_void_p(self.active_rows[0].data_ptr())
-            with torch.cuda.device(dev):                             # the kernel itself advances the counters and writes st["step"]
+            with _hip.device_ctx(dev):                               # the kernel itself advances the counters and writes st["step"]
                 _lib.check(L.egs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), NN, arr(4), arr(5), arr(6), float(betas[0]),
                                                       float(betas[1]), float(eps), skip, rows, RF if rows is not None else None,
-                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                                      _hip.stream_of(dev)))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -257,14 +283,19 @@ class FusedAdam(torch.optim.Optimizer):
                 by_cfg.setdefault(key, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), int(st["step"])))
         for (dev, betas, eps), items in by_cfg.items():
             n = len(items)
-            PP = (C.c_void_p * n)(*[t[0].data_ptr() for t in items])
+            # the parameter / moment pointer arrays change only when the tensors do (densification): kept between steps
+            sig = tuple((t[0].data_ptr(), t[2].data_ptr(), t[3].data_ptr()) for t in items)
+            cached = self._arrays.get((dev, betas, eps))
+            if cached is None or cached[0] != sig:
+                cached = self._arrays[(dev, betas, eps)] = (sig, (C.c_void_p * n)(*[t[0].data_ptr() for t in items]),
+                                                            (C.c_void_p * n)(*[t[2].data_ptr() for t in items]),
+                                                            (C.c_void_p * n)(*[t[3].data_ptr() for t in items]),
+                                                            (C.c_int64 * n)(*[t[0].numel() for t in items]))
+            _, PP, MM, VV, NN = cached
             GG = (C.c_void_p * n)(*[t[1].data_ptr() for t in items])
-            MM = (C.c_void_p * n)(*[t[2].data_ptr() for t in items])
-            VV = (C.c_void_p * n)(*[t[3].data_ptr() for t in items])
-            NN = (C.c_int64 * n)(*[t[0].numel() for t in items])
             LR = (C.c_float * n)(*[t[4] for t in items])
             ST = (C.c_int64 * n)(*[t[5] for t in items])
-            with torch.cuda.device(dev):
+            with _hip.device_ctx(dev):
                 _lib.check(L.egs_adam_step(n, PP, GG, MM, VV, NN, LR, ST, float(betas[0]), float(betas[1]), float(eps),
-                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                           _hip.stream_of(dev)))
         return loss

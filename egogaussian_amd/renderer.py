@@ -49,6 +49,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     `visibility_filter` is radii > 0 as written by the preprocess kernel: a fresh tensor in eager calls; while a hipGraph is being
     captured it is a VIEW of the rasterizer's saved state that follows every replay (no launch) -- clone it to keep or edit it."""
     xyz = pc.get_xyz
+    if optimizer is None:
+        optimizer = getattr(pc, "_egs_fused_optimizer", None)      # adapter.attach(..., fuse_optimizer=True)
     screenspace_points = _screenspace_leaf(xyz)
     rasterizer = GaussianRasterizer(raster_settings=get_raster_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
 
