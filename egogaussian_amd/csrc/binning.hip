@@ -413,6 +413,7 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, int gpr,
 #define TS_DBITS 9
 #define TS_DIGITS (1 << TS_DBITS)
 #define TS_BUCKET_MAX 96u           // largest top-digit bucket the in-bucket comparison takes (see k_tile_sort)
+#define TS_SLAB_BUCKET_MAX 512u     // the same for a tile sorted in depth slabs (what it falls back to is far slower than a long comparison loop)
 
 __device__ __forceinline__ uint64_t digit_peers(uint32_t d, bool ok) {
     uint64_t peers = __ballot(ok);
@@ -714,13 +715,75 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
         return;
     }
 
-    // ---- oversize bucket: same digits, keys stay in global memory (ping-pong with `scratch`), full (index, depth) order ----
-    uint32_t (*wide)[TS_DIGITS] = reinterpret_cast<uint32_t (*)[TS_DIGITS]>(xbuf);     // xbuf is idle on this path
+    // ---- a tile with more instances than the registers hold: DEPTH SLABS through the same LDS buffer ----
+    // The one-pass idea again, with the keys streamed from global memory: histogram all n keys into the TS_NB linear depth buckets,
+    // scan, then take runs of consecutive buckets holding at most TS_CAP keys ("slabs") one after another -- gather the slab's keys
+    // into LDS in bucket order, rank every key inside its bucket by comparison, write its index.  Slabs are disjoint depth ranges in
+    // increasing order, so the list comes out sorted; the keys are read once per slab (n^2 / TS_CAP reads in all, L2-resident).
+    // Trained scenes put 5-10 k splats into their densest tiles; the digit-by-digit global-memory passes below (six passes with
+    // agent-scope fences) took 2.2 ms per frame for S(500k) with every splat three times larger (profiles/r3_footprint_sweep.md).
     uint64_t* src = pairs + beg;
-    uint64_t* dst = scratch + beg;
     uint32_t dmin = 0xffffffffu, dmax = 0u;
     for (uint32_t i = threadIdx.x; i < n; i += TS_THREADS) { const uint32_t dw = (uint32_t)(src[i] >> 32); dmin = min(dmin, dw); dmax = max(dmax, dw); }
+    for (int k = threadIdx.x; k < TS_NB; k += TS_THREADS) bkt[k] = 0;
     block_min_max<TS_WAVES>(dmin, dmax, lds8);
+    if (dmax > dmin) {
+        const float zmin = __uint_as_float(dmin), zscale = (float)TS_NB / (__uint_as_float(dmax) - zmin);
+        auto bucket = [&](uint64_t kv) -> uint32_t {
+            const float f = (__uint_as_float((uint32_t)(kv >> 32)) - zmin) * zscale;
+            return (uint32_t)fminf(fmaxf(f, 0.f), (float)(TS_NB - 1));
+        };
+        for (uint32_t i = threadIdx.x; i < n; i += TS_THREADS) atomicAdd(&bkt[bucket(src[i])], 1u);
+        __syncthreads();
+        bool too_big = false;                                          // a bucket the in-bucket comparison (or a slab) cannot take
+        {
+            constexpr int PER = TS_NB / 256;
+            uint32_t c[PER], sum = 0;
+            if (threadIdx.x < 256) {
+#pragma unroll
+                for (int k = 0; k < PER; k++) { c[k] = bkt[threadIdx.x * PER + k]; sum += c[k]; too_big = too_big || c[k] > TS_SLAB_BUCKET_MAX; }
+            }
+            uint32_t base = scan_first_256(sum, lds8);
+            if (threadIdx.x < 256) {
+#pragma unroll
+                for (int k = 0; k < PER; k++) { bkt[threadIdx.x * PER + k] = base; bkt[TS_NB + threadIdx.x * PER + k] = base; base += c[k]; }
+            }
+        }
+        if (!__syncthreads_or(too_big ? 1 : 0)) {
+            auto bstart = [&](uint32_t d) -> uint32_t { return d < (uint32_t)TS_NB ? bkt[TS_NB + d] : n; };
+            for (uint32_t d0 = 0; d0 < (uint32_t)TS_NB;) {             // (every quantity below is workgroup-uniform)
+                const uint32_t s0 = bstart(d0);
+                uint32_t lo = d0 + 1, hi = TS_NB;                      // largest d1 in [d0 + 1, TS_NB] with bstart(d1) - s0 <= TS_CAP (d0 + 1 qualifies)
+                while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (bstart(mid) - s0 <= (uint32_t)TS_CAP) lo = mid; else hi = mid - 1; }
+                const uint32_t d1 = lo, m = bstart(d1) - s0;
+                if (m) {
+                    for (uint32_t i = threadIdx.x; i < n; i += TS_THREADS) {
+                        const uint64_t k = src[i];
+                        const uint32_t d = bucket(k);
+                        if (d >= d0 && d < d1) xbuf[atomicAdd(&bkt[d], 1u) - s0] = k;
+                    }
+                    __syncthreads();
+                    for (uint32_t j = threadIdx.x; j < m; j += TS_THREADS) {
+                        const uint64_t k = xbuf[j];
+                        const uint32_t d = bucket(k);
+                        const uint32_t bs = bstart(d) - s0, be = bstart(d + 1) - s0;
+                        uint32_t smaller = 0;
+                        for (uint32_t q = bs; q < be; q++) smaller += xbuf[q] < k ? 1u : 0u;
+                        point_list[beg + s0 + bs + smaller] = (uint32_t)k;
+                    }
+                    __syncthreads();                                    // xbuf is free for the next slab
+                }
+                d0 = d1;
+            }
+            return;
+        }
+    }
+    __syncthreads();
+
+    // ---- last resort (depths piled up in one bucket, or all equal): same digits as the register path's passes, keys stay in global
+    // memory (ping-pong with `scratch`), full (index, depth) order ----
+    uint32_t (*wide)[TS_DIGITS] = reinterpret_cast<uint32_t (*)[TS_DIGITS]>(xbuf);     // xbuf is idle on this path
+    uint64_t* dst = scratch + beg;
     const int depth_passes = (32 - __clz((int)(dmax - dmin)) + TS_DBITS - 1) / TS_DBITS;
     const int npass = index_passes + depth_passes;
     for (int p = 0; p < npass; p++) {

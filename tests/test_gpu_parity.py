@@ -326,6 +326,40 @@ def test_clustered_depths_take_the_sorts_fallback_and_still_match(layout):
     assert outlier_fraction(out[1].cpu().numpy(), st["color"], TOL) <= 1e-4
 
 
+@pytest.mark.parametrize("layout", ["uniform", "one-dense-tile", "dense-and-tied"])
+def test_tiles_beyond_the_register_capacity_are_sorted_in_depth_slabs(layout):
+    """Tile lists longer than the in-register capacity (2048 / 4096 keys) go through the depth-slab path: histogram into linear depth
+    buckets, runs of buckets with at most the capacity gathered into LDS and ranked one after another.  `uniform`: every tile of a
+    small image holds ~8 k instances (the second instantiation's slabs); `one-dense-tile`: a cluster of 12 k splats inside one tile of
+    an otherwise light image -- few instances per tile on average, so only the first instantiation is launched and ITS slab path takes
+    the tile; `dense-and-tied`: the same with a quarter of the cluster at one depth (ties settled by the index inside a slab, a pile
+    too big for a bucket falls through to the digit-by-digit passes).  Lists and image against the oracle."""
+    from egogaussian_amd import _C
+    dev = _dev()
+    if layout == "uniform":
+        N, H, W = 24000, 64, 64
+        d = make_inputs(N, H, W, 21, 0, "sh_cov", scale_mul=8.0)
+    else:
+        N, H, W = 16000, 128, 160
+        d = make_inputs(N, H, W, 22, 0, "sh_cov", scale_mul=0.5)
+        g = torch.Generator().manual_seed(9)
+        m3 = d["means3D"]
+        k = 12000
+        m3[:k, 0] = 0.02 * torch.randn(k, generator=g); m3[:k, 1] = 0.02 * torch.randn(k, generator=g)     # a cluster on the optical axis: one tile
+        m3[:k, 2] = 3.0 + 4.0 * torch.rand(k, generator=g)
+        if layout == "dense-and-tied":
+            m3[:3000, 2] = 4.5
+    o, st = oracle_forward(d)
+    lens = (st["ranges"][:, 1] - st["ranges"][:, 0])
+    assert lens.max() > 4096 and (layout == "uniform") == (lens.mean() > 2048), (int(lens.max()), float(lens.mean()))
+    g_, out = hip_forward(d, dev)
+    bv = _C.binning_views(out[6], N, out[0], W, H, _C.stats["capacity"]); iv = _C.image_views(out[7], W, H)
+    assert out[0] == st["R"]
+    assert np.array_equal(iv["ranges"].cpu().numpy().view(np.uint32), st["ranges"])
+    assert np.array_equal(bv["point_list"].cpu().numpy().view(np.uint32), st["point_list"]), f"longest list {int(lens.max())}"
+    assert outlier_fraction(out[1].cpu().numpy(), st["color"], TOL) <= 1e-4
+
+
 def test_ballot_rank_fallback_sorts_identically():
     """The per-tile sort has two rankers (LDS-atomic, verified on the device at first use; ballot-based fallback)."""
     from egogaussian_amd import _C, lib
