@@ -360,6 +360,19 @@ def test_tiles_beyond_the_register_capacity_are_sorted_in_depth_slabs(layout):
     assert outlier_fraction(out[1].cpu().numpy(), st["color"], TOL) <= 1e-4
 
 
+def test_ready_to_pin_harness_runs_against_the_hip_path(tmp_path):
+    """tools/compare_upstream_npz.py end to end: reference outputs written by one backend (here the oracle, standing in for a holder
+    of the CUDA build), compared with the HIP path through the drop-in module: radii, images, gradients (the lists are compared by the tests above)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "compare_upstream_npz.py")
+    r = subprocess.run([sys.executable, tool, "produce", "--backend", "oracle", "--cases", "A,E,F", "--out", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    r = subprocess.run([sys.executable, tool, "compare", "--ref", str(tmp_path), "--backend", "hip", "--cases", "A,E,F"], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0 and r.stdout.count("PASS") == 3, r.stdout + r.stderr[-1500:]
+
+
 def test_ballot_rank_fallback_sorts_identically():
     """The per-tile sort has two rankers (LDS-atomic, verified on the device at first use; ballot-based fallback)."""
     from egogaussian_amd import _C, lib

@@ -72,3 +72,24 @@ def test_bench_fine_all_inputs():
     # the per-unit byte figures of DESIGN.md section 4
     assert bench.algorithmic_bytes("preprocess", 10, 0, 0) == 10 * 104 and bench.algorithmic_bytes("render_backward", 0, 10, 100) == 10 * 92 + 32 * 100
     assert bench.algorithmic_bytes("tile_sort", 0, 7, 0) == 84 and bench.algorithmic_bytes("preprocess_backward", 10, 0, 0) == 2160
+
+
+def test_ready_to_pin_harness_inputs_are_reproducible():
+    """tools/compare_upstream_npz.py: the committed input half (tests/golden/upstream) is what the seeds regenerate -- a holder of the
+    reference's CUDA build who regenerates the inputs gets the same bytes, checked by hash before any comparison."""
+    import importlib.util
+    import os
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cmp_up", os.path.join(root, "tools", "compare_upstream_npz.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    want = dict(l.split() for l in open(os.path.join(root, "tests", "golden", "upstream", "input_sha256.txt")).read().splitlines())
+    assert set(want) == set(m.CASES)
+    for cid in ("A", "E", "F"):
+        d, grads = m.make_case(cid)
+        assert m.input_hash(d) == want[cid], cid
+        f = np.load(os.path.join(root, "tests", "golden", "upstream", f"case_{cid}_inputs.npz"))
+        for k in m.INPUT_KEYS:
+            if k in d:
+                assert np.array_equal(f[k], d[k].numpy()), (cid, k)
+        assert np.array_equal(f["gc"], grads[0].numpy())
