@@ -22,6 +22,7 @@
 #include "egs_common.h"
 #include "blend_common.h"
 #include "backward_prologue.h"
+#include "blend_instrument.h"      // measurement / ablation hooks: all empty in the product build
 #include <algorithm>
 
 namespace {
@@ -94,10 +95,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     float4* my = lds[wv];
     float* myred = red[wv];
-#if defined(EGS_MEASURE) && EGS_MEASURE == 4      // instrumentation build (tools/lane_use.py): per-wave timeline of the backward
-    const uint64_t t_start = wall_clock64();
-    uint32_t meas = 0;
-#endif
+    EGS_BWD_MEASURE(const uint64_t t_start = wall_clock64(); uint32_t meas = 0;)
     const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
     if (qx0 >= W || qy0 >= H) return;
     const int px = qx0 + (int)(lane & 7), py = qy0 + (int)(lane >> 3);
@@ -134,19 +132,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // (same values and roundings as U_next = fma(a_last, u_last - U, U); the select keeps a skipped splat's colour, NaN included,
     // out of the pixel's chain).
     float T = T_final, S = 0.f;
-#if defined(EGS_ABL) && EGS_ABL == 5
-    float abl_sink = 0.f;
-#endif
+    EGS_BWD_ABL5(float abl_sink = 0.f;)
 
     // Longest-remaining-work-first.  A SIMD issues its oldest wave first, and the tiles are dispatched most expensive first, so the
     // light, late waves used to wait for the others and then run down alone -- the last quarter of the launch had fewer than three
     // waves per SIMD (profiles/r2_blend_timelines.md).  The forward counted the splats every quadrant blends; this wave's issue
     // priority (s_setprio, 4 levels) follows the number it still has to replay, so the waves of a SIMD reach the end together.
     // Placement-like: it decides who issues first, never a result.  -DEGS_NO_LRPT builds without it.
-#ifndef EGS_NO_LRPT
-    int remaining = (int)quad_visits[tile * 4 + q];
-    int prio_now = -1;
-#endif
+    EGS_LRPT(int remaining = (int)quad_visits[tile * 4 + q]; int prio_now = -1;)
     const int nb = (int)((wmax + 63) / 64);
     int b = nb - 1;
     uint32_t id_next = (uint32_t)b * 64 + lane < wmax ? list[(uint32_t)b * 64 + lane] : 0u;
@@ -172,16 +165,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << j);
-#ifndef EGS_NO_LRPT
-            {
+            EGS_LRPT({
                 const int want = remaining >= 64 ? 3 : remaining >= 24 ? 2 : remaining >= 8 ? 1 : 0;       // (thresholds swept at config C)
                 if (want != prio_now) {
                     prio_now = want;
                     if (want == 3) __builtin_amdgcn_s_setprio(3); else if (want == 2) __builtin_amdgcn_s_setprio(2); else if (want == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                 }
                 remaining--;
-            }
-#endif
+            })
             const float4 s0 = my[j * 3 + 0], s1 = my[j * 3 + 1];
             const float2 s2 = *reinterpret_cast<const float2*>(&my[j * 3 + 2]);
             const float dx = s0.x - pxf, dy = s0.y - pyf;
@@ -197,9 +188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             a = ((uint32_t)j < lastb) ? a : 0.f;                        // 0 = this pixel does not use the splat
             const bool contrib = a > 0.f;
             if (__ballot(contrib) == 0ull) continue;
-#if defined(EGS_MEASURE) && EGS_MEASURE == 4
-            meas++;
-#endif
+            EGS_BWD_MEASURE(meas++;)
             const float rcp = __builtin_amdgcn_rcpf(1.f - a);
             const float Tn = T * rcp;                                   // transmittance in front of this splat
             const float w = a * Tn;
@@ -220,10 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const float v6 = w * g_r, v7 = w * g_g, v8 = w * g_b, v9 = HAS_DA ? w * g_d : 0.f;
             (void)t; (void)m; (void)nn;
 
-#if defined(EGS_ABL) && EGS_ABL == 5          /* ablation build (timing only): no cross-lane reduction, no atomic -- what the pair arithmetic alone costs */
-            abl_sink += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)) + (v8 + v9);
-            continue;
-#endif
+            EGS_BWD_ABL5(abl_sink += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)) + (v8 + v9); continue;)
             // 64-lane sums of v0..v9 (see the header): swap-fold, LDS regroup, quad DPP
             myred[0 * 64 + lane] = fold32(v0, v1); myred[1 * 64 + lane] = fold32(v2, v3); myred[2 * 64 + lane] = fold32(v4, v5);
             myred[3 * 64 + lane] = fold32(v6, v7); myred[4 * 64 + lane] = fold32(v8, v9);
@@ -236,23 +222,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         __builtin_amdgcn_wave_barrier();
     }
-#if defined(EGS_ABL) && EGS_ABL == 5
-    if (abl_sink == 12345.678f) grad_acc[lane] = abl_sink;
-#endif
-#if defined(EGS_MEASURE) && EGS_MEASURE == 4
-    if (inside) {                                                    // n_contrib was consumed above: reuse it as the log
-        uint32_t hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        uint32_t* log = const_cast<uint32_t*>(n_contrib) + (size_t)py * W + px;
-        if (lane == 0) *log = (uint32_t)t_start;
-        if (lane == 1) *log = (uint32_t)wall_clock64();
-        if (lane == 2) *log = ((xcc & 0xfu) << 16) | (hw & 0xffffu);
-        if (lane == 3) *log = range.y - range.x;
-        if (lane == 4) *log = meas;
-        if (lane == 5) *log = wmax;
-    }
-#endif
+    EGS_BWD_ABL5(if (abl_sink == 12345.678f) grad_acc[lane] = abl_sink;)
+    EGS_BWD_TIMELINE()
 }
 
 }  // namespace

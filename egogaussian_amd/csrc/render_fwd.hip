@@ -28,6 +28,7 @@
 #include "egs_common.h"
 #include "blend_common.h"
 #include "backward_prologue.h"
+#include "blend_instrument.h"      // measurement / ablation hooks: all empty in the product build
 
 namespace {
 
@@ -99,10 +100,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
     uint32_t last = 0;
     uint32_t visits = 0;                                            // wave-uniform: splats blended by this quadrant
     uint32_t pairs = 0;                                             // wave-uniform: (pixel, splat) pairs that contributed (scalar unit only)
-#ifdef EGS_MEASURE           // instrumentation builds only (tools/lane_use.py): 1 = (wave, splat) visits, 2 = kept lanes, 3 = timeline
-    uint32_t meas = 0;
-    const uint64_t t_start = wall_clock64();
-#endif
+    EGS_IF_MEASURE(uint32_t meas = 0; const uint64_t t_start = wall_clock64();)
 
     // software pipeline: ids two batches ahead, records one batch ahead
     uint32_t id_next = lane < n ? list[lane] : 0u;
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
     uint32_t scanned = 0;                                           // wave-uniform: batches of 64 list entries looked at
     for (uint32_t base = 0; alive && base < n; base += 64) {
         scanned++;
-#ifndef EGS_NO_LRPT
+        EGS_LRPT(
         // Longest-remaining-work-first, as in the backward (render_bwd.hip) -- but here the work left is not known, so it is estimated
         // once per batch from the quadrant's own history: its least saturated pixel has come ln(Tmax) of the way to ln(1e-4) with the
         // splats blended so far, so about visits * (ln(1e-4) - ln Tmax) / ln Tmax are left, and never more than the rest of the list
@@ -122,8 +120,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
         // never a result.
         if (base) {
             float tmax = Tl;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, d, 64));
+            _Pragma("unroll") for (int d = 32; d >= 1; d >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, d, 64));
             const float lnT = __logf(fmaxf(tmax, 1e-30f));
             const float by_decay = lnT < -1e-4f ? (9.2103404f + lnT) / -lnT : 1e9f;
             const float by_list = (float)(n - base) / (float)base;
@@ -132,8 +129,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
             if (want == 3) __builtin_amdgcn_s_setprio(3); else if (want == 2) __builtin_amdgcn_s_setprio(2); else if (want == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         } else {
             __builtin_amdgcn_s_setprio(3);
-        }
-#endif
+        })
         const float4 c0 = r0, c1 = r1, c2 = r2;
         const bool have = base + lane < n;
         // issue the next batch's gathers now
@@ -150,35 +146,10 @@ __global__ __launch_bounds__(256) void k_render_forward(
         // and the launch ends with exactly those waves.  The reads and their waits are written out (egs_lds_fetch / egs_lds_wait_*):
         // left to the compiler the fetch is either sunk next to its use or followed by a full lgkmcnt(0).  A fetch is issued on every
         // path (entry 0 again when the list is exhausted), so exactly one -- three reads -- is outstanding at each wait.
-#ifdef EGS_MEASURE
-#define EGS_FWD_MEAS(W) meas += EGS_MEASURE != 2 ? 1u : (uint32_t)__popcll(__ballot((W) > 0.f));
-#else
-#define EGS_FWD_MEAS(W)
-#endif
-#ifndef EGS_ABL
-#define EGS_ABL 0
-#endif
-#if EGS_ABL == 1 || EGS_ABL == 2      /* ablation builds (timing only, tools): drop the measurement counters / the last-contributor tracking */
-#define EGS_ABL_VISITS
-#define EGS_ABL_PAIRS
-#else
-#define EGS_ABL_VISITS visits++;
-#define EGS_ABL_PAIRS pairs += (uint32_t)__popcll(__ballot(used));
-#endif
-#if EGS_ABL == 2
-#define EGS_ABL_LAST(J) last = used ? 1u : last;
-#else
-#define EGS_ABL_LAST(J) last = used ? base + J + 1u : last;
-#endif
-#if EGS_ABL == 3
-#define EGS_ABL_ALPHA egs_alpha_noexp
-#else
-#define EGS_ABL_ALPHA egs_alpha
-#endif
 #define EGS_FWD_BLEND(J, S0, S1, S2) {                                                                                              \
-            EGS_ABL_VISITS                                                                                                          \
+            EGS_FWD_COUNT_VISIT                                                                                                     \
             float G;                                                                                                                \
-            const float a = EGS_ABL_ALPHA(S0.x - pxf, S0.y - pyf, S0.z, S0.w, S1.x, S1.y, G);   /* 0 = skipped */                   \
+            const float a = EGS_FWD_ALPHA(S0.x - pxf, S0.y - pyf, S0.z, S0.w, S1.x, S1.y, G);   /* 0 = skipped */                   \
             const float test = fmaf(-a, Tl, Tl);                  /* T (1 - alpha); == Tl when skipped, 0 when stopped */            \
             const bool cont = test >= 0.0001f;                    /* false: this splat stops the pixel (or already stopped) */       \
             const float w = cont ? a * Tl : 0.f;                                                                                    \
@@ -187,8 +158,8 @@ __global__ __launch_bounds__(256) void k_render_forward(
             Tf = cont ? test : Tf;                                                                                                  \
             Tl = cont ? test : 0.f;                                                                                                 \
             const bool used = w > 0.f;                                                                                              \
-            EGS_ABL_LAST(J)                                                                                                         \
-            EGS_ABL_PAIRS                                                                                                           \
+            EGS_FWD_LAST(used, J)                                                                                                   \
+            EGS_FWD_COUNT_PAIRS(used)                                                                                               \
             alive = __ballot(cont) != 0ull;                       /* whole quadrant saturated -> leave */                           \
             EGS_FWD_MEAS(w) }
         unsigned ja, jb;
@@ -199,26 +170,17 @@ __global__ __launch_bounds__(256) void k_render_forward(
         for (;;) {
             const bool more_b = mask != 0ull;                     // (wave-uniform)
             jb = more_b ? (unsigned)__builtin_ctzll(mask) : 0u; mask &= mask - 1ull;
-#if EGS_ABL == 4
-            b0 = a0; b1 = a1; b2 = a2;
-#else
-            egs_lds_fetch(my_addr + jb * 48u, b0, b1, b2);
-            egs_lds_wait_older(a0, a1, a2);
-#endif
+            EGS_FWD_PREFETCH(egs_lds_fetch(my_addr + jb * 48u, b0, b1, b2); egs_lds_wait_older(a0, a1, a2);, b0 = a0; b1 = a1; b2 = a2;)
             EGS_FWD_BLEND(ja, a0, a1, a2)
             if (!more_b || !alive) break;
             const bool more_a = mask != 0ull;
             ja = more_a ? (unsigned)__builtin_ctzll(mask) : 0u; mask &= mask - 1ull;
-#if EGS_ABL != 4
-            egs_lds_fetch(my_addr + ja * 48u, a0, a1, a2);
-            egs_lds_wait_older(b0, b1, b2);
-#endif
+            EGS_FWD_PREFETCH(egs_lds_fetch(my_addr + ja * 48u, a0, a1, a2); egs_lds_wait_older(b0, b1, b2);, )
             EGS_FWD_BLEND(jb, b0, b1, b2)
             if (!more_a || !alive) break;
         }
         egs_lds_wait_all(a0, a1, a2, b0, b1, b2);                  // nothing may still be landing in registers the code below reuses
 #undef EGS_FWD_BLEND
-#undef EGS_FWD_MEAS
         __builtin_amdgcn_wave_barrier();
     }
     const float T = Tf;
@@ -233,9 +195,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
             quad_pairs[tile * 4 + q] = pairs; quad_pairs[(n_tiles + tile) * 4 + q] = visits;     // measurement only (bench.py: Q, visits)
             if (cost_hint) cost_hint[tile * 4 + q] = 10u * visits + EGS_FWD_COST_BATCH * scanned;  // what THIS kernel spent on the quadrant
         }
-#ifdef EGS_MEASURE
-        if (lane == 0) quad_work[tile * 4 + q] = meas;
-#endif
+        EGS_IF_MEASURE(if (lane == 0) quad_work[tile * 4 + q] = meas;)
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
@@ -243,19 +203,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
         out_color[pix] = fmaf(T, bg[0], C0); out_color[HW + pix] = fmaf(T, bg[1], C1);
         out_color[2 * HW + pix] = fmaf(T, bg[2], C2);
         out_depth[pix] = Dacc; out_alpha[pix] = Aacc;
-#if defined(EGS_MEASURE) && EGS_MEASURE == 3
-        uint32_t hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        if (lane == 0) n_contrib[pix] = (uint32_t)t_start;
-        if (lane == 1) n_contrib[pix] = (uint32_t)wall_clock64();
-        if (lane == 2) n_contrib[pix] = ((xcc & 0xfu) << 16) | (hw & 0xffffu);
-        if (lane == 3) n_contrib[pix] = n;
-        if (lane == 4) n_contrib[pix] = meas;
-        uint32_t wm = last;
-        for (int d = 32; d >= 1; d >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, d, 64));
-        if (lane == 5) n_contrib[pix] = wm;
-#endif
+        EGS_FWD_TIMELINE()
     }
 }
 

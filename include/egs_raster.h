@@ -262,7 +262,13 @@ int egs_backward(
  *     EGS_SINK_MEANS3D of the three.  Any other colour layout: those three leaves cannot be fused.
  *   - skip_flag set: no step is taken and none is counted.  active_rows: rows >= *active_rows are left alone (capacity-sized
  *     models), as in egs_adam_step_capturable.
- *   - coef: device float[12] scratch owned by the caller, written and read by this call only. */
+ *   - coef: device float[12] scratch owned by the caller, written and read by this call only.
+ *   - CALLER-CHECKED PRECONDITION (the library cannot see the caller's computation graph): the gradient this backward produces for a
+ *     fused leaf must be the leaf's WHOLE gradient for this optimizer step -- this rasterizer call is the only consumer of the
+ *     parameter in the loss.  A second path (an entropy term on the opacities, colours computed from the positions outside the
+ *     library, a second render of the same model in the same iteration) would have its share applied with stale moments or lost.
+ *     The Python host side enforces it where it can (optim.FusedAdam.make_sink leaves the positions out when colors_precomp requires
+ *     a gradient; FusedAdam.step raises when a fused leaf arrives with a .grad from another path); a direct C caller owns the check. */
 #define EGS_SINK_MEANS3D   0    /* [P,3] */
 #define EGS_SINK_OPACITY   1    /* [P,1] */
 #define EGS_SINK_SCALES    2    /* [P,3] */

@@ -10,5 +10,9 @@ pytestmark = pytest.mark.gpu
 def test_randomised_parity_sweep(seed):
     from tests.fuzz_parity import run_draws
     n, worst = run_draws(seed=seed, n_draws=80, budget_s=240)
-    print(f"\n  seed {seed}: {n} draws; worst max-relative gradient errors: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+    strict = worst.pop("_strict_draws", 0)
+    print(f"\n  seed {seed}: {n} draws, {strict} with every image and gradient within 1e-4 outright (zero threshold flips); "
+          "worst max-relative gradient errors: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
     assert n >= 40, f"only {n} draws finished inside the time budget"
+    # the loose per-draw bounds above (outlier fraction 1e-3, max 2e-2) exist for draws with a threshold flip; most draws have none
+    assert strict >= 0.8 * n, f"only {strict} of {n} draws met the 1e-4 bar outright"
