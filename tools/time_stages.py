@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-stage HIP-event timing of the rasterizer alone (forward + backward) on a synthetic scene.
    python tools/time_stages.py [N] [H] [W] [iters]     (EGS_RASTER_LIB=path selects an A/B build of the library;
-   SH_DEGREE=d for more colour coefficients, SH_SPLIT=0 to hand them over concatenated as the reference's get_features does)"""
+   SH_DEGREE=d for more colour coefficients, SH_SPLIT=0 to hand them over concatenated as the reference's get_features does,
+   SCALE_MUL=f multiplies every splat's extent)"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +13,11 @@ from egogaussian_amd.renderer import render
 N, H, W, iters = [int(a) for a in (sys.argv[1:5] + ["500000", "540", "960", "30"][len(sys.argv) - 1:])]
 dev = "cuda:0"
 D = int(os.environ.get("SH_DEGREE", "0"))
-pc = SynthGaussians(make_scene(N, H, W, 0, sh_degree=D), device=dev, sh_degree=D)
+scene = make_scene(N, H, W, 0, sh_degree=D)
+if os.environ.get("SCALE_MUL"):
+    import numpy as np
+    scene["log_scale"] = scene["log_scale"] + np.float32(math.log(float(os.environ["SCALE_MUL"])))
+pc = SynthGaussians(scene, device=dev, sh_degree=D)
 if os.environ.get("SH_SPLIT", "1") == "0":
     pc.get_features_split = lambda: None
 vis = render(make_camera(0, H, W, device=dev), pc, Pipe, torch.zeros(3, device=dev))["visibility_filter"]
