@@ -36,10 +36,12 @@ struct EgsOrderLds {                        // 12.6 KiB
     uint16_t sorted_tile[ORDER_BALANCE_MAX];
 };
 // number of jobs a launch with NT threads per workgroup should carry
-static inline unsigned egs_prologue_jobs(size_t n4, int has_tick, int NT) {
+// `max_zero_jobs` > 0: at most that many zeroing workgroups (each then strides over a larger share) -- for a carrier whose own
+// workgroups should all be resident from the start (loss.hip)
+static inline unsigned egs_prologue_jobs(size_t n4, int has_tick, int NT, unsigned max_zero_jobs = 0) {
     const size_t per_block = (size_t)NT * 8;                         // ~8 float4 stores per thread, at most 1024 zeroing workgroups of 1024 threads' worth
     size_t z = (n4 + per_block - 1) / per_block;
-    const size_t zmax = (size_t)1024 * 1024 / NT;
+    const size_t zmax = max_zero_jobs ? (size_t)max_zero_jobs : (size_t)1024 * 1024 / NT;
     if (z > zmax) z = zmax;
     if (z < 1) z = 1;
     return (unsigned)(EGS_XCDS + (has_tick ? 1 : 0) + z);

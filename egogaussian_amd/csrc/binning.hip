@@ -453,10 +453,12 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, int gpr,
 // Stable ranking as in a global radix pass, but the whole bucket belongs to one workgroup: wave w owns the contiguous
 // quarter [w*chunk, (w+1)*chunk) in rounds of 64.
 // ---------------------------------------------------------------------------------------------
-// Two instantiations share the launch sequence: <4 waves, 2048 pairs> (20 KiB of LDS: eight workgroups per CU, so a 960x540
-// frame's 2040 tiles are all resident at once) sorts every tile of up to 2048 instances; <8 waves, 4096 pairs> takes the
-// larger ones and, beyond 4096, the global-memory path.  Each workgroup returns at once if its tile belongs to the other.
+// Two instantiations share the launch sequence: <4 waves, 1792 pairs> (18.3 KiB of LDS and 64 VGPRs: eight workgroups per CU, so a
+// 960x540 frame's 2040 tiles are all resident at once) sorts every tile of up to 1792 instances; <8 waves, 4096 pairs> takes the
+// larger ones and, beyond 4096, the depth-slab path.  Each workgroup returns at once if its tile belongs to the other.
 #define TS_DBITS 9
+#define TS_SMALL_CAP 1792           // pairs the four-wave instantiation sorts in registers: 14 KiB + 4 KiB of buckets = 18.7 KiB of LDS, EIGHT workgroups per CU
+                                    // (2048 pairs were 20.3 KiB: seven per CU, 1792 of a 960x540 frame's 2040 tiles resident)
 #define TS_DIGITS (1 << TS_DBITS)
 #define TS_BUCKET_MAX 96u           // largest top-digit bucket the in-bucket comparison takes (see k_tile_sort)
 #define TS_SLAB_BUCKET_MAX 512u     // the same for a tile sorted in depth slabs (what it falls back to is far slower than a long comparison loop)
@@ -590,7 +592,7 @@ extern "C" int egs_debug_sort_stamps(unsigned long long* host_out) { return (int
 #define SORT_STAMP(ph)
 #endif
 template <bool RANK_ATOMIC, int TS_WAVES, int TS_CAP, uint32_t N_MIN>
-__global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32_t stride, const uint32_t* __restrict__ table_scanned,
+__global__ __launch_bounds__(64 * TS_WAVES) __attribute__((amdgpu_waves_per_eu(TS_WAVES == 4 ? 8 : 5, 8))) void k_tile_sort(int n_tiles, uint32_t stride, const uint32_t* __restrict__ table_scanned,
                                                     const uint64_t* __restrict__ total, uint64_t* __restrict__ running_max,
                                                     uint32_t* __restrict__ overflow_flag, int solo,
                                                     uint32_t R /* capacity */,
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(64 * TS_WAVES) void k_tile_sort(int n_tiles, uint32
                                                     uint2* __restrict__ ranges) {
     constexpr int TS_THREADS = 64 * TS_WAVES, TS_ITEMS = TS_CAP / TS_THREADS;
     static_assert(TS_CAP * 2 >= TS_WAVES * TS_DIGITS, "the oversize path keeps its counters in the exchange buffer");
-    constexpr int TS_NB = TS_CAP / 4;                                  // depth buckets of the one-pass path (512 for 2 048 keys)
+    constexpr int TS_NB = TS_WAVES * 128;                              // depth buckets of the one-pass path (512 for the four-wave instantiation)
     static_assert(2 * TS_NB >= TS_WAVES * 256 && TS_NB % 256 == 0, "the digit counters of the fallback passes live in the bucket arrays");
     __shared__ uint64_t xbuf[TS_CAP];
     __shared__ uint32_t bkt[2 * TS_NB];                                // one-pass path: bucket cursors [TS_NB], bucket starts [TS_NB]; fallback: cnt[TS_WAVES][256]
@@ -979,16 +981,16 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     // global-memory path.
     const int solo = (uint64_t)R <= 2048ull * (uint64_t)n_tiles ? 1 : 0;
     if (fast) {
-        hipLaunchKernelGGL((k_tile_sort<true, 4, 2048, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, solo, R,
+        hipLaunchKernelGGL((k_tile_sort<true, 4, TS_SMALL_CAP, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, solo, R,
                            ip, b.pairs, b.scratch, b.point_list, im.ranges);
         if (!solo)
-            hipLaunchKernelGGL((k_tile_sort<true, 8, 4096, 2049u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, 0, R,
+            hipLaunchKernelGGL((k_tile_sort<true, 8, 4096, TS_SMALL_CAP + 1u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, 0, R,
                                ip, b.pairs, b.scratch, b.point_list, im.ranges);
     } else {
-        hipLaunchKernelGGL((k_tile_sort<false, 4, 2048, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, solo, R,
+        hipLaunchKernelGGL((k_tile_sort<false, 4, TS_SMALL_CAP, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, solo, R,
                            ip, b.pairs, b.scratch, b.point_list, im.ranges);
         if (!solo)
-            hipLaunchKernelGGL((k_tile_sort<false, 8, 4096, 2049u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, 0, R,
+            hipLaunchKernelGGL((k_tile_sort<false, 8, 4096, TS_SMALL_CAP + 1u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, 0, R,
                                ip, b.pairs, b.scratch, b.point_list, im.ranges);
     }
     egs_prof_stop(EGS_K_SORT, s);

@@ -297,10 +297,13 @@ __device__ __forceinline__ void wave_finish_loss(size_t nblocks, const float* __
 }
 
 // SIDE: the launch also carries the jobs that prepare the rasterizer's backward blend of the same frame (backward_prologue.h) in
-// its first `side_jobs` workgroups -- tile ordering on one CU per XCD, the fused optimizer's bookkeeping, clearing the gradient
-// accumulator.  They have nothing to do with the loss; they ride here because this launch sits between the two blends of a training
+// its LAST `side_jobs` workgroups -- tile ordering on one CU per XCD, the fused optimizer's bookkeeping, clearing the gradient
+// accumulator with a few dozen workgroups that stride over it.  (Round 2 put ~1 500 short zeroing workgroups FIRST: they took every
+// resident slot -- 200 VGPRs: four workgroups per CU -- and the strips, whose latency chains are the launch, started when those
+// retired: 22.3 us in the step against 18.2 us for the loss backward alone; now 20.7.  Letting every strip wave clear a share with a
+// dozen stores of its own instead was slower still, 23.3 us: the stores sit in front of the strip's first loads.)  They have nothing to do with the loss; they ride here because this launch sits between the two blends of a training
 // step and leaves most of the machine's issue slots and all of its HBM bandwidth unused, while a launch of their own costs 12 us.
-// grid: 1-D = side jobs, then per channel plane ceil(strips / WPB) strip workgroups (+ 1 for the deferred loss value)
+// grid: 1-D = per channel plane ceil(strips / WPB) strip workgroups (+ 1 for the deferred loss value), then the side jobs
 template <bool SIDE>
 __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_backward(int H, int W, int strips_x, int strips_y, const float* __restrict__ img,
                                                                 const float* __restrict__ gt, float w_l1, float w_ssim,
@@ -313,10 +316,10 @@ __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_backward(int H, int W, int
     __shared__ __attribute__((aligned(8))) float lds[WPB][3 * 80];      // per wave: [80] pairs (two maps), then [80] floats (the third)
     if (SIDE) {
         __shared__ EgsOrderLds order_lds;
-        if (blockIdx.x < side_jobs) { egs_prologue_job<64 * WPB>(side, blockIdx.x, side_jobs, order_lds); return; }
+        if (blockIdx.x >= gridDim.x - side_jobs) { egs_prologue_job<64 * WPB>(side, blockIdx.x - (gridDim.x - side_jobs), side_jobs, order_lds); return; }
     }
     const unsigned lane = threadIdx.x & 63, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
-    const unsigned rel = blockIdx.x - (SIDE ? side_jobs : 0u);
+    const unsigned rel = blockIdx.x;
     const unsigned plane_z = rel / per_plane, bx = rel - plane_z * per_plane;
     const int strip = (int)bx * WPB + (int)wv;
     if (fin_partial && bx == per_plane - 1) {                          // deferred loss value: one extra workgroup per channel plane, no strip
@@ -394,7 +397,10 @@ int egs_launch_l1_ssim_backward(int channels, int height, int width, const float
     const float n = (float)channels * (float)height * (float)width;
     const int strips_x = (width + SW - 1) / SW, strips_y = (height + SR - 1) / SR;
     const unsigned per_plane = (unsigned)((strips_x * strips_y + WPB - 1) / WPB + (deferred_partial_sums ? 1 : 0));
-    const unsigned side_jobs = side ? egs_prologue_jobs(side->n4, side->has_tick, 64 * WPB) : 0u;
+    // zeroing workgroups: what is left of the 1024 resident slots (4 per CU) next to the strips, the ordering jobs and the tick; 32 at least
+    const unsigned main_wgs = per_plane * (unsigned)channels;
+    const unsigned spare = main_wgs + EGS_XCDS + 1 + 32 <= 1024 ? 1024 - main_wgs - EGS_XCDS - 1 : 32;
+    const unsigned side_jobs = side ? egs_prologue_jobs(side->n4, side->has_tick, 64 * WPB, spare) : 0u;
     EgsPrologueArgs none = {};
 #define LB_ARGS height, width, strips_x, strips_y, img, gt, (1.f - lambda_dssim) / n, lambda_dssim / n, upstream_grad, gate, dm_dmu1, dm_dexx, \
                 dm_dexy, dL_dimg, deferred_partial_sums, (size_t)strips_x * strips_y * channels, lambda_dssim, deferred_loss,            \
