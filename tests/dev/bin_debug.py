@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Bucketing debug driver: one forward of a parity case, lists against the oracle.
-   python tools/bin_debug.py N H W seed scale_mul cull [debug]        (EGS_SUPER_LOG=lsx,lsy forces the super-tile shape)"""
+   python tests/dev/bin_debug.py N H W seed scale_mul cull [debug]        (EGS_SUPER_LOG=lsx,lsy forces the super-tile shape)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from tests.common import make_inputs, tile_culling, check_culled_lists
 from tests.test_gpu_parity import hip_forward, oracle_forward
