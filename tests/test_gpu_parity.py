@@ -328,7 +328,7 @@ def test_clustered_depths_take_the_sorts_fallback_and_still_match(layout):
 
 @pytest.mark.parametrize("layout", ["uniform", "one-dense-tile", "dense-and-tied"])
 def test_tiles_beyond_the_register_capacity_are_sorted_in_depth_slabs(layout):
-    """Tile lists longer than the in-register capacity (2048 / 4096 keys) go through the depth-slab path: histogram into linear depth
+    """Tile lists longer than the in-register capacity (1792 / 4096 keys) go through the depth-slab path: histogram into linear depth
     buckets, runs of buckets with at most the capacity gathered into LDS and ranked one after another.  `uniform`: every tile of a
     small image holds ~8 k instances (the second instantiation's slabs); `one-dense-tile`: a cluster of 12 k splats inside one tile of
     an otherwise light image -- few instances per tile on average, so only the first instantiation is launched and ITS slab path takes
@@ -352,6 +352,37 @@ def test_tiles_beyond_the_register_capacity_are_sorted_in_depth_slabs(layout):
     o, st = oracle_forward(d)
     lens = (st["ranges"][:, 1] - st["ranges"][:, 0])
     assert lens.max() > 4096 and (layout == "uniform") == (lens.mean() > 2048), (int(lens.max()), float(lens.mean()))
+    g_, out = hip_forward(d, dev)
+    bv = _C.binning_views(out[6], N, out[0], W, H, _C.stats["capacity"]); iv = _C.image_views(out[7], W, H)
+    assert out[0] == st["R"]
+    assert np.array_equal(iv["ranges"].cpu().numpy().view(np.uint32), st["ranges"])
+    assert np.array_equal(bv["point_list"].cpu().numpy().view(np.uint32), st["point_list"]), f"longest list {int(lens.max())}"
+    assert outlier_fraction(out[1].cpu().numpy(), st["color"], TOL) <= 1e-4
+
+
+@pytest.mark.parametrize("layout", ["every-tile", "one-tile"])
+def test_tiles_just_over_the_small_sorts_register_capacity(layout):
+    """The four-wave instantiation of the per-tile sort holds 1 792 pairs in registers (eight workgroups per CU); lists of 1 793 ... 2 048
+    used to fit it.  `every-tile`: lists of 1 200 ... 3 300, 2 090 on average, so both instantiations are launched and the eight-wave one takes the
+    tiles beyond 1 792; `one-tile`: a cluster of ~1 900 splats in one tile of a light image -- only the four-wave instantiation is
+    launched and that tile goes through its depth slabs.  Lists and image against the oracle."""
+    from egogaussian_amd import _C
+    dev = _dev()
+    if layout == "every-tile":
+        N, H, W = 11800, 64, 64
+        d = make_inputs(N, H, W, 23, 0, "sh_cov", scale_mul=8.0)
+    else:
+        N, H, W = 6000, 128, 160
+        d = make_inputs(N, H, W, 24, 0, "sh_cov", scale_mul=0.5)
+        g = torch.Generator().manual_seed(11)
+        m3 = d["means3D"]
+        k = 1900
+        m3[:k, 0] = 0.01 * torch.randn(k, generator=g); m3[:k, 1] = 0.01 * torch.randn(k, generator=g)
+        m3[:k, 2] = 3.0 + 4.0 * torch.rand(k, generator=g)
+    o, st = oracle_forward(d)
+    lens = (st["ranges"][:, 1] - st["ranges"][:, 0])
+    assert ((lens > 1792) & (lens <= 2048)).any(), sorted(lens.tolist())[-8:]
+    assert (layout == "every-tile") == (lens.mean() > 2048), float(lens.mean())      # > 2048 on average: both instantiations are launched
     g_, out = hip_forward(d, dev)
     bv = _C.binning_views(out[6], N, out[0], W, H, _C.stats["capacity"]); iv = _C.image_views(out[7], W, H)
     assert out[0] == st["R"]
