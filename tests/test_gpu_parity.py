@@ -484,6 +484,43 @@ def test_image_invariants_at_full_size():
     assert outlier_fraction(outp[1].cpu().numpy(), color.cpu().numpy(), 1e-5) < 1e-4
 
 
+def test_backward_properties_at_full_size():
+    """Size-independent properties of the backward at BASELINE config C shape (500k @ 960x540, the benched workload), where the oracle
+    is too slow to be the checker of every run: the forward is bit-for-bit repeatable (images AND lists); zero upstream gradients give
+    exactly zero gradients; the backward is linear in the upstream gradients (it is a vector-Jacobian product) up to the order of its
+    floating-point sums; the colour gradient of a Gaussian no pixel blends is zero."""
+    from egogaussian_amd import _C
+    dev = _dev()
+    N, H, W = 500000, 540, 960
+    d = make_inputs(N, H, W, 0, 0, "sh_cov")
+    g, out = hip_forward(d, dev)
+    keep = [t.clone() for t in out[1:5]]
+    pl = _C.binning_views(out[6], N, out[0], W, H, _C.stats["capacity"])["point_list"].clone()
+    g2, out2 = hip_forward(d, dev)
+    for a, b in zip(keep, out2[1:5]):
+        assert torch.equal(a, b), "two forwards of the same inputs differ"
+    assert out2[0] == out[0] and torch.equal(pl, _C.binning_views(out2[6], N, out2[0], W, H, _C.stats["capacity"])["point_list"])
+    ga, gb = seeded_grads(H, W, 5), seeded_grads(H, W, 6)
+    zero = [torch.zeros_like(x) for x in ga]
+    for t in hip_backward(g2, out2, zero, dev):
+        assert t.numel() == 0 or float(t.abs().max()) == 0.0, "zero upstream gradients must give zero gradients"
+    ra = [t.clone() for t in hip_backward(g2, out2, ga, dev)]
+    rb = [t.clone() for t in hip_backward(g2, out2, gb, dev)]
+    mix = [2.0 * x - 0.5 * y for x, y in zip(ga, gb)]
+    rm = hip_backward(g2, out2, mix, dev)
+    for k, (m, a, b) in enumerate(zip(rm, ra, rb)):
+        if m.numel():
+            want = (2.0 * a.double() - 0.5 * b.double()).cpu().numpy()
+            assert rel_err(m.double().cpu().numpy(), want) < 2e-5, f"gradient {k} is not linear in the upstream gradients"
+    radii = out2[4]
+    dcol = ra[1] if ra[1].numel() else None                          # dL/dcolors (colours precomputed) -- empty in the SH mode
+    dsh = ra[5]
+    if dsh.numel():
+        assert float(dsh[radii == 0].abs().max()) == 0.0, "a culled Gaussian received a colour gradient"
+    if dcol is not None:
+        assert float(dcol[radii == 0].abs().max()) == 0.0
+
+
 def test_config_D_1M_gaussians_1080p_depth_alpha_gradcheck():
     """BASELINE.json config 5 shape: 1 M Gaussians, 1920x1080, seeded upstream gradients on colour, depth and alpha;
     every output and gradient against the oracle (OpenMP over tiles on the host cores)."""
