@@ -81,6 +81,11 @@ int check_dims(int P, int W, int H) {
     if ((size_t)((W + EGS_TILE - 1) / EGS_TILE) * (size_t)((H + EGS_TILE - 1) / EGS_TILE) > EGS_MAX_TILES) return EGS_ERR_RANGE;
     return 0;
 }
+// The three opaque buffers hold 16-byte vectors at 256-byte-aligned offsets (float4 records, uint4 table words, 64-bit pairs): their
+// base addresses must be 256-byte aligned (include/egs_raster.h, Conventions).  NULL passes: emptiness is checked where it matters.
+static inline bool misaligned(const void* a, const void* b = nullptr, const void* c = nullptr) {
+    return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 255u) != 0;
+}
 int check_modes(const float* shs, const float* colors, const float* scales, const float* rots, const float* cov, int act) {
     if (act & ~(EGS_ACT_LOG_SCALES | EGS_ACT_RAW_QUATS | EGS_ACT_LOGIT_OPACITY)) return EGS_ERR_MODE;
     if ((act & (EGS_ACT_LOG_SCALES | EGS_ACT_RAW_QUATS)) && cov != nullptr) return EGS_ERR_MODE;   // nothing to activate: the covariance is given
@@ -222,6 +227,7 @@ int egs_forward_geometry(int P, int sh_degree, int sh_coeffs, const float* means
     *num_rendered = 0;
     if (P == 0) return 0;
     if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer) return EGS_ERR_ARG;
+    if (misaligned(geom_buffer)) return EGS_ERR_ARG;
     rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp, activation_flags); if (rc) return rc;
     if (shs && (sh_degree < 0 || sh_degree > EGS_MAX_SH_DEGREE || sh_coeffs < (sh_degree + 1) * (sh_degree + 1))) return EGS_ERR_RANGE;
     if (shs_rest && (!shs || sh_coeffs < 2)) return EGS_ERR_MODE;
@@ -265,6 +271,7 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     if (!num_rendered || capacity < 0 || capacity >= (1ll << 31)) return EGS_ERR_ARG;
     *num_rendered = 0;
     if (!background || !image_buffer || !out_color || !out_depth || !out_alpha) return EGS_ERR_ARG;
+    if (misaligned(geom_buffer, binning_buffer, image_buffer)) return EGS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) return egs_forward_render(0, 0, background, width, height, geom_buffer, binning_buffer, image_buffer, out_color,
                                           out_depth, out_alpha, stream, debug);
@@ -367,6 +374,7 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
     if (!background || !image_buffer || !out_color || !out_depth || !out_alpha) return EGS_ERR_ARG;
     if (P > 0 && !geom_buffer) return EGS_ERR_ARG;
     if (R > 0 && !binning_buffer) return EGS_ERR_ARG;
+    if (misaligned(geom_buffer, binning_buffer, image_buffer)) return EGS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
     EgsBinPtrs b = bin_ptrs(binning_buffer, P, R, width, height);
@@ -408,6 +416,7 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
     if (!background || !means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer ||
         !dL_dout_color || !dL_dmeans2D || !scratch)
         return EGS_ERR_ARG;
+    if (misaligned(geom_buffer, binning_buffer, image_buffer) || ((uintptr_t)scratch & 15u)) return EGS_ERR_ARG;
     // leaves a fused optimizer owns: their gradient arrays are optional
     const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);
     bool own[EGS_SINK_LEAVES] = { false, false, false, false, false, false };

@@ -25,6 +25,8 @@
  *   - All pointers are DEVICE pointers unless marked HOST.  fp32, contiguous, row-major.
  *   - The library never allocates or frees device memory; every buffer is owned by the caller and must
  *     stay alive until the work enqueued on `stream` has completed.
+ *   - The opaque geometry / binning / image buffers must start at 256-byte-aligned addresses (hipMalloc and the PyTorch allocator
+ *     give at least that); a misaligned one is refused with EGS_ERR_ARG.  Their layouts place every array at a 256-byte offset.
  *   - Process-wide state, all of it: (1) the optional profiling pool (egs_profile_begin / egs_profile_end), off by
  *     default; (2) the two debug switches egs_debug_set_tile_culling / egs_debug_force_ballot_rank (plain ints read
  *     by every subsequent forward of the process; neither changes an output value); (3) the result of the one-time

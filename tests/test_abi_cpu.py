@@ -85,6 +85,12 @@ def test_argument_errors_precede_device_work():
     # one-call forward: argument errors before any device work
     assert L.egs_forward(10, 0, 1, none, none, none, none, none, none, 1.0, none, none, 0, none, none, none, none, 64, 64, 1.0, 1.0, 0,
                          none, none, 100, none, none, none, none, none, none, C.byref(R), none, none, none, none, 0) == -1
+    # opaque buffers must be 256-byte aligned (include/egs_raster.h, Conventions): refused before any device work
+    q = C.c_void_p(4096 + 16)
+    assert L.egs_forward_geometry(10, 0, 1, p, p, none, none, p, none, 1.0, none, p, 0, p, p, p, 64, 64, 1.0, 1.0, 0, p, q, C.byref(R),
+                                  none, none, none, 0) == -1
+    assert L.egs_forward_render(10, 100, p, 64, 64, p, q, p, p, p, p, none, 0) == -1
+    assert L.egs_forward_render(10, 100, p, 64, 64, p, p, q, p, p, p, none, 0) == -1
     assert L.egs_placement_bytes(960, 540) >= (2040 * 4 + 2040) * 4 and L.egs_placement_bytes(0, 5) == 0
     assert L.egs_mark_visible(5, none, none, none, none, none) == -1
 
