@@ -295,6 +295,10 @@ def main():
         if world > 1:
             raise
         collective_error = f"{type(exc).__name__}: {exc}"
+    import torch.distributed as tdist_check
+    if tdist_check.is_initialized():                                       # the group that came up IS the run that was asked for
+        assert tdist_check.get_world_size() == args.gpus, f"--gpus {args.gpus} but the process group has {tdist_check.get_world_size()} ranks"
+        assert tdist_check.get_rank() == rank
 
     if args.eager_fast:
         torch.autograd.set_multithreading_enabled(False)          # backward on the calling thread: no hand-off to the device thread per step

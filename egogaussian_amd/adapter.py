@@ -9,7 +9,8 @@ removes the ops themselves, without editing the model's class:
 
   for the reference's OWN render() (gaussian_renderer/__init__.py:64-71 calls `pc.get_covariance` / `pc.get_rotated_covariance`):
     * `gaussians.covariance_activation`                            -> fused.covariance_from_scaling_rotation   (one launch each way)
-    * `gaussians.build_covariance_from_scaling_rotation_w_rot`     -> the fused object-rotated producer, same arguments
+    * `gaussians.covariance_activation_w_rot` (what `get_rotated_covariance` calls, gaussian_model.py:39,171) and
+      `gaussians.build_covariance_from_scaling_rotation_w_rot`     -> the fused object-rotated producer, same arguments
   for this package's render() (egogaussian_amd.renderer.render, same signature), which looks for optional hooks on the model:
     * `get_raw_parameters()`, `get_features_split()`                raw parameters straight into the rasterizer: no activation, covariance
                                                                     or concatenation launches at all
@@ -40,7 +41,7 @@ def _trainable_rotation(g, during_training):
     tom = getattr(g, "trainable_object_move", None) if during_training else None
     if tom is None:
         return None
-    return tom.rot_matrix() if hasattr(tom, "rot_matrix") else tom.rot_L(torch.eye(3, device=g._xyz.device))
+    return tom.rot_L(torch.eye(3, device=g._xyz.device))
 
 
 def _selection(g, which_object):
@@ -78,6 +79,7 @@ def attach(gaussians, optimizer=True, capturable=False, fuse_optimizer=False):
         return covariance_from_scaling_rotation(scaling, scaling_modifier, rotation)
 
     def build_covariance_w_rot(scaling, scaling_modifier, rotation, accum_R, which_object=None, during_training=False):
+        build_covariance_w_rot.calls += 1
         if scaling.is_cuda:
             return fused.rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation, accum_R, g._is_object, which_object,
                                                                   _trainable_rotation(g, during_training), selection=_selection(g, which_object))
@@ -85,7 +87,12 @@ def attach(gaussians, optimizer=True, capturable=False, fuse_optimizer=False):
         tom = getattr(g, "trainable_object_move", None) if during_training else None
         return rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation, accum_R, g._is_object, which_object,
                                                         None if tom is None else tom.rot_L)
+    build_covariance_w_rot.calls = 0                                # how often the installed producer ran (tests spy on it)
     g.covariance_activation = covariance_activation
+    # get_rotated_covariance (gaussian_model.py:170-171) calls `covariance_activation_w_rot`, the bound method setup_functions()
+    # captured at __init__ (gaussian_model.py:39) -- that attribute is the one render(rot_cov=True) reaches; the method name is
+    # replaced too for callers that go to it directly.
+    g.covariance_activation_w_rot = build_covariance_w_rot
     g.build_covariance_from_scaling_rotation_w_rot = build_covariance_w_rot
 
     # ---- this package's render(): raw parameters straight into the rasterizer ----
@@ -100,9 +107,10 @@ def attach(gaussians, optimizer=True, capturable=False, fuse_optimizer=False):
     def get_raw_parameters_rotated(accum_R, which_object, during_training):
         if not _on_hip(g) or _trainable_rotation(g, during_training) is not None:
             return None                                            # a rotation that is being trained needs the covariance path (its gradient)
-        M = torch.eye(3, device=g._xyz.device) if accum_R is None else accum_R
-        if M.requires_grad:
+        if accum_R is not None and accum_R.requires_grad:
             return None
+        # the reference's default is a CPU eye(3) and it moves accum_R itself (gaussian_model.py:54-58): tolerate a CPU matrix
+        M = torch.eye(3, device=g._xyz.device) if accum_R is None else accum_R.to(g._xyz.device, torch.float32)
         sel, mult = _selection(g, which_object)
         return g._scaling, g._rotation, g._opacity, (M, sel, mult)
 

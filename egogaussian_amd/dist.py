@@ -29,7 +29,9 @@ def env_world():
 
 
 def require_env(backend):
-    """Check (and, while no HIP context exists, set) what an RCCL group needs from the environment; raises with the fix otherwise."""
+    """What an RCCL group needs from the environment on hosts whose driver only supports dmabuf IPC: set while no HIP context exists,
+    a warning when it is unset and the context is already up (a trainer that touched the GPU first; hosts with legacy IPC work
+    without it, and an RCCL failure names the variable itself), an error only for an explicitly conflicting value."""
     if backend != "nccl":
         return
     for k, v in REQUIRED_ENV.items():
@@ -38,6 +40,11 @@ def require_env(backend):
             continue
         if have is None and not torch.cuda.is_initialized():
             os.environ[k] = v
+            continue
+        if have is None:
+            import warnings
+            warnings.warn(f"{k} is unset and a HIP context already exists: on hosts that only support dmabuf IPC multi-process RCCL "
+                          f"fails with 'hipIpcGetMemHandle: invalid argument' -- export {k}={v} in the launching shell", RuntimeWarning)
             continue
         raise RuntimeError(f"RCCL over xGMI needs {k}={v} in the environment before the first HIP call (found {have!r}); "
                            f"export it in the launching shell (egogaussian_amd/dist.py)")

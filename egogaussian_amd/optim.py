@@ -31,6 +31,10 @@ class AdamSink:
         if self._opt is not None:
             for p in self._params:
                 self._opt._sunk[p] = bool(self.keep_grads)
+                # k_adam's own per-workgroup step counters do not follow a step taken here (only state["step"] advances): the next
+                # plain step() of this parameter re-seeds them.  Set on EVERY fused backward -- a cached sink (make_sink hit) after a
+                # plain step() cleared the flag would otherwise leave the counters one behind.
+                self._opt._aux_of(p)["counter_stale"] = True
 
     def check(self, means3D, scales, rotations, sh, sh_rest, own_cov, colors):
         """Called by _C.rasterize_gaussians_backward with the arrays it is about to pass: the owned leaves must be those arrays."""
@@ -284,7 +288,9 @@ class FusedAdam(torch.optim.Optimizer):
         for (dev, betas, eps), items in by_cfg.items():
             n = len(items)
             # the parameter / moment pointer arrays change only when the tensors do (densification): kept between steps
-            sig = tuple((t[0].data_ptr(), t[2].data_ptr(), t[3].data_ptr()) for t in items)
+            # (the element count is part of the signature: clone / split / prune between two steps can hand a differently sized
+            # tensor the addresses of an old one)
+            sig = tuple((t[0].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[0].numel()) for t in items)
             cached = self._arrays.get((dev, betas, eps))
             if cached is None or cached[0] != sig:
                 cached = self._arrays[(dev, betas, eps)] = (sig, (C.c_void_p * n)(*[t[0].data_ptr() for t in items]),

@@ -206,9 +206,9 @@ class SynthGaussians:
             return None
         if during_training and self.trainable_object_move is not None:
             return None
-        M = torch.eye(3, device=self._xyz.device) if accum_R is None else accum_R
-        if M.requires_grad:
+        if accum_R is not None and accum_R.requires_grad:
             return None
+        M = torch.eye(3, device=self._xyz.device) if accum_R is None else accum_R.to(self._xyz.device, torch.float32)
         sel, mult = self._object_selection(which_object)
         return self._scaling, self._rotation, self._opacity, (M, sel, mult)
 
@@ -237,7 +237,7 @@ class SynthGaussians:
             from . import fused
             return fused.rotated_covariance_from_scaling_rotation(
                 self._scaling, scaling_modifier, self._rotation, accum_R, self._is_object, which_object,
-                None if tom is None else tom.rot_matrix(), scaling_is_log=True, selection=self._object_selection(which_object),
+                None if tom is None else tom.rot_L(torch.eye(3, device=self._xyz.device)), scaling_is_log=True, selection=self._object_selection(which_object),
                 opacity_raw=self._opacity)
         return self.get_rotated_covariance(accum_R, which_object, during_training, scaling_modifier), self.get_opacity
 
@@ -247,7 +247,7 @@ class SynthGaussians:
             from . import fused
             return fused.rotated_covariance_from_scaling_rotation(
                 self.get_scaling, scaling_modifier, self._rotation, accum_R, self._is_object, which_object,
-                None if tom is None else tom.rot_matrix(), selection=self._object_selection(which_object))
+                None if tom is None else tom.rot_L(torch.eye(3, device=self._xyz.device)), selection=self._object_selection(which_object))
         return self._cov.rotated_covariance_from_scaling_rotation(
             self.get_scaling, scaling_modifier, self._rotation, accum_R, self._is_object, which_object,
             None if tom is None else tom.rot_L)

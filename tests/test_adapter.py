@@ -27,6 +27,7 @@ class RefShaped:
         self.trainable_object_move = None
         self.covariance_activation = covariance_from_scaling_rotation
         self._rot_cov = rotated_covariance_from_scaling_rotation
+        self.covariance_activation_w_rot = self.build_covariance_from_scaling_rotation_w_rot     # bound at __init__, gaussian_model.py:39
         self.optimizer = None
 
     get_xyz = property(lambda s: s._xyz)
@@ -44,7 +45,7 @@ class RefShaped:
         return self._rot_cov(scaling, scaling_modifier, rotation, accum_R, self._is_object, which_object, None if tom is None else tom.rot_L)
 
     def get_rotated_covariance(self, accum_R, which_object, during_training, scaling_modifier=1):
-        return self.build_covariance_from_scaling_rotation_w_rot(self.get_scaling, scaling_modifier, self._rotation, accum_R, which_object, during_training)
+        return self.covariance_activation_w_rot(self.get_scaling, scaling_modifier, self._rotation, accum_R, which_object, during_training)   # :171
 
     def training_setup(self):
         groups = [{"params": [self._xyz], "lr": 1.6e-4, "name": "xyz"}, {"params": [self._features_dc], "lr": 2.5e-3, "name": "f_dc"},
@@ -85,6 +86,14 @@ def _check_attached_host_side(m):
     assert float(st["step"]) == 7.0 and float(st["exp_avg"].mean()) == 0.25 and float(st["exp_avg_sq"].mean()) == 0.5
     assert m._egs_fused_optimizer is None
     assert egogaussian_amd.attach(m).optimizer is m.optimizer                            # idempotent
+    # get_rotated_covariance() -- what the reference's render(rot_cov=True) calls -- must REACH the installed producer: it goes through
+    # the attribute setup_functions() bound at __init__ (gaussian_model.py:39,171), not through the method name
+    if hasattr(m, "_is_object"):
+        n0 = m.covariance_activation_w_rot.calls
+        before = m.get_rotated_covariance(torch.eye(3), 1, False, 1.0)
+        assert m.covariance_activation_w_rot.calls == n0 + 1, "get_rotated_covariance did not run the installed producer"
+        assert m.covariance_activation_w_rot is m.build_covariance_from_scaling_rotation_w_rot
+        assert torch.allclose(before, cov0, rtol=1e-6, atol=1e-12)                       # identity rotation: the plain covariance
 
 
 def test_attach_on_reference_shaped_model_cpu():
@@ -126,7 +135,9 @@ def test_attach_on_the_reference_class_itself_cpu():
             # the reference's own rotated-covariance entry point now runs through the installed producer (same values, CPU mirror)
             R = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
             g._is_object[::3] = 1.0
+            n0 = g.covariance_activation_w_rot.calls
             a = g.get_rotated_covariance(R, 1, False, 1.0)
+            assert g.covariance_activation_w_rot.calls == n0 + 1
             from egogaussian_amd.covariance import rotated_covariance_from_scaling_rotation
             b = rotated_covariance_from_scaling_rotation(g.get_scaling, 1.0, g._rotation, R, g._is_object, 1, None)
             assert torch.allclose(a, b)

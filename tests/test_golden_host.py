@@ -263,27 +263,38 @@ def _cam_from_train(g, k, device="cpu"):
     return SynthCamera(g[k + "wvt"].T, int(g["H"]), int(g["W"]), float(g["fov"][0]), float(g["fov"][1]), device=device)
 
 
+class _TrainablePose(torch.nn.Module):
+    """What a trainer keeps in `gaussians.trainable_object_move`, written from the contract this package relies on and nothing else:
+    a (3, 2) parameter `obj_rotation_6d` whose columns are orthonormalised in order (third axis = their cross product) to give a
+    rotation R, and `rot_L(L) = R @ L`.  The values it must reproduce are the reference's, captured in boundary_train.npz
+    (pose_arg_cov3D_precomp, pose_g_rot6d)."""
+
+    def __init__(self, six):
+        super().__init__()
+        self.obj_rotation_6d = torch.nn.Parameter(six.clone())
+
+    def rot_L(self, L):
+        u, v = self.obj_rotation_6d.unbind(dim=1)
+        e0 = u / u.norm()
+        w = v - torch.dot(e0, v) * e0
+        e1 = w / w.norm()
+        return torch.stack((e0, e1, torch.linalg.cross(e0, e1)), dim=1) @ L
+
+
 def _object_move(g, device="cpu"):
-    from egogaussian_amd.geometry import ObjectMove
-    tom = ObjectMove().to(device)
-    with torch.no_grad():
-        tom.obj_rotation_6d.copy_(torch.tensor(g["pose_rot6d"], device=device))
-    return tom
+    return _TrainablePose(torch.tensor(g["pose_rot6d"], device=device))
 
 
-def test_object_move_matches_reference_geometry_utils():
-    """geometry.ObjectMove / rot6d_to_matrix against what the reference's utils/geometry_utils.py produced: the trainable rotation's
-    matrix enters the captured covariance, and its gradient is in the fixture."""
-    from egogaussian_amd.geometry import rot6d_to_matrix, matrix_to_rot6d
+def test_trainable_pose_stand_in_is_a_rotation():
+    """The stand-in's rot_L(I) -- the only thing adapter / scene_synth ask of a trainable pose -- is a proper rotation that spans the
+    captured 6-D parameter's first column; that it is the REFERENCE's rotation is what the covariance test below pins."""
     g = load("boundary_train.npz")
-    tom = _object_move(g)
-    M = tom.rot_matrix()
+    M = _object_move(g).rot_L(torch.eye(3))
     assert M.shape == (3, 3) and torch.allclose(M @ M.t(), torch.eye(3), atol=1e-6) and abs(float(torch.det(M.detach())) - 1.0) < 1e-5
-    assert torch.allclose(matrix_to_rot6d(M), M[:, :2]) and torch.allclose(rot6d_to_matrix(matrix_to_rot6d(M)), M, atol=1e-6)
+    six = torch.tensor(g["pose_rot6d"])
+    assert torch.allclose(M[:, 0], six[:, 0] / six[:, 0].norm(), atol=1e-6)
     L = torch.randn(7, 3, 3, generator=torch.Generator().manual_seed(0))
-    assert torch.allclose(tom.rot_L(L), M @ L)
-    pts = torch.randn(5, 3, generator=torch.Generator().manual_seed(1))
-    assert torch.allclose(tom(pts), pts @ M.t())                      # (translation is zero in the fixture)
+    assert torch.allclose(_object_move(g).rot_L(L), M @ L)
 
 
 def test_training_call_shapes_hand_the_rasterizer_what_the_reference_does():

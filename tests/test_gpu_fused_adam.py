@@ -126,6 +126,44 @@ def test_fused_leaves_have_no_gradient_arrays_and_step_once():
     assert torch.equal(snap, pc._xyz.detach()) and float(opt.state[pc._xyz]["step"]) == 1.0
 
 
+def test_alternating_fused_and_plain_steps_keep_the_step_count():
+    """fused backward (sink built), plain step(), fused backward (sink found in the cache), plain step(), ...: the plain steps must use
+    the step number the fused ones advanced (bias correction), state["step"] never goes backwards, and the parameters follow
+    torch.optim.Adam fed with the same gradients (the fused backward writes them too: keep_grads)."""
+    from egogaussian_amd.scene_synth import SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.fused import l1_ssim_loss
+    from egogaussian_amd.optim import FusedAdam
+    student, cams, gts, bg = _scene(N=6000)
+    pa = SynthGaussians(student, device=DEV)
+    oa = FusedAdam(_groups(pa), lr=0.0, eps=1e-15, capturable=True)
+    pb = SynthGaussians(student, device=DEV)
+    ob = torch.optim.Adam(_groups(pb), lr=0.0, eps=1e-15)
+    real_make, made = oa.make_sink, []
+
+    def keeping(**kw):
+        sink = real_make(**kw)
+        sink.keep_grads = True
+        made.append(sink)
+        return sink
+    oa.make_sink = keeping
+    for it in range(6):
+        fused = it % 2 == 0
+        out = render(cams[it % 4], pa, Pipe, bg, optimizer=oa if fused else None)
+        l1_ssim_loss(out["render"], gts[it % 4], 0.2).backward()
+        for a in LEAVES:
+            getattr(pb, a).grad = getattr(pa, a).grad.clone()
+        oa.step(); oa.zero_grad(set_to_none=True)
+        ob.step(); ob.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        for a in LEAVES:
+            x, y = getattr(pa, a), getattr(pb, a)
+            assert float(oa.state[x]["step"]) == it + 1 == float(ob.state[y]["step"]), (it, a, float(oa.state[x]["step"]))
+            err = float((x.detach() - y.detach()).abs().max())
+            assert err <= 1e-5 * max(1.0, float(y.detach().abs().max())), f"iteration {it}: {a} off torch Adam by {err}"
+    assert len(made) == 3 and made[1] is made[0] and made[2] is made[0]          # the later fused steps DID take the cached sink
+
+
 def test_graph_step_with_and_without_fused_optimizer_agree():
     """GraphedTrainStep(fuse_optimizer=True / False) on the same frames: same step counts, no gradient arrays for the leaves in the
     fused graph, and parameters that differ from the unfused run's no more than two unfused runs differ from each other (the backward's

@@ -58,3 +58,31 @@ def test_bench_single_gpu_line_says_rccl():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["collective"] == "rccl" and "collective_error" not in j and j["n_gpus"] == 1 and j["value"] > 0
+
+
+def test_bench_two_ranks_over_rccl_on_two_devices():
+    """The first multi-rank RCCL initialisation happens here when the box has two devices (the reference's `fine_all` loop sharded over
+    GPUs, /root/reference/trainers/fine_all.py:74-101): `python bench.py --gpus 2 --verify-ranks` with the default `nccl` backend, one
+    rank per device, disjoint frames, equal replicas at the start, scalars reduced over RCCL."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs two HIP devices for a two-rank RCCL group (this box has {torch.cuda.device_count()}); "
+                    "tests/test_gpu_bench_mode.py::test_bench_two_ranks_plain_launch covers two ranks on one device over gloo")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "EGS_BENCH_SHARE_DEVICE0",
+                                                            "EGS_BENCH_BACKEND")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "5", "--gaussians", "60000", "--height", "270",
+           "--width", "480", "--no-cpu-baseline", "--no-sh3-leg", "--verify-ranks"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert j["collective"] == "rccl" and "collective_error" not in j
+    assert j["n_gpus"] == 2 and j["steps"] == 10 and j["scaling"] == "weak" and j["value"] > 0
+    r0, r1 = sorted(j["ranks"], key=lambda x: x["rank"])
+    assert (r0["rank"], r1["rank"]) == (0, 1) and (r0["device"], r1["device"]) == ("cuda:0", "cuda:1")
+    assert r0["frames"] == list(range(0, 30, 2)) and r1["frames"] == list(range(1, 30, 2))
+    assert r0["param_checksum_start"] == r1["param_checksum_start"]
+    assert r0["graph"] and r1["graph"] and r0["overflow"]["ok"] and r1["overflow"]["ok"]
+    assert r0["loss_sum"] > 0 and r1["loss_sum"] > 0 and r0["loss_sum"] != r1["loss_sum"]
+    assert abs(j["mean_loss"] - (r0["loss_sum"] + r1["loss_sum"]) / 20) < 1e-6
+    assert j["fine_all_shape"]["n_gpus"] == 2 and j["fine_all_shape"]["value"] > 0
