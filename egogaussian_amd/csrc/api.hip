@@ -77,7 +77,7 @@ EgsImgPtrs img_ptrs(void* buf, int W, int H) {
 
 int check_dims(int P, int W, int H) {
     if (P < 0 || W <= 0 || H <= 0) return EGS_ERR_ARG;
-    if (W > 65535 || H > 65535) return EGS_ERR_RANGE;
+    if (W > 32767 || H > 32767) return EGS_ERR_RANGE;                    // 15-bit pixel coordinates in the record's box (egs_common.h)
     if ((size_t)((W + EGS_TILE - 1) / EGS_TILE) * (size_t)((H + EGS_TILE - 1) / EGS_TILE) > EGS_MAX_TILES) return EGS_ERR_RANGE;
     return 0;
 }
@@ -184,7 +184,7 @@ int egs_device_info(char* name, int name_len, char* arch, int arch_len, int* com
 size_t egs_geom_bytes(int P) { return geom_layout(P).bytes; }
 size_t egs_binning_bytes(int P, int64_t R, int width, int height) { return bin_layout(P, R, width, height).bytes; }
 size_t egs_image_bytes(int width, int height) { return img_layout(width, height).bytes; }
-size_t egs_backward_scratch_bytes(int P) { return egs_align((size_t)(P > 0 ? P : 0) * EGS_GRAD_STRIDE * sizeof(float)); }
+size_t egs_backward_scratch_bytes(int P) { return egs_align(egs_acc_floats((size_t)(P > 0 ? P : 0)) * sizeof(float)); }
 
 int egs_get_geom_layout(int P, egs_geom_layout* out) { if (!out || P < 0) return EGS_ERR_ARG; *out = geom_layout(P).o; return 0; }
 int egs_get_binning_layout(int P, int64_t R, int width, int height, egs_binning_layout* out) {
@@ -467,14 +467,14 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
     }
     // the accumulator is cleared by a kernel, not a memset node (see egs_launch_zero_f4): fused into the blend's prologue
     if (R == 0 && !prologue_done) {
-        EGS_TRY(egs_launch_zero_f4((float4*)grad_acc, (size_t)P * EGS_GRAD_STRIDE / 4, s));
+        EGS_TRY(egs_launch_zero_f4((float4*)grad_acc, egs_acc_floats((size_t)P) / 4, s));
         if (sink) EGS_TRY(egs_launch_adam_tick(tick, s));
     }
     if (R > 0) {
         const uint32_t* point_list = b.point_list;
-        if (!prologue_done) EGS_TRY(egs_launch_backward_prologue(width, height, im, grad_acc, (size_t)P * EGS_GRAD_STRIDE, sink ? &tick : nullptr, s));
+        if (!prologue_done) EGS_TRY(egs_launch_backward_prologue(width, height, im, grad_acc, egs_acc_floats((size_t)P), sink ? &tick : nullptr, s));
         egs_prof_start(EGS_K_RENDER_BWD, s);                         // (the stage is the blend kernel alone)
-        EGS_TRY(egs_launch_render_backward(width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth, dL_dout_alpha, grad_acc, s));
+        EGS_TRY(egs_launch_render_backward(P, width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth, dL_dout_alpha, grad_acc, s));
         egs_prof_stop(EGS_K_RENDER_BWD, s);
         EGS_SYNC_IF_DEBUG(s);
     }
@@ -537,7 +537,7 @@ int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* im
     EgsImgPtrs im = img_ptrs(side->image_buffer, side->width, side->height);
     EgsPrologueArgs pa = {};
     pa.n_tiles = ((side->width + EGS_TILE - 1) / EGS_TILE) * ((side->height + EGS_TILE - 1) / EGS_TILE);
-    pa.quad_work = im.quad_work; pa.tile_order = im.tile_order; pa.acc4 = (float4*)side->scratch; pa.n4 = (size_t)side->P * EGS_GRAD_STRIDE / 4;
+    pa.quad_work = im.quad_work; pa.tile_order = im.tile_order; pa.acc4 = (float4*)side->scratch; pa.n4 = egs_acc_floats((size_t)side->P) / 4;
     if (side->sink) {
         if (!side->sink->coef) return EGS_ERR_ARG;
         EgsSink ks = {};

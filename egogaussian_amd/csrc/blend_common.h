@@ -25,7 +25,7 @@ __device__ __forceinline__ void egs_load_rec(const float4* __restrict__ rec, uin
 }
 
 // Can the splat reach the pixel block [qx0,qx1] x [qy0,qy1] at all?  Two stages, both conservative (never a false "no"):
-//   1. the record's pixel bounding box (c2.z = x0 | x1<<16, c2.w = y0 | y1<<16) must intersect the block;
+//   1. the record's pixel bounding box (c2.z = x0 | x1<<16, c2.w = y0 | y1<<16, 15-bit fields) must intersect the block;
 //   2. exact: max over the block of the (concave) log2 falloff  qa dx^2 + qb dx dy + qc dy^2  must reach
 //      log2(1/(255 o)) -- below that, alpha < 1/255 for every pixel of the block.  If the centre is outside the
 //      block the maximum sits on one of the (at most two) edges facing the centre, at the clamped 1-D optimum.
@@ -72,7 +72,7 @@ __device__ __forceinline__ bool egs_ellipse_hits_prepped(const float4& e0 /*x, y
 __device__ __forceinline__ bool egs_block_hits(const float4& c0, const float4& c1, const float4& c2, uint32_t qx0,
                                                uint32_t qx1, uint32_t qy0, uint32_t qy1) {
     const uint32_t bx = __float_as_uint(c2.z), by = __float_as_uint(c2.w);
-    const uint32_t x0 = bx & 0xffffu, x1 = bx >> 16, y0 = by & 0xffffu, y1 = by >> 16;
+    const uint32_t x0 = bx & EGS_BOX_MASK, x1 = (bx >> 16) & EGS_BOX_MASK, y0 = by & EGS_BOX_MASK, y1 = by >> 16;     // (the other bits: egs_hot_code)
     if (!(x0 <= qx1 && x1 >= qx0 && y0 <= qy1 && y1 >= qy0)) return false;
     return egs_ellipse_hits(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, qx0, qx1, qy0, qy1);
 }

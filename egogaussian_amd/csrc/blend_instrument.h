@@ -9,6 +9,8 @@
 //   EGS_ABL      1  forward without the visit / pair counters           2  ... and without the last-contributor index
 //                3  forward with exp2 replaced by a polynomial stub     4  forward without the LDS prefetch of the next record
 //                5  backward without the cross-lane reduction and the atomic (the pair arithmetic alone)
+//                6  backward with the atomic replaced by a plain store
+//                7  backward without the accumulation of splats whose box covers >= EGS_ABL7_AREA pixels (hot accumulator lines)
 //   EGS_NO_LRPT     no issue-priority steps (s_setprio) in either kernel
 #pragma once
 
@@ -91,6 +93,17 @@
 #else
 #define EGS_BWD_MEASURE(...)
 #define EGS_BWD_TIMELINE()
+#endif
+#if EGS_ABL == 6                       // the reduction kept, the atomic replaced by a plain store to the same word
+#define EGS_BWD_ACCUM(PTR, VAL) (*(PTR) = (VAL))
+#else
+#define EGS_BWD_ACCUM(PTR, VAL) unsafeAtomicAdd((PTR), (VAL))
+#endif
+#if EGS_ABL == 7                       // no accumulation at all for splats whose alpha >= 1/255 box covers EGS_ABL7_AREA pixels or more
+#define EGS_BWD_ABL7(C2) { const uint32_t bx_ = __float_as_uint((C2).z), by_ = __float_as_uint((C2).w);                          \
+                           if ((((bx_ >> 16) & 0x7fffu) - (bx_ & 0x7fffu) + 1u) * ((by_ >> 16) - (by_ & 0x7fffu) + 1u) >= (uint32_t)(EGS_ABL7_AREA)) continue; }
+#else
+#define EGS_BWD_ABL7(C2)
 #endif
 #if EGS_ABL == 5
 #define EGS_BWD_ABL5(...) __VA_ARGS__

@@ -11,7 +11,8 @@
 
 // Packed per-Gaussian record produced by preprocess and gathered by the blend kernels:
 //   f4[0] = (x, y, qa, qb)   f4[1] = (qc, opacity, red, green)
-//   f4[2] = (blue, depth, bits(bbox_x = x0 | x1<<16), bits(bbox_y = y0 | y1<<16))
+//   f4[2] = (blue, depth, bits(bbox_x = x0 | x1<<16 | hot bits), bits(bbox_y = y0 | y1<<16 | hot bit))
+//           box coordinates are 15 bits (image sides <= 32767); bits 15 and 31 of bbox_x and bit 15 of bbox_y hold the HOT code
 // (qa, qb, qc) = (-0.5 A, -B, -0.5 C) * log2(e): the conic pre-scaled so that
 //   log2(G) = qa dx^2 + qb dx dy + qc dy^2   feeds v_exp_f32 directly (5 VALU instead of 8).
 // The blend loop reads f4[0], f4[1] and the first half of f4[2] (ds_read_b128 x2 + ds_read_b64).
@@ -25,6 +26,30 @@
 //   [6..8]=dL/dcolor rgb  [9]=dL/ddepth  [10..11]=pad
 // k_preprocess_backward converts the five moments into dL/dmean2D and dL/dconic with the Gaussian's own opacity and conic.
 #define EGS_GRAD_STRIDE 12
+
+// Hot Gaussians.  A splat whose alpha >= 1/255 box covers EGS_HOT_MIN_TILES tiles or more is visited by hundreds to thousands of
+// quadrant-waves, all of which add into ITS ONE accumulator line -- and the waves of every tile reach it at about the same point of
+// their lists.  Atomics on one line retire one after the other (~4 ns each), and the queue behind a hot line holds up everybody's:
+// on a trained scene (a few hundred screen-filling splats) that was 52 of the backward blend's 217 us (profiles/r4_trained_scene.md).
+// Such a Gaussian therefore gets EGS_HOT_REPLICAS accumulator lines, the wave picks one by its tile, and k_preprocess_backward adds
+// them up.  Which lines: k_preprocess ranks the hot Gaussians of its 256-Gaussian workgroup (no global counter) and leaves
+// code = rank + 1 (1 .. EGS_HOT_PER_BLOCK; 0 = not hot, also for those beyond the workgroup's budget) in the record's spare bits;
+// the lines of Gaussian i with code c are hot_acc[((i / 256) * EGS_HOT_PER_BLOCK + c - 1) * EGS_HOT_REPLICAS + r], r = tile % EGS_HOT_REPLICAS,
+// EGS_HOT_LINE floats apart, right behind the P regular lines in the backward's scratch.  Sums only move between lines: every
+// gradient is the same sum of the same terms.
+#define EGS_HOT_MIN_TILES 256u
+#define EGS_HOT_PER_BLOCK 7u
+#define EGS_HOT_REPLICAS 8u
+#define EGS_HOT_LINE 16u            // floats between replica lines (64 B: two per 128-byte line)
+#define EGS_BOX_MASK 0x7fffu
+__host__ __device__ __forceinline__ uint32_t egs_hot_code(uint32_t bbx, uint32_t bby) {
+    return ((bbx >> 15) & 1u) | ((bbx >> 30) & 2u) | ((bby >> 13) & 4u);
+}
+__host__ __device__ __forceinline__ void egs_hot_code_set(uint32_t& bbx, uint32_t& bby, uint32_t code) {
+    bbx |= ((code & 1u) << 15) | ((code & 2u) << 30); bby |= (code & 4u) << 13;
+}
+static inline size_t egs_hot_floats(size_t P) { return ((P + 255) / 256) * EGS_HOT_PER_BLOCK * EGS_HOT_REPLICAS * EGS_HOT_LINE; }
+static inline size_t egs_acc_floats(size_t P) { return P * EGS_GRAD_STRIDE + egs_hot_floats(P); }    // regular lines, then the hot replicas
 
 struct EgsGeomPtrs {
     float4* rec; uint2* rect; uint32_t* offsets; uint8_t* clamped; uint8_t* visible; uint32_t* scan_scratch; uint64_t* total;
@@ -154,7 +179,7 @@ hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs 
 // The backward blend, and what it needs in place first (tile order, cleared accumulator; `tick`, may be NULL: the per-step bookkeeping
 // of an optimizer fused into this backward) as a launch of its own -- or carried by egs_l1_ssim_backward_ex (backward_prologue.h).
 hipError_t egs_launch_backward_prologue(int W, int H, EgsImgPtrs im, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick, hipStream_t s);
-hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
+hipError_t egs_launch_render_backward(int P, int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
                                       const float* dL_dalpha, float* grad_acc, hipStream_t s);
 hipError_t egs_launch_adam_tick(const EgsAdamTick& tick, hipStream_t s);       // the same bookkeeping as a launch of its own (frames with no instance)

@@ -143,7 +143,8 @@ __device__ __forceinline__ uint32_t preprocess_one(
     const float* __restrict__ rots, const float* __restrict__ cov3D_in, int act, const float* __restrict__ V,
     const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
-    uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible, const EgsObjRot rot) {
+    uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible, const EgsObjRot rot,
+    bool& hot) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     radii[i] = 0; tiles_touched[i] = 0; visible[i] = 0;
 
@@ -218,6 +219,8 @@ __device__ __forceinline__ uint32_t preprocess_one(
             if (fx0 <= fx1 && fy0 <= fy1) {
                 bbx = (uint32_t)fx0 | ((uint32_t)fx1 << 16);
                 bby = (uint32_t)fy0 | ((uint32_t)fy1 << 16);
+                // a box over this many tiles: its accumulator line would be hit by every quadrant-wave of all of them (egs_common.h)
+                hot = (((uint32_t)fx1 >> 4) - ((uint32_t)fx0 >> 4) + 1u) * (((uint32_t)fy1 >> 4) - ((uint32_t)fy0 >> 4) + 1u) >= EGS_HOT_MIN_TILES;
             } else if (!(ex == ex) || !(ey == ey) || !(px == px) || !(py == py)) {   // NaN: never cull
                 bbx = 0u | ((uint32_t)(W - 1) << 16); bby = 0u | ((uint32_t)(H - 1) << 16);
             }
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
     uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible,
     uint32_t* __restrict__ block_sums, uint32_t* __restrict__ zero_words, size_t zero_n, const int32_t* __restrict__ active_count,
     EgsPrologueArgs place, EgsObjRot rot) {
-    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wsum[4], whot[4];
     if (PLACE) {
         __shared__ EgsOrderLds order_lds;
         if (blockIdx.x < EGS_XCDS) { egs_order_band<256>(place, (int)blockIdx.x, order_lds); return; }
@@ -259,14 +262,28 @@ __global__ __launch_bounds__(256) void k_preprocess(
     // capacity-sized models (include/egs_raster.h): rows at and beyond the device-side live count are culled whatever they hold
     const int live = active_count ? min(P, max(*active_count, 0)) : P;
     if (i >= live && i < P) { radii[i] = 0; tiles_touched[i] = 0; visible[i] = 0; }
+    bool hot = false;
     if (i < live) my_tiles = preprocess_one(i, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D_in, act, V, PM, campos, W, H,
-                                         tanfovx, tanfovy, radii, rec, rect_out, tiles_touched, clamped_out, visible, rot);
+                                         tanfovx, tanfovy, radii, rec, rect_out, tiles_touched, clamped_out, visible, rot, hot);
+    hot = hot && my_tiles != 0;
+    const uint64_t hot_wave = __ballot(hot);
     // per-block instance count; the host adds the block sums to get R (no contended atomic, deterministic)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) my_tiles += (uint32_t)__shfl_xor((int)my_tiles, d, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = my_tiles;
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = my_tiles; whot[threadIdx.x >> 6] = (uint32_t)__popcll(hot_wave); }
     __syncthreads();
     if (threadIdx.x == 0) block_sums[bid] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (hot) {   // rank among the workgroup's hot Gaussians -> the code that names this one's replica lines (egs_common.h); few per frame
+        const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        uint32_t rank = (uint32_t)__popcll(hot_wave & (lane ? (~0ull >> (64 - lane)) : 0ull));
+        for (unsigned k = 0; k < w; k++) rank += whot[k];
+        if (rank < EGS_HOT_PER_BLOCK) {
+            float4* r2 = rec + (size_t)i * EGS_SPLAT_REC_F4 + 2;
+            uint32_t bbx = __float_as_uint(r2->z), bby = __float_as_uint(r2->w);
+            egs_hot_code_set(bbx, bby, rank + 1u);
+            r2->z = __uint_as_float(bbx); r2->w = __uint_as_float(bby);
+        }
+    }
 }
 
 // stage offsets (floats) of the leaves a fused optimizer owns: rows of the workgroup's 256 Gaussians, leaf after leaf
@@ -281,7 +298,7 @@ __device__ __forceinline__ void pp_bwd_one(
     const float* __restrict__ scales, float mod, const float* __restrict__ rots, const float* __restrict__ cov3D_in, int act,
     const float* __restrict__ V, const float* __restrict__ PM, const float* __restrict__ campos, int W, int H,
     float tanfovx, float tanfovy, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
-    const float4* __restrict__ rec, const float* __restrict__ grad_acc, float* __restrict__ dmeans2D, float* __restrict__ dcolors,
+    const float4* __restrict__ rec, const float* __restrict__ grad_acc, const float* __restrict__ hot_acc, float* __restrict__ dmeans2D, float* __restrict__ dcolors,
     float* __restrict__ dopac, float* __restrict__ dmeans3D, float* __restrict__ dcov3D, float* __restrict__ dsh,
     float* __restrict__ dscales, float* __restrict__ drots,
     float* __restrict__ stat_grad_accum, float* __restrict__ stat_denom, float* __restrict__ stat_max_radii,
@@ -306,6 +323,15 @@ __device__ __forceinline__ void pp_bwd_one(
     if (vis) {
         const float4* r = rec + (size_t)i * EGS_SPLAT_REC_F4;
         const float4 r0 = r[0], r1 = r[1];
+        const uint32_t code = egs_hot_code(__float_as_uint(r[2].z), __float_as_uint(r[2].w));
+        if (code) {   // a hot Gaussian: the blend spread its sums over EGS_HOT_REPLICAS lines behind the regular ones (egs_common.h)
+            const float* hl = hot_acc + (((size_t)(i >> 8) * EGS_HOT_PER_BLOCK + (code - 1u)) * EGS_HOT_REPLICAS) * EGS_HOT_LINE;
+            for (unsigned rp = 0; rp < EGS_HOT_REPLICAS; rp++) {
+                const float4* ga = reinterpret_cast<const float4*>(hl + rp * EGS_HOT_LINE);
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const float4 v = ga[k]; acc[4 * k] += v.x; acc[4 * k + 1] += v.y; acc[4 * k + 2] += v.z; acc[4 * k + 3] += v.w; }
+            }
+        }
         const float cA = r0.z * (-2.f * EGS_LN2), cB = r0.w * (-EGS_LN2), cC = r1.x * (-2.f * EGS_LN2);
         const float o = r1.y;
         gmx = -o * (cA * acc[0] + cB * acc[1]); gmy = -o * (cC * acc[1] + cB * acc[0]);
@@ -553,7 +579,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     }
     if (i < P)
         pp_bwd_one<SINK>(i, D, M, means3D, shs, scales, mod, rots, cov3D_in, act, V, PM, campos, W, H, tanfovx, tanfovy, radii, clamped, rec,
-                         grad_acc, dmeans2D, dcolors, dopac, dmeans3D, dcov3D, dsh, dscales, drots, stat_grad_accum, stat_denom,
+                         grad_acc, grad_acc + (size_t)P * EGS_GRAD_STRIDE, dmeans2D, dcolors, dopac, dmeans3D, dcov3D, dsh, dscales, drots, stat_grad_accum, stat_denom,
                          stat_max_radii, skip_flag, stage, fused, rot);
     if (!SINK) return;
     __syncthreads();

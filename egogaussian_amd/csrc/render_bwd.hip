@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ tile_order, float* __restrict__ grad_acc,
-    const uint32_t* __restrict__ quad_visits) {
+    const uint32_t* __restrict__ quad_visits, const uint32_t hot_base /* first float of the hot replica lines inside grad_acc */) {
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
     __shared__ __attribute__((aligned(16))) float red[4][5 * 64];
     __shared__ uint32_t quad_claimed;
@@ -161,6 +161,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (mask == 0ull) continue;
         my[lane * 3 + 0] = c0; my[lane * 3 + 1] = c1; my[lane * 3 + 2] = c2;
         __builtin_amdgcn_wave_barrier();
+        // entries whose Gaussian is hot (egs_common.h): their sums go to one of the Gaussian's replica lines instead of its own
+        const uint32_t my_code = egs_hot_code(__float_as_uint(c2.z), __float_as_uint(c2.w));
+        const uint64_t hot_mask = __ballot(have && my_code != 0u);
         const uint32_t lastb = last > base ? last - base : 0u;       // this pixel uses entries j < lastb of the batch
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
@@ -218,7 +221,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             out = dpp_add<0xB1>(out);       // quad_perm [1,0,3,2]
             out = dpp_add<0x4E>(out);       // quad_perm [2,3,0,1]
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)my_id, j);
-            if (slot >= 0) unsafeAtomicAdd(grad_acc + (gid * (uint32_t)EGS_GRAD_STRIDE + (uint32_t)slot), out);   // (48 P < 2^32 bytes: P < 89 M)
+            EGS_BWD_ABL7(my[j * 3 + 2])
+            uint32_t line = gid * (uint32_t)EGS_GRAD_STRIDE;            // first float of the accumulator line (48 P < 2^32 bytes: P < 89 M)
+            if ((hot_mask >> j) & 1ull) {                               // (wave-uniform, rare)
+                const uint32_t code = (uint32_t)__builtin_amdgcn_readlane((int)my_code, j);
+                line = hot_base + ((((gid >> 8) * EGS_HOT_PER_BLOCK + code - 1u) * EGS_HOT_REPLICAS) + ((uint32_t)tile % EGS_HOT_REPLICAS)) * EGS_HOT_LINE;
+            }
+            if (slot >= 0) EGS_BWD_ACCUM(grad_acc + (line + (uint32_t)slot), out);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -243,7 +252,7 @@ hipError_t egs_launch_backward_prologue(int W, int H, EgsImgPtrs im, float* grad
     return hipGetLastError();
 }
 
-hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
+hipError_t egs_launch_render_backward(int P, int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
                                       const float* dL_dalpha, float* grad_acc, hipStream_t s) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
@@ -252,10 +261,10 @@ hipError_t egs_launch_render_backward(int W, int H, const float* bg, EgsGeomPtrs
     if (dL_ddepth || dL_dalpha)
         hipLaunchKernelGGL(k_render_backward<true>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                            im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
-                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles);
+                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles, (uint32_t)((size_t)P * EGS_GRAD_STRIDE));
     else
         hipLaunchKernelGGL(k_render_backward<false>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                            im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
-                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles);
+                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles, (uint32_t)((size_t)P * EGS_GRAD_STRIDE));
     return hipGetLastError();
 }

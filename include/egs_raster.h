@@ -59,7 +59,7 @@ extern "C" {
 
 #define EGS_ERR_ARG        (-1)     /* NULL / inconsistent arguments */
 #define EGS_ERR_MODE       (-2)     /* colour or covariance mode not "exactly one of" */
-#define EGS_ERR_RANGE      (-3)     /* size outside supported range (image side > 65535 px or > 36864 tiles, R >= 2^31, degree > 3) */
+#define EGS_ERR_RANGE      (-3)     /* size outside supported range (image side > 32767 px or > 36864 tiles, R >= 2^31, degree > 3) */
 #define EGS_ERR_NO_DEVICE  (-4)     /* no HIP device / wrong architecture */
 #define EGS_RETRY_LARGER   (-100)   /* egs_forward only: capacity guess too small, nothing rendered; *num_rendered holds R */
 

@@ -2,7 +2,7 @@
 """Per-stage HIP-event timing of the rasterizer alone (forward + backward) on a synthetic scene.
    python tools/time_stages.py [N] [H] [W] [iters]     (EGS_RASTER_LIB=path selects an A/B build of the library;
    SH_DEGREE=d for more colour coefficients, SH_SPLIT=0 to hand them over concatenated as the reference's get_features does,
-   SCALE_MUL=f multiplies every splat's extent)"""
+   SCALE_MUL=f multiplies every splat's extent, SCENE=file.npz replaces the scene)"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,6 +14,11 @@ N, H, W, iters = [int(a) for a in (sys.argv[1:5] + ["500000", "540", "960", "30"
 dev = "cuda:0"
 D = int(os.environ.get("SH_DEGREE", "0"))
 scene = make_scene(N, H, W, 0, sh_degree=D)
+if os.environ.get("SCENE"):                            # e.g. SCENE=bench_data/trained_scene.npz (the densified model)
+    import numpy as np
+    z = np.load(os.environ["SCENE"])
+    scene = {k: z[k] for k in ("xyz", "log_scale", "quat", "opacity_logit", "features")}
+    N = scene["xyz"].shape[0]
 if os.environ.get("SCALE_MUL"):
     import numpy as np
     scene["log_scale"] = scene["log_scale"] + np.float32(math.log(float(os.environ["SCALE_MUL"])))
