@@ -381,11 +381,16 @@ def main():
         r_sum = [0, 0]
 
         host_t = [0.0, 0.0, 0]                                      # host seconds inside render() / loss.backward(), calls
+        # eager loop on the fast paths: no host wait for the instance count either -- the frame is checked at the next forward, a frame
+        # that did not fit is voided on the device (egogaussian_amd/_C.py StepGuard(deferred=True))
+        eguard = _C.StepGuard(dev, deferred=True) if eager_fast else None
+        if eguard is not None:
+            opt.guard = eguard
 
         def eager_step(i):
             k = i % n_used
             th0 = time.perf_counter()
-            out = render(cams[k], pc, Pipe, bg, **({"optimizer": opt} if eager_fast else {}), **rkw(rot[k] if dynamic else None))
+            out = render(cams[k], pc, Pipe, bg, **({"optimizer": opt, "guard": eguard} if eager_fast else {}), **rkw(rot[k] if dynamic else None))
             th1 = time.perf_counter()
             if args.op_only:
                 loss = (out["render"] * up_c).sum() + (out["depth"] * up_d).sum() + (out["alpha"] * up_a).sum()
@@ -467,6 +472,8 @@ def main():
         torch.cuda.synchronize()
         stages = egs_lib.profile_end()
         host_us = None if (graphed is not None or not host_t[2]) else (1e6 * host_t[0] / host_t[2], 1e6 * host_t[1] / host_t[2])
+        if eguard is not None:
+            assert eguard.check(), f"{eguard.overflows} eager frame(s) exceeded the instance capacity and were voided"
         stage_timing = "HIP events recorded by the library on the launch stream inside the timed region"
         overflow = None
         if graphed is not None:
@@ -578,7 +585,12 @@ def main():
                 "kernel_source_hash": src_hash,
                 "pairs_Q": int(head["pairs"]), "visits": int(head["visits"]), "lanes_kept_per_visit": round(head["pairs"] / max(head["visits"], 1), 2),
                 "pairs_per_s_G": pair_rows,
-                "ms_per_launch": d["ms_per_launch"], "alg_bytes_per_launch": int(d["alg_MB"] * 1e6), "timing": head["stage_timing"],
+                "ms_per_launch": d["ms_per_launch"], "alg_bytes_per_launch": int(d["alg_MB"] * 1e6),
+                **({"alg_bytes_per_launch_survey_8d": int(84 * R_kept + 32 * npix),
+                    "frac_survey_8d": round((84 * R_kept + 32 * npix) / t_dom / 1e9 / HBM_PEAK_GBS, 5),
+                    "alg_bytes_note": "alg_bytes_per_launch prices an instance at 92 B (4 id + 48 record as this library packs it + 40 accumulate), "
+                                      "SURVEY.md 8d at 84 B (44 list re-read + 40 accumulate); both + 32 B per pixel"} if dominant == "render_backward" else {}),
+                "timing": head["stage_timing"],
                 "note": "blend stages are VALU-issue-bound (per pixel-splat pair work), not HBM-bound: pairs_Q = (pixel, splat) pairs one frame "
                         "blends, visits = (8x8-pixel wave, splat) iterations of the forward; see `stages` for the streaming kernels"}
     op_ms = sum(ms / n for ms, n in stages.values() if n)
@@ -603,7 +615,10 @@ def main():
             o.backward(st, up_c.cpu(), up_d.cpu(), up_a.cpu())
             tcpu += time.perf_counter() - tc
             n_cpu += 1
-        cpu = {"value": round(n_cpu / tcpu, 4), "unit": "iters/s", "cores": cores, "kind": "port",
+        cpu = {"value": round(n_cpu / tcpu, 4), "unit": "iters/s", "cores": cores, "kind": "port", "step": "op_only",
+               "gpu_op_only": {"value": round(1e3 / op_ms, 1), "unit": "iters/s", "ms": round(op_ms, 4),
+                               "what": "the same unit of work on the GPU: rasterizer forward + backward alone (sum of the per-stage HIP-event means of "
+                                       "this run; `value` of the line is the full training step)"},
                "sample": f"{n_cpu} rasterizer forward+backward passes (op only, no loss/optimizer) over the first frames of the same "
                          f"{N}@{W}x{H} workload, oracle/raster_oracle.c with OpenMP over tiles ({tcpu:.1f} s of wall clock on {cores} cores)"}
 
@@ -622,6 +637,9 @@ def main():
         "collective": egs_dist.collective_name(), **({"collective_error": collective_error} if collective_error else {}),
         "config": {"workload": f"S({N},{H},{W},seed{args.teacher_seed}) teacher/student, 300-frame orbit, 1 frame per GPU per step; step = " + step_text[head_name],
                    "gaussians": N, "image": [H, W], "sh_degree": D, "instances_R": int(R_mean), "instances_after_tile_culling": int(R_kept),
+                   "teacher_seed": args.teacher_seed,
+                   "teacher_seed_note": "SURVEY.md 8d names instance C as S(500k,540,960,seed 0) and, in its ground-truth sentence, a teacher of seed 1; "
+                                        "the instance list is followed (as in rounds 1-3, so the numbers stay comparable); --teacher-seed 1 runs the other",
                    "tile_list_len_mean": round(head["list_mean"], 1), "tile_list_len_max": head["list_max"],
                    "sort_passes_max": passes,
                    "parallelism": f"frames sharded over {world} GPU(s), scalar all-reduce only",
@@ -697,6 +715,20 @@ def main():
                                        "step": j["config"]["workload"].split("step = ")[-1]}
         except Exception as exc:
             out["eager_fused_step"] = {"error": f"{type(exc).__name__}: {exc}"}
+        # ... and the same loop for a trainer that reads the loss only now and then: with the instance count checked at the NEXT forward
+        # (StepGuard(deferred=True)) nothing in the iteration waits for the GPU, so the host runs ahead and the two overlap
+        try:
+            leg = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-graph", "--eager-fast", "--steps", str(min(args.steps, 200)),
+                                  "--warmup", "20", "--no-cpu-baseline", "--gaussians", str(N), "--height", str(H), "--width", str(W)],
+                                 capture_output=True, text=True, timeout=600)
+            j = json.loads(leg.stdout.strip().splitlines()[-1])
+            out["eager_fused_step_no_sync"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                                               "host_us_per_forward": j.get("host_us_per_forward"), "host_us_per_backward": j.get("host_us_per_backward"),
+                                               "psnr_db": j["psnr_db"],
+                                               "launch": "eager, no host synchronisation inside the loop: the forward is enqueued against the capacity hint and "
+                                                         "checked at the next forward (a frame that did not fit is voided on the device)"}
+        except Exception as exc:
+            out["eager_fused_step_no_sync"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world == 1 and not args.no_config_legs and not (args.op_only or args.torch_host_ops or args.no_graph or args.dynamic or D > 0):
         # BASELINE.json configs 2 and 5 on the same GPU, in this process (the training legs' tensors are released first)
         legs.clear(); head = None
@@ -709,6 +741,15 @@ def main():
                                           "/root/reference/gaussian_renderer/__init__.py:90-98 with depth + alpha gradients, BASELINE.json config 5")
             except Exception as exc:
                 out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        # A TRAINED scene: what the reference's trainers and its evaluation actually render (densified every 100 iterations,
+        # /root/reference/trainers/train_static.py:129-133; rendered by trainers/fine_all.py:93 and trainers/eval_metric.py:107) -- a few
+        # screen-filling splats among many small, faint ones.  The committed model of bench_data/ (tools/make_trained_scene.py).
+        try:
+            scene, how = trained_scene(dev)
+            out["trained_scene_op_only"] = config_leg(dev, scene["xyz"].shape[0], 540, 960, False, iters=30, scene=scene, what=how)
+            out["trained_scene_op_only"]["reference"] = "/root/reference/trainers/train_static.py:129-133 (densification), trainers/fine_all.py:93, trainers/eval_metric.py:107"
+        except Exception as exc:
+            out["trained_scene_op_only"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world == 1 and args.footprints:
         out["footprints"] = footprint_legs(dev)
     egs_dist.shutdown()

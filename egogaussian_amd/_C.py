@@ -31,9 +31,46 @@ class StepGuard:
     for such a frame.  `running_max` int64[1] -- raised to the instance count of every forward, so one host read tells whether
     ANY replay overflowed and by how much."""
 
-    def __init__(self, device):
+    def __init__(self, device, deferred=False):
         self.overflow = torch.zeros(2, dtype=torch.int32, device=device)      # [0] flag, [1] instance count of the latest frame
         self.running_max = torch.zeros(1, dtype=torch.int64, device=device)
+        # deferred=True (EAGER loops): forwards that carry this guard are enqueued against the capacity hint WITHOUT the host wait for
+        # the instance count (egs_forward_enqueue, as under graph capture); the count and the overflow word of a frame are read from
+        # page-locked memory at the NEXT forward.  A frame that did not fit is then already voided on the device (the backward's
+        # statistics and the Adam step of a FusedAdam(capturable=True) honour the overflow word), `overflows` counts it, and the next
+        # frame runs with room.  Its IMAGE and loss value are clipped: use for training loops, not for evaluation renders.
+        self.deferred = bool(deferred)
+        self.overflows = 0                    # frames of this guard that were clipped (found at the following forward / check())
+        self.frames = 0
+        self.last_R = 0                       # rectangle instances of the last CHECKED frame
+        self._pending = None                  # (page-locked counts, event, P, capacity) of the frame not checked yet
+        self._pinned = [None, None]
+
+    def check(self):
+        """Settle the frame that has not been checked yet (waits for it).  -> True when no frame of this guard has been clipped."""
+        _settle(self)
+        return self.overflows == 0
+
+
+def _settle(guard):
+    """Read the counts the previous deferred forward of `guard` copied out; raise the capacity hint when it did not fit."""
+    pend = guard._pending
+    if pend is None:
+        return
+    pinned, P, cap, key = pend
+    guard._pending = None
+    nb = (P + 255) // 256
+    tail = pinned[nb:nb + 2]
+    if int(tail[0]) == -1:                    # the copy that ends the frame's chain has not landed yet (no sentinel overwritten): wait for
+        torch.cuda.synchronize(key)           # it -- rare: a loop that runs the backward in between finds it long complete
+    R = int(_lib.load().egs_sum_counts(int(P), C.c_void_p(pinned.data_ptr())))
+    clipped, kept = int(tail[0]), int(tail[1]) & 0xffffffff
+    guard.last_R = R
+    if clipped:
+        guard.overflows += 1
+        stats["retries"] += 1
+    if clipped or R > cap:
+        _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(max(R, kept) * 1.25) + 65536)
 
 
 def binning_passes(P, W, H):
@@ -220,7 +257,33 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         place = None if _NO_PLACEMENT else placement_buffer(dev, W, H)
         rot_st, _rot_keep = _object_rotation_struct(object_rotation, dev, P)
         rot_arg = C.byref(rot_st) if rot_st is not None else None
-        if capturing:
+        deferred = guard is not None and getattr(guard, "deferred", False) and not capturing and P != 0
+        if deferred:
+            _settle(guard)                                       # the previous frame of this guard: did it fit?
+            new_cap = _capacity_hint.get(key, 0)
+            if new_cap != cap:                                   # it did not (or nothing is known yet): lay the buffers out again
+                cap = new_cap
+                gb, ib, bb, total_off = _buffer_sizes(L, P, W, H, cap)
+                state = torch.empty((gb + ib + bb,), device=dev, dtype=torch.uint8)
+                geom, img, binning = state[:gb], state[gb:gb + ib], state[gb + ib:]
+            deferred = cap > 0                                   # no capacity known yet: this call establishes it the waiting way
+        if deferred:
+            i = guard.frames & 1
+            pin = guard._pinned[i]
+            if pin is None or pin.numel() < nb + 2:
+                pin = guard._pinned[i] = torch.empty((max(nb + 2, 4096),), dtype=torch.int32, pin_memory=True)
+            pin[nb] = -1                                         # sentinel: overwritten (0 / 1) by the copy that ends the chain
+            _lib.check(L.egs_forward_enqueue(
+                P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier),
+                _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), _ptr(background), W, H,
+                float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
+                _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), C.c_void_p(pin.data_ptr()), _ptr(guard.running_max),
+                _ptr(active_count), _ptr(guard.overflow), _ptr(place), rot_arg, _stream(dev)))
+            guard._pending = (pin, P, cap, key)
+            guard.frames += 1
+            R = C.c_int64(cap)                      # layout size, as under capture; the frame's own count is read at the next call
+            rc = 0
+        elif capturing:
             # hipGraph capture of a whole training step (egogaussian_amd/graph.py): nothing may wait on the host, so the
             # chain is enqueued against the capacity established by earlier eager calls and R is checked after replays.
             if cap <= 0 or P == 0:
@@ -248,10 +311,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                       _ptr(out_depth), _ptr(out_alpha), _stream(dev), int(bool(debug)))
             stats["retries"] += 1
         _lib.check(rc)
-        if P and not capturing:
+        if P and not capturing and not deferred:
             _capacity_hint[key] = max(cap, 0) if R.value else _capacity_hint.get(key, 0)
         stats["capacity"] = cap
-    stats["num_rendered"] = int(R.value)
+    stats["num_rendered"] = int(guard.last_R) if deferred else int(R.value)
     stats["P"] = P
     stats["image_buffer"] = img
     if cap > 0:                                     # device-side instance count of this forward (int64[1] view, for graph replays)

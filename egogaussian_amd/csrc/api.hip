@@ -154,6 +154,10 @@ const char* egs_profile_stage_name(int stage) {
 }
 
 int egs_abi_version(void) { return EGS_ABI_VERSION; }
+#ifndef EGS_SOURCE_HASH
+#define EGS_SOURCE_HASH "unknown"
+#endif
+const char* egs_source_hash(void) { return EGS_SOURCE_HASH; }
 
 int egs_debug_set_tile_culling(int on) { const int old = egs_tile_culling; egs_tile_culling = on ? 1 : 0; return old; }
 int egs_debug_force_ballot_rank(int on) { const int old = egs_force_ballot_rank; egs_force_ballot_rank = on ? 1 : 0; return old; }
@@ -316,6 +320,10 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
         egs_prof_start(EGS_K_RENDER_FWD, s);
         EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, placement ? 1 : 0, s));
         egs_prof_stop(EGS_K_RENDER_FWD, s);
+        // a caller that checks LATER (egs_forward_enqueue outside a graph: the eager loop without a host wait per forward) also gets the
+        // overflow word -- [0] clipped, [1] instances bucketed -- behind the counts, once the chain that writes it has run
+        if (!wait_for_count && pinned_host_counts && overflow_flag)
+            EGS_TRY(hipMemcpyAsync(pinned_host_counts + nb, overflow_flag, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     if (!wait_for_count) { *num_rendered = -1; return 0; }              // graph-capturable: no host wait at all
     EGS_TRY(hipEventSynchronize(ev));

@@ -50,6 +50,7 @@ SINK_MEANS3D, SINK_OPACITY, SINK_SCALES, SINK_ROTATIONS, SINK_SH, SINK_SH_REST =
 # name -> (restype, argtypes); every symbol include/egs_raster.h declares
 SIGNATURES = {
     "egs_abi_version": (C.c_int, []),
+    "egs_source_hash": (C.c_char_p, []),
     "egs_error_string": (C.c_char_p, [C.c_int]),
     "egs_device_info": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     "egs_geom_bytes": (C.c_size_t, [i32]),
@@ -121,18 +122,15 @@ _lib = None
 def kernel_source_hash():
     """sha256 (first 16 hex digits) over the library's sources -- csrc/*.hip, csrc/*.h, include/egs_raster.h, the Makefile -- in
     name order.  Counter files under profiles/ carry the hash they were collected at; bench.py reports their numbers only
-    while it still equals this one (a profile of other kernels describes other kernels)."""
-    import glob
-    import hashlib
-    csrc = os.path.join(_HERE, "csrc")
-    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(csrc, "Makefile")])
-    files.append(os.path.join(os.path.dirname(_HERE), "include", "egs_raster.h"))
-    h = hashlib.sha256()
-    for f in files:
-        h.update(os.path.basename(f).encode())
-        with open(f, "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    while it still equals this one (a profile of other kernels describes other kernels).  The library embeds the same hash at build
+    time: built_source_hash()."""
+    from .srchash import source_hash
+    return source_hash()
+
+
+def built_source_hash():
+    """The source hash `make` embedded into the loaded library (egs_source_hash()): equal to kernel_source_hash() unless the build is stale."""
+    return load().egs_source_hash().decode()
 
 
 def library_path():

@@ -202,6 +202,12 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def _step_capturable(self):
         L = _lib.load()
+        sunk = self._sunk
+        if len(sunk) and all(p.grad is None for group in self.param_groups for p in group["params"]):
+            # every parameter that had work was stepped inside the rasterizer backward (the common eager-fast iteration): nothing to
+            # launch, nothing to look up
+            self._sunk = WeakIdKeyDictionary()
+            return
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
         by_cfg = {}
@@ -245,7 +251,9 @@ class FusedAdam(torch.optim.Optimizer):
             RF = (C.c_int32 * n)(*[t[7] for t in items])
             # the guard's overflow word is written by CAPTURED forwards only (egs_forward_enqueue); an eager step() follows an eager
             # render, which is never clipped, and must not be voided by what the last replay left in that word
-            skip = None if (self.guard is None or not torch.cuda.is_current_stream_capturing()) else C.c_void_p(self.guard.overflow.data_ptr())
+            # (... unless the eager render itself ran without the host wait: a StepGuard(deferred=True) frame can be clipped)
+            honour = self.guard is not None and (torch.cuda.is_current_stream_capturing() or getattr(self.guard, "deferred", False))
+            skip = C.c_void_p(self.guard.overflow.data_ptr()) if honour else None
             rows = None if self.active_rows is None else C.c_void_p(self.active_rows[0].data_ptr())
             with _hip.device_ctx(dev):                               # the kernel itself advances the counters and writes st["step"]
                 _lib.check(L.egs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), NN, arr(4), arr(5), arr(6), float(betas[0]),

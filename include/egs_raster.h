@@ -64,6 +64,7 @@ extern "C" {
 #define EGS_RETRY_LARGER   (-100)   /* egs_forward only: capacity guess too small, nothing rendered; *num_rendered holds R */
 
 int         egs_abi_version(void);
+const char* egs_source_hash(void);      /* hash of the sources this library was built from (csrc/Makefile); "unknown" if built by hand */
 const char* egs_error_string(int code);
 /* Name of the device the current HIP context runs on and its gcnArchName; returns 0 or an error. */
 int         egs_device_info(char* name, int name_len, char* arch, int arch_len, int* compute_units);
@@ -208,7 +209,10 @@ size_t egs_placement_bytes(int width, int height);
 /* ---- the same chain with NO host wait, for hipGraph capture of a whole training step: everything is only enqueued
  *      (capacity must be > 0).  A frame that needs more than `capacity` instances is invalid (its kernels were clipped to
  *      the capacity) and must be redone with a larger buffer; the caller finds out after synchronising, from either of
- *        pinned_host_counts   optional (NULL: no copy): the per-workgroup rectangle counts, R = egs_sum_counts(P, ..)
+ *        pinned_host_counts   optional (NULL: no copy): the per-workgroup rectangle counts, R = egs_sum_counts(P, ..); when
+ *                             `overflow_flag` is given as well the buffer holds ceil(P/256) + 2 words and the two overflow words
+ *                             ([0] this frame was clipped, [1] instances bucketed) are copied behind the counts at the end of the
+ *                             chain -- what an EAGER loop needs to check the frame at its next call instead of waiting now
  *        running_max          optional device uint64: raised by the chain to the number of instances it bucketed whenever
  *                             that is larger, so one word tells whether ANY replay so far overflowed. */
 int egs_forward_enqueue(

@@ -278,6 +278,44 @@ def test_capacity_guess_paths_agree():
     assert _C._capacity_hint[key] >= outs[0][0]
 
 
+def test_deferred_count_check_agrees_and_finds_a_clipped_frame():
+    """The eager forward WITHOUT the host wait for the instance count (a StepGuard(deferred=True): enqueued against the capacity hint,
+    checked at the next forward): with room its outputs are those of the synchronous path bit for bit; with too little room the
+    frame is clipped, which the following call finds -- the overflow is counted, the hint is raised, and that call's outputs are
+    the synchronous path's again.  /root/reference/trainers/train_static.py:67-138 is the loop this serves."""
+    from egogaussian_amd import _C
+    dev = _dev()
+    d = make_inputs(4000, 96, 128, 8, 0, "sh_cov", scale_mul=3.0)
+    key = torch.cuda.current_device()
+    _C._capacity_hint[key] = 0
+    g, ref = hip_forward(d, dev)                                   # synchronous: establishes the capacity
+    R = ref[0]
+    bv = _C.binning_views(ref[6], 4000, R, 128, 96, _C.stats["capacity"])
+    ref_list = bv["point_list"].clone()
+
+    def deferred_forward(guard):
+        gg = _to(d, dev)
+        e = torch.empty(0, device=dev)
+        return _C.rasterize_gaussians(gg["bg"], gg["means3D"], e, gg["opacities"], e, e, 1.0, gg["cov3D_precomp"], gg["viewmatrix"],
+                                      gg["projmatrix"], gg["tanfovx"], gg["tanfovy"], 96, 128, gg["shs"], 0, gg["campos"], False, False, guard=guard)
+    guard = _C.StepGuard(dev, deferred=True)
+    out = deferred_forward(guard)
+    assert out[0] == _C.stats["capacity"] >= R                     # the layout size, as under graph capture
+    assert all(torch.equal(a, b) for a, b in zip(out[1:5], ref[1:5]))
+    assert torch.equal(_C.binning_views(out[6], 4000, R, 128, 96, _C.stats["capacity"])["point_list"], ref_list)
+    assert guard.check() and guard.last_R == R and guard.frames == 1 and int(guard.overflow[0].item()) == 0
+    # too little room: the frame is clipped (and would be voided: the overflow word is set), the NEXT call knows
+    _C._capacity_hint[key] = 1000
+    guard2 = _C.StepGuard(dev, deferred=True)
+    deferred_forward(guard2)
+    torch.cuda.synchronize()
+    assert int(guard2.overflow[0].item()) == 1 and guard2.overflows == 0        # clipped on the device, not yet seen by the host
+    out = deferred_forward(guard2)
+    assert guard2.overflows == 1 and _C.stats["capacity"] >= R and _C._capacity_hint[key] >= R
+    assert all(torch.equal(a, b) for a, b in zip(out[1:5], ref[1:5]))
+    assert guard2.check() is False and guard2.last_R == R and int(guard2.overflow[0].item()) == 0
+
+
 def test_depth_ties_keep_index_order():
     """All Gaussians at the same depth: every tile list must come out in Gaussian-index order (oracle: stable sort)."""
     from egogaussian_amd import _C
