@@ -49,7 +49,7 @@ ImgLayout img_layout(int W, int H) {
     L.o.final_T = off;   off = egs_align(off + px * sizeof(float));
     L.o.n_contrib = off; off = egs_align(off + px * sizeof(uint32_t));
     L.o.quad_work = off; off = egs_align(off + gx * gy * 4 * sizeof(uint32_t));
-    L.o.tile_order = off; off = egs_align(off + ((gx * gy + 7) / 8) * 8 * sizeof(uint32_t));
+    L.o.tile_order = off; off = egs_align(off + (size_t)egs_blocks_for_tiles((int)(gx * gy)) * sizeof(uint32_t));       // EGS_XCDS bands of egs_tiles_per_xcd() slots
     L.o.quad_pairs = off; off = egs_align(off + gx * gy * 8 * sizeof(uint32_t));                 // pairs [tiles][4], then visits [tiles][4]
     L.bytes = off; return L;
 }
@@ -198,7 +198,11 @@ int egs_get_binning_layout(int P, int64_t R, int width, int height, egs_binning_
 size_t egs_placement_bytes(int width, int height) {
     if (width <= 0 || height <= 0) return 0;
     const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
-    return egs_align((nt * 4 + ((nt + 7) / 8) * 8) * sizeof(uint32_t));
+    return egs_align((nt * 4 + (size_t)egs_blocks_for_tiles((int)nt)) * sizeof(uint32_t));
+}
+int egs_order_words(int width, int height) {
+    if (width <= 0 || height <= 0) return 0;
+    return egs_blocks_for_tiles(((width + EGS_TILE - 1) / EGS_TILE) * ((height + EGS_TILE - 1) / EGS_TILE));
 }
 static void placement_ptrs(void* placement, int width, int height, EgsImgPtrs& im) {
     const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);

@@ -53,11 +53,11 @@ template <int NT>
 __device__ __forceinline__ void egs_order_band(const EgsPrologueArgs& a, const int x, EgsOrderLds& L) {
     const uint32_t* __restrict__ quad_work = a.quad_work; uint32_t* __restrict__ tile_order = a.tile_order;
     const int n_tiles = a.n_tiles, tid = (int)threadIdx.x;
-    const int per = egs_tiles_per_xcd(n_tiles);
-    const int t0 = x * per, n = max(0, min(per, n_tiles - t0));
+    const int per = egs_tiles_per_xcd(n_tiles);                      // slots of a band; its tiles: egs_band_tile(x, i), i < n
+    const int n = egs_band_count(x, n_tiles);
     const int slots = ((per + 31) / 32) * 32;
     if (per > ORDER_MAX_BAND) {                                      // very large images: keep index order
-        for (int sl = tid; sl < per; sl += NT) tile_order[8 * sl + x] = sl < n ? (uint32_t)(t0 + sl) : 0xffffffffu;
+        for (int sl = tid; sl < per; sl += NT) tile_order[8 * sl + x] = sl < n ? (uint32_t)egs_band_tile(x, sl, n_tiles) : 0xffffffffu;
         return;
     }
     const bool small = per <= ORDER_BALANCE_MAX;
@@ -66,7 +66,7 @@ __device__ __forceinline__ void egs_order_band(const EgsPrologueArgs& a, const i
     __syncthreads();
     uint32_t mx = 0;
     for (int i = tid; i < n; i += NT) {
-        const uint4 w4 = *reinterpret_cast<const uint4*>(quad_work + 4 * (size_t)(t0 + i));
+        const uint4 w4 = *reinterpret_cast<const uint4*>(quad_work + 4 * (size_t)egs_band_tile(x, i, n_tiles));
         mx = max(mx, w4.x + w4.y + w4.z + w4.w);
         if (small) L.quad_cost[i] = w4;
     }
@@ -79,7 +79,7 @@ __device__ __forceinline__ void egs_order_band(const EgsPrologueArgs& a, const i
     const float to_level = (float)(ORDER_LEVELS - 1) / (float)L.wmax;
     // level of tile i, 0 = most expensive (evaluated twice per tile, from the same words: the band's costs stay in L2 / LDS)
     auto level_of = [&](int i) -> uint32_t {
-        const uint4 w4 = small ? L.quad_cost[i] : *reinterpret_cast<const uint4*>(quad_work + 4 * (size_t)(t0 + i));
+        const uint4 w4 = small ? L.quad_cost[i] : *reinterpret_cast<const uint4*>(quad_work + 4 * (size_t)egs_band_tile(x, i, n_tiles));
         return (uint32_t)(ORDER_LEVELS - 1) - min((uint32_t)((float)(w4.x + w4.y + w4.z + w4.w) * to_level), (uint32_t)(ORDER_LEVELS - 1));
     };
     for (int i = tid; i < n; i += NT) atomicAdd(&L.level_fill[level_of(i)], 1u);
@@ -108,7 +108,7 @@ __device__ __forceinline__ void egs_order_band(const EgsPrologueArgs& a, const i
         int slot = round * 32 + ((round & 1) ? 31 - pos : pos);
         if (slot >= per) slot = round * 32 + pos;                    // last, partial round: no room to mirror
         if (slot >= per) slot = per - 1 - (slots - 1 - slot);        // (cannot happen when per is a multiple of 32)
-        tile_order[8 * slot + x] = (uint32_t)(t0 + i);
+        tile_order[8 * slot + x] = (uint32_t)egs_band_tile(x, i, n_tiles);
     }
     if (!small) return;
     // Small band (every workgroup of the launch resident at once: the workgroup in slot 32 k + c of the band runs on CU c).  With the
@@ -157,7 +157,7 @@ __device__ __forceinline__ void egs_order_band(const EgsPrologueArgs& a, const i
                 ls0 += sd[r] == 0u ? cd[r] : 0u; ls1 += sd[r] == 1u ? cd[r] : 0u; ls2 += sd[r] == 2u ? cd[r] : 0u; ls3 += sd[r] == 3u ? cd[r] : 0u;
             }
             load_cu += w4.x + w4.y + w4.z + w4.w;
-            word = (uint32_t)(t0 + i) | (perm << 16) | EGS_ORDER_HAS_PERM;
+            word = (uint32_t)egs_band_tile(x, i, n_tiles) | (perm << 16) | EGS_ORDER_HAS_PERM;
         }
         if (has_slot) tile_order[8 * (32 * k + c) + x] = word;
     }

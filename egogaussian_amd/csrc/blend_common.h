@@ -3,14 +3,31 @@
 #include "egs_common.h"
 
 // Tiles are handed to workgroups so that each XCD (workgroup b runs on XCD b % 8 on MI355X -- used for
-// L2 affinity only, never for correctness) owns one contiguous band of tile rows: neighbouring tiles
-// share most of their splats, so a band keeps its splat records in that XCD's private 4 MiB L2.
+// L2 affinity only, never for correctness) owns contiguous runs of tile rows: neighbouring tiles
+// share most of their splats, so a run keeps its splat records in that XCD's private 4 MiB L2.
+// EGS_BAND_SEGMENTS runs per XCD: the image is cut into 8 x EGS_BAND_SEGMENTS segments of consecutive tiles and segment g belongs
+// to XCD g % 8 -- one segment each (= one band) keeps the most records private, several spread a scene whose cost varies down the
+// image over the XCDs (a launch ends with its busiest XCD: profiles/r4_trained_scene.md).  Band-local index i of XCD x <-> tile:
 #define EGS_XCDS 8
-__host__ __device__ __forceinline__ int egs_tiles_per_xcd(int n_tiles) { return (n_tiles + EGS_XCDS - 1) / EGS_XCDS; }
+#ifndef EGS_BAND_SEGMENTS
+#define EGS_BAND_SEGMENTS 4
+#endif
+__host__ __device__ __forceinline__ int egs_band_seg(int n_tiles) { return (n_tiles + EGS_XCDS * EGS_BAND_SEGMENTS - 1) / (EGS_XCDS * EGS_BAND_SEGMENTS); }
+__host__ __device__ __forceinline__ int egs_tiles_per_xcd(int n_tiles) { return egs_band_seg(n_tiles) * EGS_BAND_SEGMENTS; }      // slots of a band
 __host__ __forceinline__ int egs_blocks_for_tiles(int n_tiles) { return egs_tiles_per_xcd(n_tiles) * EGS_XCDS; }
+__host__ __device__ __forceinline__ int egs_band_tile(int x, int i, int n_tiles) {     // -1 beyond the band's last tile (valid i form a prefix)
+    const int seg = egs_band_seg(n_tiles), sg = i / seg;
+    const int t = (sg * EGS_XCDS + x) * seg + (i - sg * seg);
+    return (sg < EGS_BAND_SEGMENTS && t < n_tiles) ? t : -1;
+}
+__host__ __device__ __forceinline__ int egs_band_count(int x, int n_tiles) {          // tiles of band x
+    const int seg = egs_band_seg(n_tiles);
+    int n = 0;
+    for (int sg = 0; sg < EGS_BAND_SEGMENTS; sg++) n += max(0, min(seg, n_tiles - (sg * EGS_XCDS + x) * seg));
+    return n;
+}
 __device__ __forceinline__ int egs_tile_of_block(unsigned b, int n_tiles) {
-    const int t = (int)(b % EGS_XCDS) * egs_tiles_per_xcd(n_tiles) + (int)(b / EGS_XCDS);
-    return (b / EGS_XCDS) < (unsigned)egs_tiles_per_xcd(n_tiles) && t < n_tiles ? t : -1;
+    return (b / EGS_XCDS) < (unsigned)egs_tiles_per_xcd(n_tiles) ? egs_band_tile((int)(b % EGS_XCDS), (int)(b / EGS_XCDS), n_tiles) : -1;
 }
 
 __device__ __forceinline__ void egs_load_rec(const float4* __restrict__ rec, uint32_t id, bool ok, float4& a,

@@ -34,9 +34,10 @@
 // Such a Gaussian therefore gets EGS_HOT_REPLICAS accumulator lines, the wave picks one by its tile, and k_preprocess_backward adds
 // them up.  Which lines: k_preprocess ranks the hot Gaussians of its 256-Gaussian workgroup (no global counter) and leaves
 // code = rank + 1 (1 .. EGS_HOT_PER_BLOCK; 0 = not hot, also for those beyond the workgroup's budget) in the record's spare bits;
-// the lines of Gaussian i with code c are hot_acc[((i / 256) * EGS_HOT_PER_BLOCK + c - 1) * EGS_HOT_REPLICAS + r], r = tile % EGS_HOT_REPLICAS,
-// EGS_HOT_LINE floats apart, right behind the P regular lines in the backward's scratch.  Sums only move between lines: every
-// gradient is the same sum of the same terms.
+// the lines of Gaussian i with code c are hot_acc[r * slots + (i / 256) * EGS_HOT_PER_BLOCK + c - 1] (lines of EGS_HOT_LINE floats, slots =
+// ceil(P / 256) * EGS_HOT_PER_BLOCK), r = the XCD the blending workgroup runs on, right behind the P regular lines in the backward's
+// scratch.  Replica-major: a Gaussian's replicas lie hundreds of KB apart, i.e. in different memory channels -- side by side they
+// relieved the line but not the channel that serves it.  Sums only move between lines: every gradient is the same sum of the same terms.
 #define EGS_HOT_MIN_TILES 256u
 #define EGS_HOT_PER_BLOCK 7u
 #define EGS_HOT_REPLICAS 8u
@@ -48,7 +49,8 @@ __host__ __device__ __forceinline__ uint32_t egs_hot_code(uint32_t bbx, uint32_t
 __host__ __device__ __forceinline__ void egs_hot_code_set(uint32_t& bbx, uint32_t& bby, uint32_t code) {
     bbx |= ((code & 1u) << 15) | ((code & 2u) << 30); bby |= (code & 4u) << 13;
 }
-static inline size_t egs_hot_floats(size_t P) { return ((P + 255) / 256) * EGS_HOT_PER_BLOCK * EGS_HOT_REPLICAS * EGS_HOT_LINE; }
+__host__ __device__ static inline size_t egs_hot_slots(size_t P) { return ((P + 255) / 256) * EGS_HOT_PER_BLOCK; }
+static inline size_t egs_hot_floats(size_t P) { return egs_hot_slots(P) * EGS_HOT_REPLICAS * EGS_HOT_LINE; }
 static inline size_t egs_acc_floats(size_t P) { return P * EGS_GRAD_STRIDE + egs_hot_floats(P); }    // regular lines, then the hot replicas
 
 struct EgsGeomPtrs {

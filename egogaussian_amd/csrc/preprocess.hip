@@ -298,7 +298,7 @@ __device__ __forceinline__ void pp_bwd_one(
     const float* __restrict__ scales, float mod, const float* __restrict__ rots, const float* __restrict__ cov3D_in, int act,
     const float* __restrict__ V, const float* __restrict__ PM, const float* __restrict__ campos, int W, int H,
     float tanfovx, float tanfovy, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
-    const float4* __restrict__ rec, const float* __restrict__ grad_acc, const float* __restrict__ hot_acc, float* __restrict__ dmeans2D, float* __restrict__ dcolors,
+    const float4* __restrict__ rec, const float* __restrict__ grad_acc, const float* __restrict__ hot_acc, const size_t hot_slots, float* __restrict__ dmeans2D, float* __restrict__ dcolors,
     float* __restrict__ dopac, float* __restrict__ dmeans3D, float* __restrict__ dcov3D, float* __restrict__ dsh,
     float* __restrict__ dscales, float* __restrict__ drots,
     float* __restrict__ stat_grad_accum, float* __restrict__ stat_denom, float* __restrict__ stat_max_radii,
@@ -325,9 +325,9 @@ __device__ __forceinline__ void pp_bwd_one(
         const float4 r0 = r[0], r1 = r[1];
         const uint32_t code = egs_hot_code(__float_as_uint(r[2].z), __float_as_uint(r[2].w));
         if (code) {   // a hot Gaussian: the blend spread its sums over EGS_HOT_REPLICAS lines behind the regular ones (egs_common.h)
-            const float* hl = hot_acc + (((size_t)(i >> 8) * EGS_HOT_PER_BLOCK + (code - 1u)) * EGS_HOT_REPLICAS) * EGS_HOT_LINE;
+            const float* hl = hot_acc + ((size_t)(i >> 8) * EGS_HOT_PER_BLOCK + (code - 1u)) * EGS_HOT_LINE;
             for (unsigned rp = 0; rp < EGS_HOT_REPLICAS; rp++) {
-                const float4* ga = reinterpret_cast<const float4*>(hl + rp * EGS_HOT_LINE);
+                const float4* ga = reinterpret_cast<const float4*>(hl + (size_t)rp * hot_slots * EGS_HOT_LINE);
 #pragma unroll
                 for (int k = 0; k < 3; k++) { const float4 v = ga[k]; acc[4 * k] += v.x; acc[4 * k + 1] += v.y; acc[4 * k + 2] += v.z; acc[4 * k + 3] += v.w; }
             }
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(
     }
     if (i < P)
         pp_bwd_one<SINK>(i, D, M, means3D, shs, scales, mod, rots, cov3D_in, act, V, PM, campos, W, H, tanfovx, tanfovy, radii, clamped, rec,
-                         grad_acc, grad_acc + (size_t)P * EGS_GRAD_STRIDE, dmeans2D, dcolors, dopac, dmeans3D, dcov3D, dsh, dscales, drots, stat_grad_accum, stat_denom,
+                         grad_acc, grad_acc + (size_t)P * EGS_GRAD_STRIDE, egs_hot_slots((size_t)P), dmeans2D, dcolors, dopac, dmeans3D, dcov3D, dsh, dscales, drots, stat_grad_accum, stat_denom,
                          stat_max_radii, skip_flag, stage, fused, rot);
     if (!SINK) return;
     __syncthreads();

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ tile_order, float* __restrict__ grad_acc,
-    const uint32_t* __restrict__ quad_visits, const uint32_t hot_base /* first float of the hot replica lines inside grad_acc */) {
+    const uint32_t* __restrict__ quad_visits, const uint32_t hot_base /* first float of the hot replica lines inside grad_acc */,
+    const uint32_t hot_slots /* lines per replica = ceil(P / 256) * EGS_HOT_PER_BLOCK */) {
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
     __shared__ __attribute__((aligned(16))) float red[4][5 * 64];
     __shared__ uint32_t quad_claimed;
@@ -225,7 +226,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             uint32_t line = gid * (uint32_t)EGS_GRAD_STRIDE;            // first float of the accumulator line (48 P < 2^32 bytes: P < 89 M)
             if ((hot_mask >> j) & 1ull) {                               // (wave-uniform, rare)
                 const uint32_t code = (uint32_t)__builtin_amdgcn_readlane((int)my_code, j);
-                line = hot_base + ((((gid >> 8) * EGS_HOT_PER_BLOCK + code - 1u) * EGS_HOT_REPLICAS) + ((uint32_t)tile % EGS_HOT_REPLICAS)) * EGS_HOT_LINE;
+                // replica = the XCD this workgroup runs on (b % 8); the replicas of a Gaussian lie hot_slots lines apart (egs_common.h)
+                line = hot_base + ((blockIdx.x % EGS_HOT_REPLICAS) * hot_slots + (gid >> 8) * EGS_HOT_PER_BLOCK + code - 1u) * EGS_HOT_LINE;
             }
             if (slot >= 0) EGS_BWD_ACCUM(grad_acc + (line + (uint32_t)slot), out);
         }
@@ -261,10 +263,10 @@ hipError_t egs_launch_render_backward(int P, int W, int H, const float* bg, EgsG
     if (dL_ddepth || dL_dalpha)
         hipLaunchKernelGGL(k_render_backward<true>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                            im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
-                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles, (uint32_t)((size_t)P * EGS_GRAD_STRIDE));
+                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles, (uint32_t)((size_t)P * EGS_GRAD_STRIDE), (uint32_t)egs_hot_slots((size_t)P));
     else
         hipLaunchKernelGGL(k_render_backward<false>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
                            im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
-                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles, (uint32_t)((size_t)P * EGS_GRAD_STRIDE));
+                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles, (uint32_t)((size_t)P * EGS_GRAD_STRIDE), (uint32_t)egs_hot_slots((size_t)P));
     return hipGetLastError();
 }

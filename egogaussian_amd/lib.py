@@ -57,6 +57,7 @@ SIGNATURES = {
     "egs_binning_bytes": (C.c_size_t, [i32, i64, i32, i32]),
     "egs_image_bytes": (C.c_size_t, [i32, i32]),
     "egs_backward_scratch_bytes": (C.c_size_t, [i32]),
+    "egs_order_words": (C.c_int, [i32, i32]),
     "egs_get_geom_layout": (C.c_int, [i32, C.POINTER(GeomLayout)]),
     "egs_get_binning_layout": (C.c_int, [i32, i64, i32, i32, C.POINTER(BinningLayout)]),
     "egs_get_image_layout": (C.c_int, [i32, i32, C.POINTER(ImageLayout)]),

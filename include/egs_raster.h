@@ -74,6 +74,9 @@ size_t egs_geom_bytes(int P);
 size_t egs_binning_bytes(int P, int64_t R, int width, int height);
 size_t egs_image_bytes(int width, int height);
 size_t egs_backward_scratch_bytes(int P);
+/* words of a tile-order array (image layout `tile_order`; second part of the placement buffer, behind 4 words per tile): one per
+ * workgroup of a blend launch -- 8 XCD bands of equal slot counts, 0xffffffff = padding workgroup */
+int    egs_order_words(int width, int height);
 
 /* ---- buffer layouts, for tests and tools: byte offsets of the named sub-arrays ----------------- */
 typedef struct egs_geom_layout {

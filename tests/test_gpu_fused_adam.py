@@ -306,7 +306,7 @@ def test_loss_backward_carrying_the_raster_prologue(H, W):
         grads.append({a: getattr(pc, a).grad.clone() for a in LEAVES} | {"image": out["render"].grad.clone(), "screen": out["viewspace_points"].grad.clone()})
         nt = ((W + 15) // 16) * ((H + 15) // 16)
         lay = _C._lib.ImageLayout(); _C._lib.load().egs_get_image_layout(W, H, __import__("ctypes").byref(lay))
-        words = img_buf[lay.tile_order:lay.tile_order + 4 * 8 * ((nt + 7) // 8)].view(torch.int32).cpu().numpy().astype("uint32")
+        words = img_buf[lay.tile_order:lay.tile_order + 4 * _C._lib.load().egs_order_words(W, H)].view(torch.int32).cpu().numpy().astype("uint32")
         tiles = [int(w & 0xffff) if (w & 0x01000000) else int(w) for w in words if w != 0xffffffff]
         orders.append(sorted(tiles))
     assert orders[0] == orders[1] == list(range(nt))
@@ -353,7 +353,7 @@ def test_forward_placement_buffer_never_changes_results(H, W):
             out = render(cams[2], pc, Pipe, bg)
         torch.cuda.synchronize()
         outs.append((out["render"].clone(), out["depth"].clone(), out["alpha"].clone()))
-        order = words[nt * 4:nt * 4 + 8 * ((nt + 7) // 8)].cpu().numpy().astype("uint32")
+        order = words[nt * 4:nt * 4 + lib.load().egs_order_words(W, H)].cpu().numpy().astype("uint32")
         tiles = sorted(int(w & 0xffff) if (w & 0x01000000) else int(w) for w in order if w != 0xffffffff)
         assert tiles == list(range(nt)), fill
         cost = words[:nt * 4].cpu().numpy()
