@@ -20,7 +20,7 @@ GeomLayout geom_layout(int P) {
     L.o.offsets = off;      off = egs_align(off + n * sizeof(uint32_t));
     L.o.clamped = off;      off = egs_align(off + n);
     L.o.visible = off;      off = egs_align(off + n);
-    L.o.scan_scratch = off; off = egs_align(off + ((n + 255) / 256 + 64) * sizeof(uint32_t));     // per-block instance counts
+    L.o.scan_scratch = off; off = egs_align(off + (2 * ((n + 255) / 256) + 64) * sizeof(uint32_t)); // per-block instance counts, 64 spare words, per-block hot counts
     L.o.total = off;        off = egs_align(off + sizeof(uint64_t));
     L.bytes = off; return L;
 }
@@ -57,7 +57,9 @@ EgsGeomPtrs geom_ptrs(void* buf, int P) {
     const GeomLayout L = geom_layout(P); char* b = (char*)buf; EgsGeomPtrs g;
     g.rec = (float4*)(b + L.o.rec); g.rect = (uint2*)(b + L.o.rect); g.offsets = (uint32_t*)(b + L.o.offsets);
     g.clamped = (uint8_t*)(b + L.o.clamped); g.visible = (uint8_t*)(b + L.o.visible); g.scan_scratch = (uint32_t*)(b + L.o.scan_scratch);
-    g.total = (uint64_t*)(b + L.o.total); return g;
+    g.total = (uint64_t*)(b + L.o.total);
+    g.block_hot = g.scan_scratch + ((size_t)(P > 0 ? P : 0) + 255) / 256 + 64;
+    return g;
 }
 EgsBinPtrs bin_ptrs(void* buf, int P, int64_t R, int W, int H) {
     const BinLayout L = bin_layout(P, R, W, H); char* b = (char*)buf; EgsBinPtrs p;
@@ -484,7 +486,7 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
     }
     if (R > 0) {
         const uint32_t* point_list = b.point_list;
-        if (!prologue_done) EGS_TRY(egs_launch_backward_prologue(width, height, im, grad_acc, egs_acc_floats((size_t)P), sink ? &tick : nullptr, s));
+        if (!prologue_done) EGS_TRY(egs_launch_backward_prologue(P, width, height, im, grad_acc, g.block_hot, sink ? &tick : nullptr, s));
         egs_prof_start(EGS_K_RENDER_BWD, s);                         // (the stage is the blend kernel alone)
         EGS_TRY(egs_launch_render_backward(P, width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth, dL_dout_alpha, grad_acc, s));
         egs_prof_stop(EGS_K_RENDER_BWD, s);
@@ -549,7 +551,10 @@ int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* im
     EgsImgPtrs im = img_ptrs(side->image_buffer, side->width, side->height);
     EgsPrologueArgs pa = {};
     pa.n_tiles = ((side->width + EGS_TILE - 1) / EGS_TILE) * ((side->height + EGS_TILE - 1) / EGS_TILE);
-    pa.quad_work = im.quad_work; pa.tile_order = im.tile_order; pa.acc4 = (float4*)side->scratch; pa.n4 = egs_acc_floats((size_t)side->P) / 4;
+    pa.quad_work = im.quad_work; pa.tile_order = im.tile_order;
+    if (side->geom_buffer && misaligned(side->geom_buffer)) return EGS_ERR_ARG;
+    egs_prologue_acc(pa, (float*)side->scratch, (size_t)side->P,
+                     side->geom_buffer ? geom_ptrs(const_cast<void*>(side->geom_buffer), side->P).block_hot : nullptr);
     if (side->sink) {
         if (!side->sink->coef) return EGS_ERR_ARG;
         EgsSink ks = {};

@@ -29,7 +29,16 @@
 
 struct EgsPrologueArgs {
     int n_tiles; const uint32_t* quad_work; uint32_t* tile_order; float4* acc4; size_t n4; int has_tick; EgsAdamTick tick;
+    // hot replica lines (egs_common.h): n4 covers the regular lines AND the replicas when block_hot == NULL; else the regular lines only
+    // and of the replicas those in use are cleared: block_hot[b] lines of each of the EGS_HOT_REPLICAS copies of workgroup b's budget
+    const uint32_t* block_hot; uint32_t hot_blocks, hot_slots; float* hot_base;
 };
+// Fills the accumulator part of the arguments for a model of P Gaussians whose backward scratch starts at `scratch`.
+static inline void egs_prologue_acc(EgsPrologueArgs& a, float* scratch, size_t P, const uint32_t* block_hot) {
+    a.acc4 = (float4*)scratch; a.block_hot = block_hot;
+    a.n4 = (block_hot ? P * EGS_GRAD_STRIDE : egs_acc_floats(P)) / 4;
+    a.hot_blocks = (uint32_t)((P + 255) / 256); a.hot_slots = (uint32_t)egs_hot_slots(P); a.hot_base = scratch + P * EGS_GRAD_STRIDE;
+}
 struct EgsOrderLds {                        // 12.6 KiB
     uint32_t level_base[ORDER_LEVELS], level_fill[ORDER_LEVELS], wsum[16], wmax;
     uint4 quad_cost[ORDER_BALANCE_MAX];     // the four quadrant costs of every tile of a small band
@@ -171,6 +180,16 @@ __device__ __forceinline__ void egs_prologue_job(const EgsPrologueArgs& a, const
     if (job < first) { if (threadIdx.x < 64) egs_adam_tick(a.tick, threadIdx.x); return; }
     const size_t stride = (size_t)(n_jobs - first) * NT;
     for (size_t i = (size_t)(job - first) * NT + threadIdx.x; i < a.n4; i += stride) a.acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.block_hot) {   // one thread per (workgroup of k_preprocess, replica): a few hundred hot Gaussians per frame, mostly nothing to do
+        const size_t pairs = (size_t)a.hot_blocks * EGS_HOT_REPLICAS;
+        for (size_t i = (size_t)(job - first) * NT + threadIdx.x; i < pairs; i += stride) {
+            const uint32_t b = (uint32_t)(i / EGS_HOT_REPLICAS), r = (uint32_t)(i % EGS_HOT_REPLICAS);
+            const uint32_t cnt = min(a.block_hot[b], EGS_HOT_PER_BLOCK);
+            float4* line = reinterpret_cast<float4*>(a.hot_base + ((size_t)r * a.hot_slots + (size_t)b * EGS_HOT_PER_BLOCK) * EGS_HOT_LINE);
+            for (uint32_t k = 0; k < cnt; k++)
+                for (uint32_t q = 0; q < EGS_GRAD_STRIDE / 4; q++) line[k * (EGS_HOT_LINE / 4) + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
 }
 
 // loss.hip: the image loss's backward, optionally carrying the jobs above (side != NULL)

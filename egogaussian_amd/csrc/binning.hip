@@ -897,8 +897,13 @@ hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int 
 
 // The count table has one column per bucketing workgroup and one row per tile; its scan and the strided column accesses grow
 // with (tiles x workgroups), which at 2M Gaussians @ 3840x2160 (32 400 tiles) made the bucketing 2.3 ms with 1024 Gaussians per
-// workgroup.  The workgroup count is therefore capped near 512 (two per CU): gpb = 1024 x ceil(P / (1024 x 512)).
-int egs_bin_gpb(int P) { const int k = (P + EGS_BIN_GPB * 512 - 1) / (EGS_BIN_GPB * 512); return EGS_BIN_GPB * (k > 1 ? k : 1); }
+// workgroup.  The workgroup count is therefore kept near 512 (two per CU) whatever P is: gpb = 64 x ceil(P / (64 x 512)) -- whole
+// 64-Gaussian groups; 1024 at 500k Gaussians, 256 at 100k (98 workgroups of 1024 Gaussians left most CUs idle while each walked
+// four times the slots: BASELINE config 2's bucketing 28.9 us), 512 on the 253k-Gaussian trained scene.
+#ifndef EGS_BIN_TARGET_BLOCKS
+#define EGS_BIN_TARGET_BLOCKS 512
+#endif
+int egs_bin_gpb(int P) { const int k = (P + 64 * EGS_BIN_TARGET_BLOCKS - 1) / (64 * EGS_BIN_TARGET_BLOCKS); return 64 * (k > 1 ? k : 1); }
 uint32_t egs_bin_blocks(int P) { const int g = egs_bin_gpb(P); return (uint32_t)((P + g - 1) / g); }
 
 hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,

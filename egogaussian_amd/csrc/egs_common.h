@@ -33,7 +33,8 @@
 // on a trained scene (a few hundred screen-filling splats) that was 52 of the backward blend's 217 us (profiles/r4_trained_scene.md).
 // Such a Gaussian therefore gets EGS_HOT_REPLICAS accumulator lines, the wave picks one by its tile, and k_preprocess_backward adds
 // them up.  Which lines: k_preprocess ranks the hot Gaussians of its 256-Gaussian workgroup (no global counter) and leaves
-// code = rank + 1 (1 .. EGS_HOT_PER_BLOCK; 0 = not hot, also for those beyond the workgroup's budget) in the record's spare bits;
+// code = rank + 1 (1 .. EGS_HOT_PER_BLOCK; 0 = not hot, also for those beyond the workgroup's budget) in the record's spare bits
+// (and in bits 3-5 of the Gaussian's `clamped` byte, where k_preprocess_backward finds it without another load);
 // the lines of Gaussian i with code c are hot_acc[r * slots + (i / 256) * EGS_HOT_PER_BLOCK + c - 1] (lines of EGS_HOT_LINE floats, slots =
 // ceil(P / 256) * EGS_HOT_PER_BLOCK), r = the XCD the blending workgroup runs on, right behind the P regular lines in the backward's
 // scratch.  Replica-major: a Gaussian's replicas lie hundreds of KB apart, i.e. in different memory channels -- side by side they
@@ -55,7 +56,9 @@ static inline size_t egs_acc_floats(size_t P) { return P * EGS_GRAD_STRIDE + egs
 
 struct EgsGeomPtrs {
     float4* rec; uint2* rect; uint32_t* offsets; uint8_t* clamped; uint8_t* visible; uint32_t* scan_scratch; uint64_t* total;
+    uint32_t* block_hot;    // [ceil(P / 256)] hot Gaussians of every 256-Gaussian workgroup of k_preprocess (<= EGS_HOT_PER_BLOCK): which replica lines are in use
 };
+#define EGS_CLAMP_MASK 7u           // `clamped` byte: bits 0-2 colour channel clamped at zero, bits 3-5 the HOT code (below)
 struct EgsBinPtrs {
     uint64_t* pairs;        // [R] (depth<<32 | index), bucketed by tile
     uint64_t* scratch;      // [R] ping-pong space for oversize buckets
@@ -77,7 +80,7 @@ static inline size_t egs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 #ifdef EGS_BIN_GPB_OVERRIDE
 #define EGS_BIN_GPB EGS_BIN_GPB_OVERRIDE
 #else
-#define EGS_BIN_GPB 1024                                       // Gaussians per bucketing workgroup (minimum; see egs_bin_gpb)
+#define EGS_BIN_GPB 1024                                       // Gaussians per bucketing workgroup at config C (see egs_bin_gpb: sized by P)
 #endif
 #ifdef EGS_BIN_THREADS_OVERRIDE
 #define EGS_BIN_THREADS EGS_BIN_THREADS_OVERRIDE
@@ -180,7 +183,8 @@ hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs 
                                      hipStream_t s);
 // The backward blend, and what it needs in place first (tile order, cleared accumulator; `tick`, may be NULL: the per-step bookkeeping
 // of an optimizer fused into this backward) as a launch of its own -- or carried by egs_l1_ssim_backward_ex (backward_prologue.h).
-hipError_t egs_launch_backward_prologue(int W, int H, EgsImgPtrs im, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick, hipStream_t s);
+// block_hot (may be NULL: every replica line is cleared): the per-workgroup hot counts of the frame's preprocess -- only the replica lines in use are cleared
+hipError_t egs_launch_backward_prologue(int P, int W, int H, EgsImgPtrs im, float* grad_acc, const uint32_t* block_hot, const EgsAdamTick* tick, hipStream_t s);
 hipError_t egs_launch_render_backward(int P, int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
                                       const float* dL_dalpha, float* grad_acc, hipStream_t s);

@@ -150,20 +150,37 @@ __device__ __forceinline__ void fwd_step(FwdCtx& c, v2f (&w01)[11], v2f (&w23)[1
     LOSS_STAMP(y_in - c.row0, 3);
 }
 
-// grid: (ceil(strips_x * strips_y / WPB), 1, C); a wave = one strip
+// Workgroup b runs on XCD b % 8 (blend_common.h).  Neighbouring strips share their halo -- 10 of 64 columns, 10 of 25 rows -- and the
+// 128-byte lines a misaligned 256-byte row segment straddles; dealt in index order they land on eight different L2s and every strip
+// fetches its whole footprint from HBM (43.6 MB for 12.4 MB of image, profiles/r4_loss_traffic.md).  Logical workgroup
+// (b % 8) * per + b / 8 gives each XCD one contiguous run of strips, so that its L2 serves the shared lines.  -> logical index, or
+// `main` and beyond for the padding workgroups of the rounded-up grid.
+__device__ __forceinline__ unsigned loss_logical_block(unsigned b, unsigned main) {
+#ifdef EGS_LOSS_NO_REMAP                     // A/B switch (tools/loss_time.py): index order
+    (void)main; return b;
+#else
+    const unsigned per = (main + 7u) / 8u;
+    return (b & 7u) * per + (b >> 3);
+#endif
+}
+
+// grid: 8 * ceil(C * ceil(strips_x * strips_y / WPB) / 8) (1-D, see loss_logical_block); a wave = one strip
 __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_forward(int H, int W, int strips_x, int strips_y, const float* __restrict__ img,
                                                                const float* __restrict__ gt, float* __restrict__ partial,
                                                                float* __restrict__ dm_dmu1, float* __restrict__ dm_dexx,
-                                                               float* __restrict__ dm_dexy) {
+                                                               float* __restrict__ dm_dexy, unsigned per_plane, unsigned main_wgs) {
     __shared__ v2f lds[WPB][2 * 80];
     const unsigned lane = threadIdx.x & 63, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
-    const int strip = blockIdx.x * WPB + (int)wv;
+    const unsigned rel = loss_logical_block(blockIdx.x, main_wgs);
+    if (rel >= main_wgs) return;
+    const unsigned plane_z = rel / per_plane;
+    const int strip = (int)(rel - plane_z * per_plane) * WPB + (int)wv;
     if (strip >= strips_x * strips_y) return;
     for (int k = lane; k < 2 * 80; k += 64) lds[wv][k] = (v2f)(0.f);   // the padding words stay zero
     __builtin_amdgcn_wave_barrier();
     FwdCtx c;
     c.H = H; c.W = W; c.lane = lane; c.dm_dmu1 = dm_dmu1; c.dm_dexx = dm_dexx; c.dm_dexy = dm_dexy;
-    c.rows = lds[wv]; c.plane = (size_t)blockIdx.z * H * W; c.l1 = 0.f; c.sm = 0.f;
+    c.rows = lds[wv]; c.plane = (size_t)plane_z * H * W; c.l1 = 0.f; c.sm = 0.f;
     const int sx = strip % strips_x, sy = strip / strips_x;
     c.gx = sx * SW - HALO + (int)lane;
     c.col_ok = c.gx >= 0 && c.gx < W;
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_forward(int H, int W, int 
     c.y_first = sy * SR; c.y_end = min(c.y_first + SR, H);
     c.stamp = false; c.row0 = c.y_first - HALO;
 #ifdef EGS_LOSS_TIMING
-    c.stamp = blockIdx.x == EGS_LOSS_TIMING && blockIdx.z == 0 && wv == 0;
+    c.stamp = rel == EGS_LOSS_TIMING && wv == 0;
 #endif
     v2f w01[11], w23[11];
 #pragma unroll
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_forward(int H, int W, int 
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { l1 += __shfl_xor(l1, d, 64); sm += __shfl_xor(sm, d, 64); }
     if (lane == 0) {
-        const size_t b = (size_t)blockIdx.z * strips_x * strips_y + strip;
+        const size_t b = (size_t)plane_z * strips_x * strips_y + strip;
         partial[2 * b] = l1; partial[2 * b + 1] = sm;
     }
 }
@@ -312,14 +329,15 @@ __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_backward(int H, int W, int
                                                                 const float* __restrict__ dm_dexy, float* __restrict__ dimg,
                                                                 const float* __restrict__ fin_partial, size_t fin_n, float fin_lambda,
                                                                 float* __restrict__ fin_loss, float* __restrict__ fin_running,
-                                                                unsigned per_plane, unsigned side_jobs, EgsPrologueArgs side) {
+                                                                unsigned per_plane, unsigned main_wgs, unsigned side_jobs, EgsPrologueArgs side) {
     __shared__ __attribute__((aligned(8))) float lds[WPB][3 * 80];      // per wave: [80] pairs (two maps), then [80] floats (the third)
     if (SIDE) {
         __shared__ EgsOrderLds order_lds;
         if (blockIdx.x >= gridDim.x - side_jobs) { egs_prologue_job<64 * WPB>(side, blockIdx.x - (gridDim.x - side_jobs), side_jobs, order_lds); return; }
     }
     const unsigned lane = threadIdx.x & 63, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
-    const unsigned rel = blockIdx.x;
+    const unsigned rel = loss_logical_block(blockIdx.x, main_wgs);    // (the strip workgroups come first in the grid, rounded up to a multiple of 8)
+    if (rel >= main_wgs) return;
     const unsigned plane_z = rel / per_plane, bx = rel - plane_z * per_plane;
     const int strip = (int)bx * WPB + (int)wv;
     if (fin_partial && bx == per_plane - 1) {                          // deferred loss value: one extra workgroup per channel plane, no strip
@@ -404,9 +422,10 @@ int egs_launch_l1_ssim_backward(int channels, int height, int width, const float
     EgsPrologueArgs none = {};
 #define LB_ARGS height, width, strips_x, strips_y, img, gt, (1.f - lambda_dssim) / n, lambda_dssim / n, upstream_grad, gate, dm_dmu1, dm_dexx, \
                 dm_dexy, dL_dimg, deferred_partial_sums, (size_t)strips_x * strips_y * channels, lambda_dssim, deferred_loss,            \
-                deferred_partial_sums ? loss_running_sum : nullptr, per_plane, side_jobs
-    if (side) hipLaunchKernelGGL(k_l1_ssim_backward<true>, dim3(side_jobs + per_plane * (unsigned)channels), dim3(64 * WPB), 0, stream, LB_ARGS, *side);
-    else hipLaunchKernelGGL(k_l1_ssim_backward<false>, dim3(per_plane * (unsigned)channels), dim3(64 * WPB), 0, stream, LB_ARGS, none);
+                deferred_partial_sums ? loss_running_sum : nullptr, per_plane, main_wgs, side_jobs
+    const unsigned main_pad = ((main_wgs + 7u) / 8u) * 8u;            // loss_logical_block: eight equal runs
+    if (side) hipLaunchKernelGGL(k_l1_ssim_backward<true>, dim3(side_jobs + main_pad), dim3(64 * WPB), 0, stream, LB_ARGS, *side);
+    else hipLaunchKernelGGL(k_l1_ssim_backward<false>, dim3(main_pad), dim3(64 * WPB), 0, stream, LB_ARGS, none);
 #undef LB_ARGS
     return (int)hipGetLastError();
 }
@@ -427,9 +446,9 @@ int egs_l1_ssim_forward(int channels, int height, int width, const float* img, c
     if (channels <= 0 || height <= 0 || width <= 0 || !img || !gt || !partial_sums || !dm_dmu1 || !dm_dexx || !dm_dexy)
         return EGS_ERR_ARG;
     const int strips_x = (width + SW - 1) / SW, strips_y = (height + SR - 1) / SR;
-    dim3 grid((strips_x * strips_y + WPB - 1) / WPB, 1, channels);
-    hipLaunchKernelGGL(k_l1_ssim_forward, grid, dim3(64 * WPB), 0, (hipStream_t)stream, height, width, strips_x, strips_y, img, gt,
-                       partial_sums, dm_dmu1, dm_dexx, dm_dexy);
+    const unsigned per_plane = (unsigned)((strips_x * strips_y + WPB - 1) / WPB), main_wgs = per_plane * (unsigned)channels;
+    hipLaunchKernelGGL(k_l1_ssim_forward, dim3(((main_wgs + 7u) / 8u) * 8u), dim3(64 * WPB), 0, (hipStream_t)stream, height, width, strips_x, strips_y, img, gt,
+                       partial_sums, dm_dmu1, dm_dexx, dm_dexy, per_plane, main_wgs);
     const float n = (float)channels * (float)height * (float)width;
     if (loss)                                       // loss == NULL: the value is assembled by egs_l1_ssim_backward (deferred)
         hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, (size_t)strips_x * strips_y * channels, partial_sums,

@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256) void k_preprocess(
     const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
     uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible,
-    uint32_t* __restrict__ block_sums, uint32_t* __restrict__ zero_words, size_t zero_n, const int32_t* __restrict__ active_count,
-    EgsPrologueArgs place, EgsObjRot rot) {
+    uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_hot, uint32_t* __restrict__ zero_words, size_t zero_n,
+    const int32_t* __restrict__ active_count, EgsPrologueArgs place, EgsObjRot rot) {
     __shared__ uint32_t wsum[4], whot[4];
     if (PLACE) {
         __shared__ EgsOrderLds order_lds;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
     for (int d = 32; d >= 1; d >>= 1) my_tiles += (uint32_t)__shfl_xor((int)my_tiles, d, 64);
     if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = my_tiles; whot[threadIdx.x >> 6] = (uint32_t)__popcll(hot_wave); }
     __syncthreads();
-    if (threadIdx.x == 0) block_sums[bid] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) { block_sums[bid] = wsum[0] + wsum[1] + wsum[2] + wsum[3]; block_hot[bid] = min(whot[0] + whot[1] + whot[2] + whot[3], EGS_HOT_PER_BLOCK); }
     if (hot) {   // rank among the workgroup's hot Gaussians -> the code that names this one's replica lines (egs_common.h); few per frame
         const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63;
         uint32_t rank = (uint32_t)__popcll(hot_wave & (lane ? (~0ull >> (64 - lane)) : 0ull));
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
             uint32_t bbx = __float_as_uint(r2->z), bby = __float_as_uint(r2->w);
             egs_hot_code_set(bbx, bby, rank + 1u);
             r2->z = __uint_as_float(bbx); r2->w = __uint_as_float(bby);
+            clamped_out[i] = (uint8_t)((clamped_out[i] & EGS_CLAMP_MASK) | ((rank + 1u) << 3));   // where the backward looks for it
         }
     }
 }
@@ -323,7 +324,7 @@ __device__ __forceinline__ void pp_bwd_one(
     if (vis) {
         const float4* r = rec + (size_t)i * EGS_SPLAT_REC_F4;
         const float4 r0 = r[0], r1 = r[1];
-        const uint32_t code = egs_hot_code(__float_as_uint(r[2].z), __float_as_uint(r[2].w));
+        const uint32_t code = (uint32_t)clamped[i] >> 3;
         if (code) {   // a hot Gaussian: the blend spread its sums over EGS_HOT_REPLICAS lines behind the regular ones (egs_common.h)
             const float* hl = hot_acc + ((size_t)(i >> 8) * EGS_HOT_PER_BLOCK + (code - 1u)) * EGS_HOT_LINE;
             for (unsigned rp = 0; rp < EGS_HOT_REPLICAS; rp++) {
@@ -442,7 +443,7 @@ __device__ __forceinline__ void pp_bwd_one(
         const float* sh = shs + (size_t)i * M * 3;
         // (fused SH leaf: M == 1, checked by the caller; without a dsh array the three values go straight to the stage)
         float* gsh = dsh ? dsh + (size_t)i * M * 3 : stage + ST_SH + 3 * tid;
-        const uint32_t cl = clamped[i];
+        const uint32_t cl = clamped[i] & EGS_CLAMP_MASK;
         float gdir[3] = { 0.f, 0.f, 0.f };
         for (int ch = 0; ch < 3; ch++) {
             const float g = ((cl >> ch) & 1u) ? 0.f : acc[6 + ch];
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(64) void k_sh_forward(int P, int D, int M, const fl
         if (v < 0.f) cl |= 1u << ch;
         rgb[ch] = fmaxf(v, 0.f);
     }
-    clamped[i] = (uint8_t)cl;
+    clamped[i] = (uint8_t)((clamped[i] & ~EGS_CLAMP_MASK) | cl);      // (bits 3-5: the HOT code k_preprocess left)
     float* r = reinterpret_cast<float*>(rec + (size_t)i * EGS_SPLAT_REC_F4);
     r[6] = rgb[0]; r[7] = rgb[1]; r[8] = rgb[2];
 }
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(64) void k_sh_backward(int P, int D, int M, const f
         const float d0[3] = { p[0] - campos[0], p[1] - campos[1], p[2] - campos[2] };
         const float inv = 1.f / sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
         const float x = d0[0] * inv, y = d0[1] * inv, z = d0[2] * inv;
-        const uint32_t cl = clamped[i];
+        const uint32_t cl = clamped[i] & EGS_CLAMP_MASK;
         float gdir[3] = { 0.f, 0.f, 0.f };
         for (int ch = 0; ch < 3; ch++) {
             const float g = ((cl >> ch) & 1u) ? 0.f : dcolors[3 * i + ch];
@@ -983,7 +984,7 @@ __global__ __launch_bounds__(64) void k_sh16_forward(int P, int D, const float* 
         if (v < 0.f) cl |= 1u << ch;
         rgb[ch] = fmaxf(v, 0.f);
     }
-    clamped[i] = (uint8_t)cl;
+    clamped[i] = (uint8_t)((clamped[i] & ~EGS_CLAMP_MASK) | cl);      // (bits 3-5: the HOT code k_preprocess left)
     float* r = reinterpret_cast<float*>(rec + (size_t)i * EGS_SPLAT_REC_F4);
     r[6] = rgb[0]; r[7] = rgb[1]; r[8] = rgb[2];
 }
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(64) void k_sh16_backward(int P, int D, const float*
     if (inb) {                                                         // everything the row math needs besides the rows, issued up front
         p[0] = means3D[3 * i]; p[1] = means3D[3 * i + 1]; p[2] = means3D[3 * i + 2];
         dc[0] = dcolors[3 * i]; dc[1] = dcolors[3 * i + 1]; dc[2] = dcolors[3 * i + 2];
-        cl = clamped[i];
+        cl = clamped[i] & EGS_CLAMP_MASK;
         if (D > 0 || (SINK && sink.leaf[EGS_SINK_MEANS3D].p)) { gm[0] = dmeans3D[3 * i]; gm[1] = dmeans3D[3 * i + 1]; gm[2] = dmeans3D[3 * i + 2]; }
     }
     const uint64_t vmask = __ballot(vis);
@@ -1168,7 +1169,7 @@ hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, cons
     if (!zero_words) zero_n = 0;
     EgsPrologueArgs pa = {};
 #define PP_ARGS P, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.tanfovx, \
-                cam.tanfovy, radii, g.rec, g.rect, g.offsets, g.clamped, g.visible, g.scan_scratch, zero_words, zero_n, active_count
+                cam.tanfovy, radii, g.rec, g.rect, g.offsets, g.clamped, g.visible, g.scan_scratch, g.block_hot, zero_words, zero_n, active_count
     if (place) {
         pa.n_tiles = ((cam.W + EGS_TILE - 1) / EGS_TILE) * ((cam.H + EGS_TILE - 1) / EGS_TILE);
         pa.quad_work = place->fwd_cost; pa.tile_order = place->fwd_order;

@@ -241,14 +241,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 // What the blend below needs in place: tile order, cleared accumulator, (fused optimizer) bookkeeping -- as a launch of its own
 // (egs_l1_ssim_backward_ex can carry the same jobs instead).
-hipError_t egs_launch_backward_prologue(int W, int H, EgsImgPtrs im, float* grad_acc, size_t acc_floats, const EgsAdamTick* tick, hipStream_t s) {
+hipError_t egs_launch_backward_prologue(int P, int W, int H, EgsImgPtrs im, float* grad_acc, const uint32_t* block_hot, const EgsAdamTick* tick, hipStream_t s) {
     const int n_tiles = ((W + EGS_TILE - 1) / EGS_TILE) * ((H + EGS_TILE - 1) / EGS_TILE);
     if (n_tiles == 0) {
         if (tick) { hipError_t e = egs_launch_adam_tick(*tick, s); if (e != hipSuccess) return e; }
-        return egs_launch_zero_f4((float4*)grad_acc, acc_floats / 4, s);
+        return egs_launch_zero_f4((float4*)grad_acc, egs_acc_floats((size_t)P) / 4, s);
     }
     EgsPrologueArgs pa = {};
-    pa.n_tiles = n_tiles; pa.quad_work = im.quad_work; pa.tile_order = im.tile_order; pa.acc4 = (float4*)grad_acc; pa.n4 = acc_floats / 4;
+    pa.n_tiles = n_tiles; pa.quad_work = im.quad_work; pa.tile_order = im.tile_order;
+    egs_prologue_acc(pa, grad_acc, (size_t)P, block_hot);
     pa.has_tick = tick ? 1 : 0; if (tick) pa.tick = *tick;
     hipLaunchKernelGGL(k_backward_prologue, dim3(egs_prologue_jobs(pa.n4, pa.has_tick, 1024)), dim3(1024), 0, s, pa);
     return hipGetLastError();

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EGS_RASTER_LIB", os.path.join(_HERE, "libegs_raster.so"))      # override for A/B builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 RETRY_LARGER = -100
 
 vp, f32, i32, i64 = C.c_void_p, C.c_float, C.c_int, C.c_int64
@@ -42,7 +42,7 @@ class ObjectRotation(C.Structure):               # egs_object_rotation
 
 class BackwardPrologue(C.Structure):             # egs_backward_prologue
     _fields_ = [("P", C.c_int), ("width", C.c_int), ("height", C.c_int), ("image_buffer", C.c_void_p), ("scratch", C.c_void_p),
-                ("sink", C.POINTER(AdamSink)), ("skip_flag", C.c_void_p)]
+                ("sink", C.POINTER(AdamSink)), ("skip_flag", C.c_void_p), ("geom_buffer", C.c_void_p)]
 
 
 SINK_MEANS3D, SINK_OPACITY, SINK_SCALES, SINK_ROTATIONS, SINK_SH, SINK_SH_REST = range(6)      # EGS_SINK_*

@@ -107,7 +107,7 @@ def backward_prologue_of(node):
         saved = node.saved_tensors
     except RuntimeError:
         return None                                   # already freed: that backward ran before
-    means3D, img = saved[1], saved[9]
+    means3D, geom, img = saved[1], saved[7], saved[9]
     P = means3D.shape[0]
     sink = node.sink
     if P == 0 or node.prologue_scratch is not None:
@@ -116,7 +116,7 @@ def backward_prologue_of(node):
     scratch = torch.empty((_lib.load().egs_backward_scratch_bytes(P),), device=means3D.device, dtype=torch.uint8)
     side = _lib.BackwardPrologue()
     side.P, side.width, side.height = P, int(rs.image_width), int(rs.image_height)
-    side.image_buffer, side.scratch = img.data_ptr(), scratch.data_ptr()
+    side.image_buffer, side.scratch, side.geom_buffer = img.data_ptr(), scratch.data_ptr(), geom.data_ptr()
     if sink is not None:
         side.sink = C.pointer(sink.struct)
     if node.guard is not None:

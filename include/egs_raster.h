@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 2
+#define EGS_ABI_VERSION 3
 #define EGS_TILE 16                 /* tile edge in pixels; part of the parity contract */
 #define EGS_MAX_SH_DEGREE 3
 
@@ -377,6 +377,8 @@ typedef struct egs_backward_prologue {
     void* scratch;                   /* egs_backward_scratch_bytes(P): the backward's scratch */
     const egs_adam_sink* sink;       /* HOST, or NULL */
     const uint32_t* skip_flag;       /* device uint32[1] or NULL */
+    const void* geom_buffer;         /* ABI 3: of that call's forward, or NULL.  With it only the accumulator lines in use are cleared
+                                      * (the replica lines of the frame's hot Gaussians, csrc/egs_common.h); NULL: all of them */
 } egs_backward_prologue;
 int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
                             const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
