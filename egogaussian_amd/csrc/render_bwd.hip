@@ -164,7 +164,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         __builtin_amdgcn_wave_barrier();
         // entries whose Gaussian is hot (egs_common.h): their sums go to one of the Gaussian's replica lines instead of its own
         const uint32_t my_code = egs_hot_code(__float_as_uint(c2.z), __float_as_uint(c2.w));
+#ifdef EGS_NO_HOT                          // A/B switch: every splat accumulates into its own line
+        const uint64_t hot_mask = 0ull; (void)my_code;
+#else
         const uint64_t hot_mask = __ballot(have && my_code != 0u);
+#endif
         const uint32_t lastb = last > base ? last - base : 0u;       // this pixel uses entries j < lastb of the batch
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);

@@ -30,6 +30,12 @@ class AdamSink:
         alone even if a gradient reached them (keep_grads)."""
         if self._opt is not None:
             for p in self._params:
+                if p in self._opt._sunk:
+                    # the sole-consumer precondition of egs_backward_adam (include/egs_raster.h), enforced where it can be seen: a second
+                    # rasterizer backward of the same iteration has just stepped this leaf again with its partial gradient
+                    raise RuntimeError("FusedAdam: a parameter took its Adam step inside two rasterizer backwards of one iteration (two renders "
+                                       "with optimizer= feed one loss); render all but one of them without optimizer=, or call optimizer.step() "
+                                       "between them")
                 self._opt._sunk[p] = bool(self.keep_grads)
                 # k_adam's own per-workgroup step counters do not follow a step taken here (only state["step"] advances): the next
                 # plain step() of this parameter re-seeds them.  Set on EVERY fused backward -- a cached sink (make_sink hit) after a

@@ -164,6 +164,31 @@ def test_alternating_fused_and_plain_steps_keep_the_step_count():
     assert len(made) == 3 and made[1] is made[0] and made[2] is made[0]          # the later fused steps DID take the cached sink
 
 
+def test_two_fused_consumers_in_one_iteration_are_refused():
+    """The sole-consumer precondition of egs_backward_adam: a loss that reaches the parameters through TWO renders, both with
+    optimizer=, would step every leaf twice with partial gradients -- the second backward raises."""
+    from egogaussian_amd.scene_synth import SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.fused import l1_ssim_loss
+    from egogaussian_amd.optim import FusedAdam
+    student, cams, gts, bg = _scene(N=4000)
+    pc = SynthGaussians(student, device=DEV)
+    opt = FusedAdam(_groups(pc), lr=0.0, eps=1e-15, capturable=True)
+    a = render(cams[0], pc, Pipe, bg, optimizer=opt)
+    b = render(cams[1], pc, Pipe, bg, optimizer=opt)
+    loss = l1_ssim_loss(a["render"], gts[0], 0.2) + l1_ssim_loss(b["render"], gts[1], 0.2)
+    with pytest.raises(RuntimeError, match="two rasterizer backwards"):
+        loss.backward()
+    opt._sunk.clear(); opt.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    # one fused consumer per iteration, iteration after iteration, is the supported use
+    for k in range(2):
+        out = render(cams[k], pc, Pipe, bg, optimizer=opt)
+        l1_ssim_loss(out["render"], gts[k], 0.2).backward()
+        opt.step()
+    torch.cuda.synchronize()
+
+
 def test_graph_step_with_and_without_fused_optimizer_agree():
     """GraphedTrainStep(fuse_optimizer=True / False) on the same frames: same step counts, no gradient arrays for the leaves in the
     fused graph, and parameters that differ from the unfused run's no more than two unfused runs differ from each other (the backward's
