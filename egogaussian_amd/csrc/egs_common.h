@@ -39,7 +39,9 @@
 // ceil(P / 256) * EGS_HOT_PER_BLOCK), r = the XCD the blending workgroup runs on, right behind the P regular lines in the backward's
 // scratch.  Replica-major: a Gaussian's replicas lie hundreds of KB apart, i.e. in different memory channels -- side by side they
 // relieved the line but not the channel that serves it.  Sums only move between lines: every gradient is the same sum of the same terms.
+#ifndef EGS_HOT_MIN_TILES
 #define EGS_HOT_MIN_TILES 256u
+#endif
 #define EGS_HOT_PER_BLOCK 7u
 #define EGS_HOT_REPLICAS 8u
 #define EGS_HOT_LINE 16u            // floats between replica lines (64 B: two per 128-byte line)
