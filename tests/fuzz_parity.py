@@ -63,6 +63,11 @@ def run_draws(seed=0, budget_s=None, n_draws=None, dev=None, verbose=False):
                 f = outlier_fraction(hip.cpu().numpy(), ora, TOL)
                 strict = strict and f == 0.0
                 assert f <= max(1e-3, 8.0 / hip.numel()), f"{tag}: {name} outliers {f}"
+            # pixels on the other side of an alpha / transmittance threshold than the oracle's (v_exp_f32 vs glibc expf in the last place)
+            flips = 0
+            if R:
+                flips = int(((np.abs(color.cpu().numpy() - st["color"]) > TOL * max(np.abs(st["color"]).max(), 1e-30)).any(0) |
+                             (np.abs(iv["final_T"].cpu().numpy() - st["final_T"]) > TOL)).sum())
             grads = seeded_grads(H, W, 7)
             if split:
                 gc, gd, ga = [x.to(dev) for x in grads]
@@ -83,7 +88,10 @@ def run_draws(seed=0, budget_s=None, n_draws=None, dev=None, verbose=False):
             f, e = outlier_fraction(hh, ora, TOL), rel_err(hh, ora)
             worst[name] = max(worst.get(name, 0.0), e)
             strict = strict and e <= TOL
-            assert f <= max(1e-3, 8.0 / hh.size) and e < 2e-2, f"{tag}: {name} outliers {f} max rel {e}"
+            # a flipped pair moves the gradients of ITS splat by that pair's whole share -- for a faint splat that reaches three or four
+            # pixels a few per cent of its dL/dopacity (seed 4242, draw 3215: one flipped pixel, 2.3 %, identical with the round-3
+            # kernels; tests/dev/fuzz_repro.py replays a draw) -- so the bound on the maximum is wider when the frame has a flip
+            assert f <= max(1e-3, 8.0 / hh.size) and e < (5e-2 if flips else 2e-2), f"{tag}: {name} outliers {f} max rel {e} ({flips} flipped pixels)"
         n_cases += 1
         worst["_strict_draws"] = worst.get("_strict_draws", 0) + (1 if strict else 0)
     return n_cases, worst
