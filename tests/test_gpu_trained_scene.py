@@ -84,6 +84,51 @@ def test_hot_gaussians_accumulate_through_replica_lines(cull):
     print("\n   hot replica lines: " + _check_grads(hb, gb, flips, "hot") + f"; flips {flips}")
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_hot_layouts_vs_oracle(seed):
+    """Random image sizes (272 .. 1 100 tiles), random numbers of screen-filling splats at random places of the array (clustered, so that
+    workgroups run over their budget of seven, or spread), random opacities, either covariance mode, culling on or off: radii, images
+    and every gradient against the oracle; hot codes: at most seven per 256-Gaussian workgroup, distinct, only on large boxes."""
+    dev = _dev()
+    rng = np.random.default_rng(100 + seed)
+    H, W = int(rng.integers(260, 420)), int(rng.integers(270, 680))
+    N = int(rng.choice([700, 2500, 6000]))
+    mode = str(rng.choice(["col_sr", "sh_sr"]))
+    cull = bool(rng.integers(0, 2))
+    d = make_inputs(N, H, W, 200 + seed, 0, mode, scale_mul=float(rng.choice([1.0, 2.0])))
+    n_big = int(rng.integers(1, 24))
+    start = int(rng.integers(0, N - 40))
+    big = sorted(set((start + rng.integers(0, 40 if rng.integers(0, 2) else N - start, n_big)).tolist()))
+    gen = torch.Generator().manual_seed(seed)
+    d["means3D"][big, 0] = 0.8 * (torch.rand(len(big), generator=gen) - 0.5)
+    d["means3D"][big, 1] = 0.5 * (torch.rand(len(big), generator=gen) - 0.5)
+    d["means3D"][big, 2] = 2.5 + 7.0 * torch.rand(len(big), generator=gen)
+    d["scales"][big] = 1.0 + 3.0 * torch.rand(len(big), 3, generator=gen)
+    d["opacities"][big] = (0.01 + 0.5 * torch.rand(len(big), generator=gen)).view(-1, *d["opacities"].shape[1:])
+    o, st = oracle_forward(d)
+    with tile_culling(cull):
+        g, out = hip_forward(d, dev, debug=True)
+        grads = seeded_grads(H, W, 50 + seed)
+        hb = hip_backward(g, out, grads, dev, debug=True)
+    torch.cuda.synchronize()
+    assert out[0] == st["R"] and np.array_equal(out[4].cpu().numpy(), st["radii"])
+    code = _hot_codes(out[5], N, out[4])
+    for b in range((N + 255) // 256):
+        c = code[256 * b:256 * (b + 1)]; c = c[c != 0]
+        assert len(c) <= 7 and sorted(c.tolist()) == list(range(1, len(c) + 1)), (b, c)
+    assert set(np.nonzero(code)[0].tolist()) <= set(big)
+    from egogaussian_amd import _C
+    iv = _C.image_views(out[7], W, H)
+    for name, hip, ora in (("color", out[1], st["color"]), ("depth", out[2], st["depth"]), ("alpha", out[3], st["alpha"])):
+        assert outlier_fraction(hip.cpu().numpy(), ora, TOL) <= 1e-4, name
+    flips = int(((np.abs(out[1].cpu().numpy() - st["color"]) > TOL * np.abs(st["color"]).max()).any(0) |
+                 (np.abs(iv["final_T"].cpu().numpy() - st["final_T"]) > TOL)).sum())
+    if not cull:
+        flips += int((iv["n_contrib"].cpu().numpy().view(np.uint32) != st["n_contrib"]).sum())
+    gb = o.backward(st, *grads)
+    print(f"\n   [{N}@{W}x{H} {mode} cull={cull}] {len(big)} large splats, {int((code != 0).sum())} hot: " + _check_grads(hb, gb, flips, "random hot") + f"; flips {flips}")
+
+
 def _trained_inputs():
     from egogaussian_amd.scene_synth import make_camera, SynthGaussians
     z = np.load(os.path.join(ROOT, "bench_data", "trained_scene.npz"))
