@@ -277,6 +277,10 @@ def main():
                     help="wall-clock milliseconds of forward-only renders (no training) right before the warm-up steps: clock spin-up; 0 = none")
     ap.add_argument("--steps-per-replay", type=int, default=5,
                     help="training steps captured into one hipGraph (each on its own frame); lowered to a divisor of --steps when needed; 1 = one launch per step")
+    ap.add_argument("--double-buffer", action="store_true",
+                    help="two captured graphs on two sets of static frames, alternated, the copy of the next replay's frames on a side stream "
+                         "under the previous replay (GraphedTrainStep(double_buffer=True)).  Measured SLOWER than the one graph with the copy "
+                         "between two replays (3 175 vs 3 225 it/s, three A/B pairs): off by default")
     ap.add_argument("--item-every-step", action="store_true",
                     help="with --no-graph: read loss.item() after every step, as /root/reference/trainers/train_static.py:112 does (a host "
                          "synchronisation per iteration), and report the host time spent inside render() and loss.backward()")
@@ -420,7 +424,7 @@ def main():
         if use_graph:                                               # the whole iteration as one hipGraph (egogaussian_amd/graph.py)
             spr = next(k for k in range(max(1, min(args.steps_per_replay, args.steps)), 0, -1) if args.steps % k == 0)
             try:
-                graphed = GraphedTrainStep(pc, opt, bg, 0.2, dynamic=dynamic, gated=dynamic, steps_per_replay=spr)
+                graphed = GraphedTrainStep(pc, opt, bg, 0.2, dynamic=dynamic, gated=dynamic, steps_per_replay=spr, double_buffer=args.double_buffer)
                 graphed.capture(cams[0], gts[0], warmup=2, accum_R=rot[0] if dynamic else None, gate=gates[0] if dynamic else None,
                                 capacity_cams=cams[::max(1, n_used // 6)])
             except Exception as exc:                                # keep measuring, eagerly, rather than lose the run

@@ -36,41 +36,46 @@ class StepGuard:
         self.running_max = torch.zeros(1, dtype=torch.int64, device=device)
         # deferred=True (EAGER loops): forwards that carry this guard are enqueued against the capacity hint WITHOUT the host wait for
         # the instance count (egs_forward_enqueue, as under graph capture); the count and the overflow word of a frame are read from
-        # page-locked memory at the NEXT forward.  A frame that did not fit is then already voided on the device (the backward's
+        # page-locked memory at a FOLLOWING forward (the next one whose call finds the copy landed; never a wait).  A frame that did not fit is then already voided on the device (the backward's
         # statistics and the Adam step of a FusedAdam(capturable=True) honour the overflow word), `overflows` counts it, and the next
         # frame runs with room.  Its IMAGE and loss value are clipped: use for training loops, not for evaluation renders.
         self.deferred = bool(deferred)
         self.overflows = 0                    # frames of this guard that were clipped (found at the following forward / check())
         self.frames = 0
         self.last_R = 0                       # rectangle instances of the last CHECKED frame
-        self._pending = None                  # (page-locked counts, event, P, capacity) of the frame not checked yet
-        self._pinned = [None, None]
+        self._pending = []                    # frames not checked yet, oldest first: (page-locked counts, P, capacity, device index)
+        self._pinned = [None] * _DEFER_RING
 
     def check(self):
-        """Settle the frame that has not been checked yet (waits for it).  -> True when no frame of this guard has been clipped."""
-        _settle(self)
+        """Settle every frame that has not been checked yet (waits for them).  -> True when no frame of this guard has been clipped."""
+        _settle(self, wait=True)
         return self.overflows == 0
 
 
-def _settle(guard):
-    """Read the counts the previous deferred forward of `guard` copied out; raise the capacity hint when it did not fit."""
-    pend = guard._pending
-    if pend is None:
-        return
-    pinned, P, cap, key = pend
-    guard._pending = None
-    nb = (P + 255) // 256
-    tail = pinned[nb:nb + 2]
-    if int(tail[0]) == -1:                    # the copy that ends the frame's chain has not landed yet (no sentinel overwritten): wait for
-        torch.cuda.synchronize(key)           # it -- rare: a loop that runs the backward in between finds it long complete
-    R = int(_lib.load().egs_sum_counts(int(P), C.c_void_p(pinned.data_ptr())))
-    clipped, kept = int(tail[0]), int(tail[1]) & 0xffffffff
-    guard.last_R = R
-    if clipped:
-        guard.overflows += 1
-        stats["retries"] += 1
-    if clipped or R > cap:
-        _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(max(R, kept) * 1.25) + 65536)
+_DEFER_RING = 8                       # deferred frames in flight before a forward waits for the oldest (a host that runs far ahead)
+
+
+def _settle(guard, wait=False):
+    """Read the counts the earlier deferred forwards of `guard` copied out, oldest first, as far as they have landed (a sentinel
+    word tells); raise the capacity hint when one did not fit.  Never waits for the GPU unless `wait` or the ring is full: a host
+    that runs ahead of the GPU (no synchronisation in its loop) checks a frame a few forwards later instead."""
+    while guard._pending:
+        pinned, P, cap, key = guard._pending[0]
+        nb = (P + 255) // 256
+        tail = pinned[nb:nb + 2]
+        if int(tail[0]) == -1:                # the copy that ends the frame's chain has not landed yet (the sentinel is still there)
+            if not (wait or len(guard._pending) >= _DEFER_RING - 1):
+                return
+            torch.cuda.synchronize(key)
+        guard._pending.pop(0)
+        R = int(_lib.load().egs_sum_counts(int(P), C.c_void_p(pinned.data_ptr())))
+        clipped, kept = int(tail[0]), int(tail[1]) & 0xffffffff
+        guard.last_R = R
+        if clipped:
+            guard.overflows += 1
+            stats["retries"] += 1
+        if clipped or R > cap:
+            _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(max(R, kept) * 1.25) + 65536)
 
 
 def binning_passes(P, W, H):
@@ -268,7 +273,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 geom, img, binning = state[:gb], state[gb:gb + ib], state[gb + ib:]
             deferred = cap > 0                                   # no capacity known yet: this call establishes it the waiting way
         if deferred:
-            i = guard.frames & 1
+            i = guard.frames % _DEFER_RING
             pin = guard._pinned[i]
             if pin is None or pin.numel() < nb + 2:
                 pin = guard._pinned[i] = torch.empty((max(nb + 2, 4096),), dtype=torch.int32, pin_memory=True)
@@ -279,7 +284,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
                 _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), C.c_void_p(pin.data_ptr()), _ptr(guard.running_max),
                 _ptr(active_count), _ptr(guard.overflow), _ptr(place), rot_arg, _stream(dev)))
-            guard._pending = (pin, P, cap, key)
+            guard._pending.append((pin, P, cap, key))
             guard.frames += 1
             R = C.c_int64(cap)                      # layout size, as under capture; the frame's own count is read at the next call
             rc = 0

@@ -93,7 +93,7 @@ class _StaticCamera:
 
 class GraphedTrainStep:
     def __init__(self, pc, optimizer, bg, lambda_dssim=0.2, pipe=Pipe, render_kwargs=None, densify_stats=False, dynamic=False,
-                 which_object=1, gated=False, check_every=0, steps_per_replay=1, fuse_optimizer=True):
+                 which_object=1, gated=False, check_every=0, steps_per_replay=1, fuse_optimizer=True, double_buffer=False):
         """densify_stats: the captured step also keeps the per-iteration densification statistics (trainers/train_static.py:125-127:
                        max_radii2D, xyz_gradient_accum, denom) -- updated by the rasterizer's backward itself, no launch of their own.
         dynamic:       the `fine_all` call shape (/root/reference/trainers/fine_all.py:88-93): render(..., rot_cov=True,
@@ -105,11 +105,18 @@ class GraphedTrainStep:
         steps_per_replay: S > 1 captures S complete iterations back to back, each on its own static frame; one launch then runs
                        S training steps on S frames (`__call__` takes the S packed frames as one [S, frame] tensor or a list).  A
                        graph launch leaves the GPU idle for ~9 us before its first node; this divides that by S.
+        double_buffer: capture the step TWICE, on two sets of static frame buffers, and alternate between the two graphs: the copy of
+                       call k + 1's frames then runs on a side stream while call k's replay is still working (it only has to wait for
+                       replay k - 1, the last user of its buffer), instead of between two replays (packed frames only; 31 MB per five
+                       960x540 frames: 2.7 us per step).  Results are those of the single-buffered step.  MEASURED at config C: 1.6 % slower than
+                       the single graph (3 175 vs 3 225 it/s) -- the event waits between the streams cost more than the hidden copy --,
+                       so it is off by default and bench.py does not use it.
         fuse_optimizer: the parameters render() hands to the rasterizer as stored take their Adam step inside its backward
                        (renderer.render, optimizer=): no gradient arrays, no optimizer launch for them; the step's loss must then
                        depend on the model through that one render only -- which is the step this class captures.  Results are
                        bit-identical either way."""
         self.fuse_optimizer = bool(fuse_optimizer)
+        self.double_buffer = bool(double_buffer)
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True)")
         self.pc, self.opt, self.bg, self.lam, self.pipe = pc, optimizer, bg, lambda_dssim, pipe
@@ -119,6 +126,7 @@ class GraphedTrainStep:
         self.check_every = int(check_every)
         self.steps_per_replay = max(1, int(steps_per_replay))
         self.graph = None
+        self._sets = None
         self.guard = None
         self.loss_sum = None
         self.recaptures = 0               # re-captures this object did on its own (overflow)
@@ -224,6 +232,49 @@ class GraphedTrainStep:
                 self.graph.capture_end()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        self._sets = None
+        if self.double_buffer:
+            # the same iterations recorded once more on a second set of static frames; what the two captures share -- parameters,
+            # optimizer state, guard words, loss_sum -- is shared by address
+            first = dict(graph=self.graph, frames=self._frames, slots=self._slots, loss=self.loss, losses=self.losses, image=self.image,
+                         radii=self.radii, visibility_filter=self.visibility_filter, viewspace_grad=self.viewspace_grad)
+            frames2 = self._frames.clone()
+            off, _ = self._frame_layout(self.gt)
+            slots2 = []
+            for k in range(self.steps_per_replay):
+                fr, src = frames2[k], self._slots[k]
+                sl = {"gt": fr[off["gt"][0]:off["gt"][1]].view(src["gt"].shape), "accum_R": None, "gate": None}
+                sl["cam"] = _StaticCamera(src["cam"], storage=fr[off["cam"][0]:off["cam"][1]])
+                if self.dynamic:
+                    sl["accum_R"] = fr[off["accum_R"][0]:off["accum_R"][1]].view(3, 3)
+                if self.gated:
+                    sl["gate"] = fr[off["gate"][0]:off["gate"][1]].view(src["gt"].shape[-2], src["gt"].shape[-1])
+                slots2.append(sl)
+            self._slots = slots2
+            self.opt.zero_grad(set_to_none=True)
+            g2 = torch.cuda.CUDAGraph()
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                g2.capture_begin(capture_error_mode="thread_local")
+                try:
+                    losses2 = []
+                    for k in range(self.steps_per_replay):
+                        if k:
+                            self.opt.zero_grad(set_to_none=True)
+                        loss2, out2 = self._body(k)
+                        losses2.append(loss2)
+                finally:
+                    g2.capture_end()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            second = dict(graph=g2, frames=frames2, slots=slots2, loss=loss2, losses=losses2, image=out2["render"].detach(), radii=out2["radii"],
+                          visibility_filter=out2["visibility_filter"], viewspace_grad=out2["viewspace_points"].grad)
+            self._slots = first["slots"]
+            self._sets = [first, second]
+            self._copy_stream = torch.cuda.Stream(device=dev)
+            self._done = [torch.cuda.Event(), torch.cuda.Event()]       # replay of set b finished reading its frames
+            self._copied = [torch.cuda.Event(), torch.cuda.Event()]
+            self._used = [False, False]
         self.guard.running_max.zero_(); self.guard.overflow.zero_()
         return self
 
@@ -233,12 +284,15 @@ class GraphedTrainStep:
         cam = self.cam if cam is None else cam
         gt = self.gt if gt is None else gt
         self.graph = None                                            # drop the old graph and its private memory pool first
+        self._sets = None
         return self.capture(cam, gt, warmup=warmup, capacity_margin=capacity_margin, capacity_cams=capacity_cams)
 
     def __call__(self, cam, gt=None, accum_R=None, gate=None):
         """One training iteration (steps_per_replay of them): copy inputs in, replay.  Returns the (device, static) loss tensor of
         the last iteration (`self.losses` has all).  Either (camera, ground-truth image[, accum_R][, gate]) or packed frames from
         pack_frame(): one for a single-iteration step, a [S, frame] tensor (one copy) or a list of S for steps_per_replay = S."""
+        if gt is None and self._sets is not None:
+            return self._call_double_buffered(cam)
         if gt is None:
             if isinstance(cam, (list, tuple)):
                 for k, fr in enumerate(cam):
@@ -259,6 +313,38 @@ class GraphedTrainStep:
                                "the captured launches point at freed memory -- call recapture() first")
         self.opt.sync_lr()                                           # a fill per group whose learning rate was edited since the last call
         self.graph.replay()
+        self._calls += 1
+        if self.check_every > 0 and self._calls % self.check_every == 0:
+            self.check()
+        return self.loss
+
+    def _call_double_buffered(self, frames):
+        """Packed frames, two captured graphs: the copy into set b's static frames runs on a side stream as soon as set b's previous
+        replay has finished, i.e. under the replay of the other set that is still running."""
+        b = self._calls & 1
+        st = self._sets[b]
+        main = torch.cuda.current_stream(st["frames"].device)
+        if self._used[b]:
+            self._copy_stream.wait_event(self._done[b])
+        else:
+            self._copy_stream.wait_stream(main)                      # first use: after whatever produced the frames / the capture
+        with torch.cuda.stream(self._copy_stream):
+            if isinstance(frames, (list, tuple)):
+                for k, fr in enumerate(frames):
+                    st["frames"][k].copy_(fr, non_blocking=True)
+            else:
+                st["frames"].copy_(frames.view(st["frames"].shape), non_blocking=True)
+            self._copied[b].record(self._copy_stream)
+        if getattr(self.pc, "model_version", 0) != self._model_version:
+            raise RuntimeError("GraphedTrainStep: the model reallocated its arrays (CapacityGaussians.grow) after this step was captured; "
+                               "the captured launches point at freed memory -- call recapture() first")
+        self.opt.sync_lr()
+        main.wait_event(self._copied[b])
+        st["graph"].replay()
+        self._done[b].record(main)
+        self._used[b] = True
+        self.loss, self.losses, self.image, self.radii = st["loss"], st["losses"], st["image"], st["radii"]
+        self.visibility_filter, self.viewspace_grad = st["visibility_filter"], st["viewspace_grad"]
         self._calls += 1
         if self.check_every > 0 and self._calls % self.check_every == 0:
             self.check()

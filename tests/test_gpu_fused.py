@@ -441,3 +441,47 @@ def test_object_rotation_inside_the_rasterizer_matches_the_covariance_path():
     # and a rotation that is being trained keeps the covariance path (its gradient needs it)
     pc = SynthGaussians(student, device=DEV); pc._is_object = is_obj
     assert pc.get_raw_parameters_rotated(R.clone().requires_grad_(True), 1, False) is None
+
+
+@pytest.mark.gpu
+def test_double_buffered_graph_step_matches_single_buffered():
+    """GraphedTrainStep(double_buffer=True): two captures of the same iterations on two sets of static frames, alternated, the copy of
+    the next call's frames on a side stream.  Ten calls of three iterations each must leave the parameters where the single-buffered
+    step leaves them (same frames in the same order; only the accumulation order of the atomics differs), count every step, and
+    report each call's losses."""
+    import math
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.optim import FusedAdam
+    from egogaussian_amd.graph import GraphedTrainStep, pack_frame
+    N, H, W, S, CALLS = 20000, 96, 160, 3, 10
+    teacher = make_scene(N, H, W, 0); teacher["log_scale"] += math.log(2.0)
+    student = perturb_student(teacher)
+    cams = [make_camera(k, H, W, device=DEV) for k in range(0, 120, 10)]
+    bg = torch.zeros(3, device=DEV)
+    with torch.no_grad():
+        tpc = SynthGaussians(teacher, device=DEV, requires_grad=False)
+        gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
+    frames = torch.stack([pack_frame(c, g_) for c, g_ in zip(cams, gts)])
+    res = {}
+    for db in (False, True):
+        pc = SynthGaussians(student, device=DEV)
+        opt = FusedAdam([{"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3}, {"params": [pc._opacity], "lr": 0.05},
+                         {"params": [pc._scaling], "lr": 5e-3}, {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15, capturable=True)
+        step = GraphedTrainStep(pc, opt, bg, steps_per_replay=S, double_buffer=db).capture(cams[0], gts[0], warmup=2)
+        losses = []
+        for c in range(CALLS):
+            k = (c * S) % (len(cams) - S + 1)
+            step(frames[k:k + S])
+            losses.append([l.clone() for l in step.losses])
+        torch.cuda.synchronize()
+        assert step.ok()
+        res[db] = (pc, opt, [[float(l) for l in ls] for ls in losses], float(step.loss_sum))
+    (pa, oa, la, sa), (pb, ob, lb, sb) = res[False], res[True]
+    assert float(oa.state[pa._xyz]["step"]) == float(ob.state[pb._xyz]["step"]) == 2 + S * CALLS
+    for x, y in zip(la, lb):
+        assert all(abs(u - v) <= 2e-3 * abs(u) for u, v in zip(x, y)), (x, y)
+    assert abs(sa - sb) <= 2e-3 * abs(sa)
+    for a in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"):
+        u, v = getattr(pa, a).detach(), getattr(pb, a).detach()
+        assert float((u - v).abs().mean()) <= 2e-4 * float(u.abs().mean()) + 1e-7, a
