@@ -174,11 +174,17 @@ __device__ __forceinline__ void egs_order_band(const EgsPrologueArgs& a, const i
 
 template <int NT>
 __device__ __forceinline__ void egs_prologue_job(const EgsPrologueArgs& a, const unsigned job, const unsigned n_jobs, EgsOrderLds& L) {
+#if defined(EGS_ABL_SIDE) && EGS_ABL_SIDE == 2      // timing ablations of the carried jobs (tools/loss_side_time.py): 2 = no ordering, 1 = no zeroing
+    if (job < EGS_XCDS) return;
+#endif
     if (job < EGS_XCDS) { egs_order_band<NT>(a, (int)job, L); return; }
     // the optimizer's bookkeeping has a workgroup of its own (the first after the ordering ones) so that no zeroing waits for its pow() calls
     const unsigned first = EGS_XCDS + (a.has_tick ? 1u : 0u);
     if (job < first) { if (threadIdx.x < 64) egs_adam_tick(a.tick, threadIdx.x); return; }
     const size_t stride = (size_t)(n_jobs - first) * NT;
+#if defined(EGS_ABL_SIDE) && EGS_ABL_SIDE == 1
+    return;
+#endif
     for (size_t i = (size_t)(job - first) * NT + threadIdx.x; i < a.n4; i += stride) a.acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.block_hot) {   // one thread per (workgroup of k_preprocess, replica): a few hundred hot Gaussians per frame, mostly nothing to do
         const size_t pairs = (size_t)a.hot_blocks * EGS_HOT_REPLICAS;

@@ -417,13 +417,15 @@ int egs_launch_l1_ssim_backward(int channels, int height, int width, const float
     const unsigned per_plane = (unsigned)((strips_x * strips_y + WPB - 1) / WPB + (deferred_partial_sums ? 1 : 0));
     // zeroing workgroups: what is left of the 1024 resident slots (4 per CU) next to the strips, the ordering jobs and the tick; 32 at least
     const unsigned main_wgs = per_plane * (unsigned)channels;
-    const unsigned spare = main_wgs + EGS_XCDS + 1 + 32 <= 1024 ? 1024 - main_wgs - EGS_XCDS - 1 : 32;
+    const unsigned main_pad = ((main_wgs + 7u) / 8u) * 8u;            // loss_logical_block: eight equal runs (the grid of strip workgroups)
+    // (counted against the PADDED grid: one workgroup over the 1024 slots waits ~15 us for a strip to end and then clears its share --
+    // the launch took 24.4 instead of 17.9 us, tools/loss_side_time.py)
+    const unsigned spare = main_pad + EGS_XCDS + 1 + 32 <= 1024 ? 1024 - main_pad - EGS_XCDS - 1 : 32;
     const unsigned side_jobs = side ? egs_prologue_jobs(side->n4, side->has_tick, 64 * WPB, spare) : 0u;
     EgsPrologueArgs none = {};
 #define LB_ARGS height, width, strips_x, strips_y, img, gt, (1.f - lambda_dssim) / n, lambda_dssim / n, upstream_grad, gate, dm_dmu1, dm_dexx, \
                 dm_dexy, dL_dimg, deferred_partial_sums, (size_t)strips_x * strips_y * channels, lambda_dssim, deferred_loss,            \
                 deferred_partial_sums ? loss_running_sum : nullptr, per_plane, main_wgs, side_jobs
-    const unsigned main_pad = ((main_wgs + 7u) / 8u) * 8u;            // loss_logical_block: eight equal runs
     if (side) hipLaunchKernelGGL(k_l1_ssim_backward<true>, dim3(side_jobs + main_pad), dim3(64 * WPB), 0, stream, LB_ARGS, *side);
     else hipLaunchKernelGGL(k_l1_ssim_backward<false>, dim3(main_pad), dim3(64 * WPB), 0, stream, LB_ARGS, none);
 #undef LB_ARGS
