@@ -165,7 +165,9 @@ def set_capacity_hint(instances, device=None):
 
 
 def _ptr(t):
-    return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+    """Device address as a plain int (ctypes converts it for a c_void_p parameter; building the c_void_p object here cost ~7 us per
+    eager step over fifty arguments), None for an absent / empty tensor."""
+    return None if t is None or t.numel() == 0 else t.data_ptr()
 
 
 def _object_rotation_struct(object_rotation, dev, P):

@@ -19,7 +19,7 @@ from . import _hip
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()
 
 
 _stream = _hip.stream_of           # (device) -> c_void_p of its current stream

@@ -23,6 +23,7 @@ class AdamSink:
         self.struct, self.owned, self.ptrs, self._keep = struct, owned, ptrs, keep
         self.split16 = False              # True: features_dc / features_rest / positions are stepped by the spherical-harmonics launch
         self._opt, self._params = opt, tuple(params)
+        self._aux = [opt._aux_of(p) for p in self._params] if opt is not None else []      # the per-parameter derived-state dicts (no weak lookup per step)
         self.keep_grads = False           # True: the backward also writes (and returns) the owned leaves' gradients -- inspection / tests
 
     def mark_stepped(self):
@@ -37,10 +38,11 @@ class AdamSink:
                                        "with optimizer= feed one loss); render all but one of them without optimizer=, or call optimizer.step() "
                                        "between them")
                 self._opt._sunk[p] = bool(self.keep_grads)
-                # k_adam's own per-workgroup step counters do not follow a step taken here (only state["step"] advances): the next
-                # plain step() of this parameter re-seeds them.  Set on EVERY fused backward -- a cached sink (make_sink hit) after a
-                # plain step() cleared the flag would otherwise leave the counters one behind.
-                self._opt._aux_of(p)["counter_stale"] = True
+            # k_adam's own per-workgroup step counters do not follow a step taken here (only state["step"] advances): the next
+            # plain step() of this parameter re-seeds them.  Set on EVERY fused backward -- a cached sink (make_sink hit) after a
+            # plain step() cleared the flag would otherwise leave the counters one behind.
+            for a in self._aux:
+                a["counter_stale"] = True
 
     def check(self, means3D, scales, rotations, sh, sh_rest, own_cov, colors):
         """Called by _C.rasterize_gaussians_backward with the arrays it is about to pass: the owned leaves must be those arrays."""
