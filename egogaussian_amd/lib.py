@@ -148,6 +148,16 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the MI355X rasterizer has no CPU or PyTorch fallback. "
             "Build it first (python -c 'import __graft_entry__ as g; g.build()' or make -C egogaussian_amd/csrc).")
+    # PyTorch-ROCm bundles its own libamdhip64.so while this library links the system one (libamdhip64.so.7): two copies of the HIP
+    # runtime live in the process.  That works as long as TORCH's copy is the one that opened the device first; the other way round --
+    # this library loaded (its kernels registered) before torch's first HIP call -- every launch of ours then fails with
+    # hipErrorNoDevice (found by running build() and smoke() in one process).  So: bring torch's runtime up first when a device exists.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:                  # (a C-ABI user without torch: nothing to order)
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
