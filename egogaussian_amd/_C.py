@@ -213,6 +213,8 @@ def _opt(t):
 
 ACT_LOG_SCALES, ACT_RAW_QUATS, ACT_LOGIT_OPACITY = 1, 2, 4      # include/egs_raster.h: EGS_ACT_*
 ACT_RAW_PARAMETERS = ACT_LOG_SCALES | ACT_RAW_QUATS | ACT_LOGIT_OPACITY
+# include/egs_raster.h: EGS_GRAD_* (which inputs' gradients the caller reads; 0 = all)
+GRAD_MEANS3D, GRAD_MEANS2D, GRAD_SH, GRAD_COLORS, GRAD_OPACITY, GRAD_SCALES, GRAD_ROTATIONS, GRAD_COV3D = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -343,7 +345,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alpha,
                                  debug, activation_flags=0, sh_rest=None, densify_stats=None, guard=None, sink=None,
-                                 prologue_scratch=None, object_rotation=None):
+                                 prologue_scratch=None, object_rotation=None, grad_mask=0):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
            dL_dscales[P,3], dL_drotations[P,4]); with sh_rest, dL_dsh is [P,1,3] and a ninth element dL_dsh_rest[P,M-1,3] follows.
     densify_stats (extension): (xyz_gradient_accum[P,1], denom[P,1], max_radii2D[P] or None), float32, updated in place by the kernel
@@ -352,7 +354,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     sink (extension): an optim.AdamSink -- the leaves it owns take their Adam step inside this backward (include/egs_raster.h,
     egs_backward_adam); their gradients are not produced: those positions of the result are None.
     prologue_scratch (extension): the scratch buffer a preceding egs_l1_ssim_backward_ex prepared for THIS backward (tile order,
-    cleared accumulator, optimizer bookkeeping: fused.l1_ssim_loss(raster_prologue=True)); the backward then starts at its blend kernel."""
+    cleared accumulator, optimizer bookkeeping: fused.l1_ssim_loss(raster_prologue=True)); the backward then starts at its blend kernel.
+    grad_mask (extension, ABI 4): GRAD_* bits of the inputs whose gradient the caller reads (autograd's needs_input_grad), 0 = all.
+    GRAD_COLORS alone with `colors` given -- the reference's label call, /root/reference/gaussian_renderer/render_helper.py:38-54 --
+    takes the colours-only backward: only dL_dcolors is produced, every other position of the result is None."""
     L = _lib.load()
     means3D = _f32c(means3D, "means3D")
     dev = means3D.device
@@ -367,6 +372,18 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     g_alpha = _opt(_f32c(dL_dout_alpha, "dL_dout_alpha"))
     sh_rest = _opt(_f32c(sh_rest, "sh_rest"))
     M = 0 if sh is None else sh.shape[1] + (0 if sh_rest is None else sh_rest.shape[1])
+    if P != 0 and grad_mask == GRAD_COLORS and colors is not None and sink is None and densify_stats is None and object_rotation is None:
+        with _hip.device_ctx(dev):
+            dcolors = torch.empty((P, 3), device=dev, dtype=torch.float32)
+            scratch = prologue_scratch if prologue_scratch is not None else torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
+            _lib.check(L.egs_backward_adam(
+                P, int(degree), M, int(R), _ptr(background), _ptr(means3D), None, None, _ptr(colors), _ptr(scales),
+                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
+                _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
+                _ptr(imageBuffer), _ptr(g_color), None, None, None, _ptr(dcolors), None, None, None, None, None, None, None,
+                None, None, None, None, None, 1 if prologue_scratch is not None else 0, None, GRAD_COLORS, _ptr(scratch), _stream(dev),
+                int(bool(debug))))
+        return None, dcolors, None, None, None, None, None, None
     with _hip.device_ctx(dev):
         e = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
         own_cov = cov3D_precomp is None
@@ -403,7 +420,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(dopacity), _ptr(dmeans3D_arg), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
                 _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
                 C.byref(sink.struct) if owned else None, 1 if prologue_scratch is not None else 0,
-                C.byref(rot_st) if rot_st is not None else None, _ptr(scratch), _stream(dev), int(bool(debug))))
+                C.byref(rot_st) if rot_st is not None else None, 0, _ptr(scratch), _stream(dev), int(bool(debug))))
             if owned:
                 sink.mark_stepped()
         elif P != 0:
@@ -415,7 +432,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(imageBuffer), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(dmeans2D), _ptr(dcolors),
                 _ptr(dopacity), _ptr(dmeans3D), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
                 _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
-                _ptr(scratch), _stream(dev), int(bool(debug))))
+                0, _ptr(scratch), _stream(dev), int(bool(debug))))
     if sh_rest is not None:
         return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots, dsh_rest
     return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots

@@ -24,11 +24,20 @@ GeomLayout geom_layout(int P) {
     L.o.total = off;        off = egs_align(off + sizeof(uint64_t));
     L.bytes = off; return L;
 }
+// spine words: [0, sums) chunk sums of the two-walk bucketing | 32 scratch words | total (u64) | alloc (u64) | tile_start [n_tiles + 2]
+struct SpineWords { size_t flag, total, alloc, tile_start, end; };
+static SpineWords spine_words(size_t sums, size_t n_tiles) {
+    SpineWords w; w.flag = sums; w.total = (sums + 32 + 1) & ~(size_t)1; w.alloc = w.total + 2; w.tile_start = w.alloc + 2; w.end = w.tile_start + n_tiles + 2;
+    return w;
+}
 BinLayout bin_layout(int P, int64_t R, int W, int H) {
     BinLayout L; size_t off = 0; const size_t n = (size_t)(R > 0 ? R : 0);
     const size_t gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const size_t nblocks = egs_bin_blocks(P > 0 ? P : 0), stride = egs_table_stride((uint32_t)nblocks), tab = gx * gy * stride;
     const size_t sums = EGS_BIN_GROUPS * egs_table_chunks(gx * gy, (uint32_t)stride);
+    const EgsBinPlan plan = egs_bin_plan(P > 0 ? P : 0, R > 0 ? R : 0, (int)(gx * gy));
+    const size_t tab_new = ((size_t)plan.max_cols * plan.row * sizeof(uint16_t) + 255) / 256 * 256 + (size_t)plan.max_cols * sizeof(uint32_t);
+    const SpineWords sw = spine_words(sums, gx * gy);
     L.o.key_bits = egs_key_bits_for_tiles((int)(gx * gy));
     L.o.bin_blocks = (int)nblocks;
     L.o.table_stride = (int)stride;
@@ -37,9 +46,9 @@ BinLayout bin_layout(int P, int64_t R, int W, int H) {
     L.o.point_list = off; off = egs_align(off + n * sizeof(uint32_t));          // first: the backward needs nothing else
     L.o.pairs = off;      off = egs_align(off + n * sizeof(uint64_t));
     L.o.scratch = off;    off = egs_align(off + n * sizeof(uint64_t));
-    L.o.table = off;      off = egs_align(off + (n ? tab : 0) * sizeof(uint32_t));
-    L.o.spine = off;      off = egs_align(off + (n ? sums + 64 + 4 : 0) * sizeof(uint32_t));
-    L.o.total = L.o.spine + ((sums + 32 + 1) & ~(size_t)1) * sizeof(uint32_t);
+    L.o.table = off;      off = egs_align(off + (n ? (tab * sizeof(uint32_t) > tab_new ? tab * sizeof(uint32_t) : tab_new) : 0));
+    L.o.spine = off;      off = egs_align(off + (n ? sw.end : 0) * sizeof(uint32_t));
+    L.o.total = L.o.spine + sw.total * sizeof(uint32_t);
     L.bytes = off; return L;
 }
 ImgLayout img_layout(int W, int H) {
@@ -67,6 +76,12 @@ EgsBinPtrs bin_ptrs(void* buf, int P, int64_t R, int W, int H) {
     p.point_list = (uint32_t*)(b + L.o.point_list); p.table = (uint32_t*)(b + L.o.table); p.chunk_sum = (uint32_t*)(b + L.o.spine);
     p.total = (uint64_t*)(b + L.o.total);
     p.flag = (uint32_t*)p.total - 32;                                 // (the 32 words before `total`)
+    const size_t nt = (size_t)((W + EGS_TILE - 1) / EGS_TILE) * (size_t)((H + EGS_TILE - 1) / EGS_TILE);
+    const EgsBinPlan plan = egs_bin_plan(P > 0 ? P : 0, R > 0 ? R : 0, (int)nt);
+    p.alloc = (unsigned long long*)(p.total + 1);
+    p.tile_start = (uint32_t*)(p.total + 2);
+    p.rel = (uint16_t*)p.table;
+    p.colbase = (uint32_t*)((char*)p.table + ((size_t)plan.max_cols * plan.row * sizeof(uint16_t) + 255) / 256 * 256);
     return p;
 }
 EgsImgPtrs img_ptrs(void* buf, int W, int H) {
@@ -307,6 +322,7 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
         b_spec = bin_ptrs(binning_buffer, P, capacity, width, height);
         const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
         n_sums = EGS_BIN_GROUPS * egs_table_chunks(nt, egs_table_stride(egs_bin_blocks(P)));
+        if (!egs_bin_legacy) { b_spec.chunk_sum = (uint32_t*)b_spec.alloc; n_sums = 2; }     // the one-walk bucketing: its allocation word
     }
     // ... and carries the placement of the forward blend's tiles (backward_prologue.h), computed from the costs the image buffer holds
     EgsImgPtrs im_spec = img_ptrs(image_buffer, width, height);
@@ -421,16 +437,39 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
                  const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
                  float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
                  float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
-                 const uint32_t* skip_flag, const egs_adam_sink* sink, int prologue_done, const egs_object_rotation* rot, void* scratch,
+                 const uint32_t* skip_flag, const egs_adam_sink* sink, int prologue_done, const egs_object_rotation* rot, int grad_mask, void* scratch,
                  void* stream, int debug) {
     int rc = check_dims(P, width, height); if (rc) return rc;
     EgsObjRot orot; rc = obj_rot_args(rot, scales, orot); if (rc) return rc;
     if (P == 0) return 0;
     if (R < 0 || R >= (1ll << 31)) return EGS_ERR_RANGE;
+    if (grad_mask & ~EGS_GRAD_MASK_BITS) return EGS_ERR_ARG;
+    // Only the precomputed colours' gradient is wanted (the reference's label call): a blend that sums w dL/dC alone, no preprocess backward
+    const bool colors_only = grad_mask == EGS_GRAD_COLORS && colors_precomp && !sink && !stat_grad_accum;
     if (!background || !means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer ||
-        !dL_dout_color || !dL_dmeans2D || !scratch)
+        !dL_dout_color || (!dL_dmeans2D && !colors_only) || !scratch)
         return EGS_ERR_ARG;
     if (misaligned(geom_buffer, binning_buffer, image_buffer) || ((uintptr_t)scratch & 15u)) return EGS_ERR_ARG;
+    if (colors_only) {
+        if (!dL_dcolors || (R > 0 && !binning_buffer)) return EGS_ERR_ARG;
+        rc = check_modes(shs, colors_precomp, scales, rotations, cov3D_precomp, activation_flags); if (rc) return rc;
+        hipStream_t s = (hipStream_t)stream;
+        EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
+        float* grad_acc = (float*)scratch;
+        if (R == 0) return (int)egs_launch_zero_u32((uint32_t*)dL_dcolors, (size_t)P * 3, s);
+        EgsBinPtrs b = bin_ptrs(const_cast<void*>(binning_buffer), P, R, width, height);
+        EgsImgPtrs im = img_ptrs(const_cast<void*>(image_buffer), width, height);
+        if (!prologue_done) EGS_TRY(egs_launch_backward_prologue(P, width, height, im, grad_acc, g.block_hot, nullptr, s));
+        egs_prof_start(EGS_K_RENDER_BWD, s);
+        EGS_TRY(egs_launch_render_backward(P, width, height, background, g, b.point_list, im, dL_dout_color, nullptr, nullptr, grad_acc, 1, s));
+        egs_prof_stop(EGS_K_RENDER_BWD, s);
+        EGS_SYNC_IF_DEBUG(s);
+        egs_prof_start(EGS_K_PREPROCESS_BWD, s);
+        EGS_TRY(egs_launch_colors_from_acc(P, grad_acc, g.clamped, radii, dL_dcolors, s));
+        egs_prof_stop(EGS_K_PREPROCESS_BWD, s);
+        EGS_SYNC_IF_DEBUG(s);
+        return 0;
+    }
     // leaves a fused optimizer owns: their gradient arrays are optional
     const bool sh_apart = shs && (sh_coeffs > 1 || shs_rest);
     bool own[EGS_SINK_LEAVES] = { false, false, false, false, false, false };
@@ -488,7 +527,7 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
         const uint32_t* point_list = b.point_list;
         if (!prologue_done) EGS_TRY(egs_launch_backward_prologue(P, width, height, im, grad_acc, g.block_hot, sink ? &tick : nullptr, s));
         egs_prof_start(EGS_K_RENDER_BWD, s);                         // (the stage is the blend kernel alone)
-        EGS_TRY(egs_launch_render_backward(P, width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth, dL_dout_alpha, grad_acc, s));
+        EGS_TRY(egs_launch_render_backward(P, width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth, dL_dout_alpha, grad_acc, 0, s));
         egs_prof_stop(EGS_K_RENDER_BWD, s);
         EGS_SYNC_IF_DEBUG(s);
     }
@@ -513,13 +552,14 @@ int egs_backward(int P, int sh_degree, int sh_coeffs, int64_t R, const float* ba
                  const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
                  float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
                  float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
-                 const uint32_t* skip_flag, void* scratch, void* stream, int debug) {
-    if (!dL_dcolors || !dL_dopacity || !dL_dmeans3D) return P == 0 ? 0 : EGS_ERR_ARG;
+                 const uint32_t* skip_flag, int grad_mask, void* scratch, void* stream, int debug) {
+    if (grad_mask == EGS_GRAD_COLORS && colors_precomp && !stat_grad_accum) { if (!dL_dcolors) return P == 0 ? 0 : EGS_ERR_ARG; }
+    else if (!dL_dcolors || !dL_dopacity || !dL_dmeans3D) return P == 0 ? 0 : EGS_ERR_ARG;
     return backward_impl(P, sh_degree, sh_coeffs, R, background, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations,
                          cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, geom_buffer,
                          binning_buffer, image_buffer, dL_dout_color, dL_dout_depth, dL_dout_alpha, dL_dmeans2D, dL_dcolors, dL_dopacity,
                          dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscales, dL_drotations, stat_grad_accum, stat_denom, stat_max_radii,
-                         skip_flag, nullptr, 0, nullptr, scratch, stream, debug);
+                         skip_flag, nullptr, 0, nullptr, grad_mask, scratch, stream, debug);
 }
 
 int egs_backward_adam(int P, int sh_degree, int sh_coeffs, int64_t R, const float* background, const float* means3D,
@@ -530,13 +570,13 @@ int egs_backward_adam(int P, int sh_degree, int sh_coeffs, int64_t R, const floa
                       const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans2D,
                       float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
                       float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
-                      const uint32_t* skip_flag, const egs_adam_sink* sink, int prologue_done, const egs_object_rotation* rot, void* scratch,
+                      const uint32_t* skip_flag, const egs_adam_sink* sink, int prologue_done, const egs_object_rotation* rot, int grad_mask, void* scratch,
                       void* stream, int debug) {
     return backward_impl(P, sh_degree, sh_coeffs, R, background, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations,
                          cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, geom_buffer,
                          binning_buffer, image_buffer, dL_dout_color, dL_dout_depth, dL_dout_alpha, dL_dmeans2D, dL_dcolors, dL_dopacity,
                          dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscales, dL_drotations, stat_grad_accum, stat_denom, stat_max_radii,
-                         skip_flag, sink, prologue_done, rot, scratch, stream, debug);
+                         skip_flag, sink, prologue_done, rot, grad_mask, scratch, stream, debug);
 }
 
 int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,

@@ -58,9 +58,12 @@ __global__ __launch_bounds__(1024) void k_backward_prologue(EgsPrologueArgs a) {
 }
 
 // 8 waves per SIMD (64 VGPRs, one spilled): every wave of a 960x540 frame is resident from the start (-2% vs 70 VGPRs / 7 waves)
-// HAS_DA: upstream gradients on the depth and / or alpha outputs exist (the training loss uses colour only: three FMAs and a
+// MODE 2: upstream gradients on the depth and / or alpha outputs exist; MODE 1: colour only (the training loss: three FMAs and a
 // multiply less per (wave, splat) visit of a kernel that is 86 % VALU-busy).
-template <bool HAS_DA>
+// MODE 0 (ABI 4, egs_backward grad_mask == EGS_GRAD_COLORS): only dL/dcolors_precomp is wanted -- the reference's label call
+// (/root/reference/gaussian_renderer/render_helper.py:38-54 detaches every geometric input).  dL/dcolour_c = sum over pixels of
+// w dL/dC_c with w = alpha T: no dL/dalpha recurrence, no background term, no moments -- three sums per (wave, splat) instead of ten.
+template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_render_backward(
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
@@ -68,6 +71,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ tile_order, float* __restrict__ grad_acc,
     const uint32_t* __restrict__ quad_visits, const uint32_t hot_base /* first float of the hot replica lines inside grad_acc */,
     const uint32_t hot_slots /* lines per replica = ceil(P / 256) * EGS_HOT_PER_BLOCK */) {
+    constexpr bool HAS_DA = MODE == 2;
+    constexpr int NV = MODE == 0 ? 3 : 10;                            // sums per (wave, splat)
     __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
     __shared__ __attribute__((aligned(16))) float red[4][5 * 64];
     __shared__ uint32_t quad_claimed;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (HAS_DA && dL_ddepth) g_d = dL_ddepth[pix];
         if (HAS_DA && dL_dalpha) g_a = dL_dalpha[pix];
     }
-    const float bg_term = -T_final * (bg[0] * g_r + bg[1] * g_g + bg[2] * g_b);
+    const float bg_term = MODE == 0 ? 0.f : -T_final * (bg[0] * g_r + bg[1] * g_g + bg[2] * g_b);
     uint32_t wmax = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
@@ -125,8 +130,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // stage 2/3 of the reduction: lane 4v+g (v < 10) sums partials [8g, 8g+8) of value v; lane 4v publishes it.
     // After the permlane32 fold, value v lives in register row v/2, lanes (v%2)*32 .. +31.
     const unsigned rv = lane >> 2, rg = lane & 3;
-    const float4* red_src = reinterpret_cast<const float4*>(myred + (rv < 10 ? (rv >> 1) * 64 + (rv & 1) * 32 + rg * 8 : 0));
-    const int slot = (rg == 0 && rv < 10) ? (int)rv : -1;
+    const float4* red_src = reinterpret_cast<const float4*>(myred + (rv < (unsigned)NV ? (rv >> 1) * 64 + (rv & 1) * 32 + rg * 8 : 0));
+    const int slot = (rg == 0 && rv < (unsigned)NV) ? (int)rv + (MODE == 0 ? 6 : 0) : -1;      // (MODE 0: the three colour slots of the line)
 
     // S = the blended colour-gradient term of everything BEHIND the splat being processed (U of the header), kept "ready for the
     // next contributor": after a splat with (a, u) it becomes a u + (1 - a) S -- one state word and one select instead of three
@@ -200,6 +205,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const float rcp = __builtin_amdgcn_rcpf(1.f - a);
             const float Tn = T * rcp;                                   // transmittance in front of this splat
             const float w = a * Tn;
+            if (MODE == 0) {
+                T = Tn;
+                const float v6 = w * g_r, v7 = w * g_g, v8 = w * g_b;
+                (void)t; (void)m; (void)nn; (void)S; (void)bg_term;
+                myred[0 * 64 + lane] = fold32(v6, v7); myred[1 * 64 + lane] = fold32(v8, 0.f);
+            } else {
             const float u = HAS_DA ? fmaf(s1.z, g_r, fmaf(s1.w, g_g, fmaf(s2.x, g_b, fmaf(s2.y, g_d, g_a))))
                                    : fmaf(s1.z, g_r, fmaf(s1.w, g_g, s2.x * g_b));
             float dLda = fmaf(bg_term, rcp, (u - S) * Tn);
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             // 64-lane sums of v0..v9 (see the header): swap-fold, LDS regroup, quad DPP
             myred[0 * 64 + lane] = fold32(v0, v1); myred[1 * 64 + lane] = fold32(v2, v3); myred[2 * 64 + lane] = fold32(v4, v5);
             myred[3 * 64 + lane] = fold32(v6, v7); myred[4 * 64 + lane] = fold32(v8, v9);
+            }
             const float4 pa = red_src[0], pb = red_src[1];
             float out = ((pa.x + pa.y) + (pa.z + pa.w)) + ((pb.x + pb.y) + (pb.z + pb.w));
             out = dpp_add<0xB1>(out);       // quad_perm [1,0,3,2]
@@ -261,17 +273,49 @@ hipError_t egs_launch_backward_prologue(int P, int W, int H, EgsImgPtrs im, floa
 
 hipError_t egs_launch_render_backward(int P, int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
-                                      const float* dL_dalpha, float* grad_acc, hipStream_t s) {
+                                      const float* dL_dalpha, float* grad_acc, int colors_only, hipStream_t s) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
     if (n_tiles == 0) return hipSuccess;
-    if (dL_ddepth || dL_dalpha)
-        hipLaunchKernelGGL(k_render_backward<true>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
-                           im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
-                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles, (uint32_t)((size_t)P * EGS_GRAD_STRIDE), (uint32_t)egs_hot_slots((size_t)P));
-    else
-        hipLaunchKernelGGL(k_render_backward<false>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
-                           im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,
-                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles, (uint32_t)((size_t)P * EGS_GRAD_STRIDE), (uint32_t)egs_hot_slots((size_t)P));
+#define EGS_BWD_LAUNCH(MODE) hipLaunchKernelGGL(k_render_backward<MODE>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles, \
+                           im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, \
+                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles, (uint32_t)((size_t)P * EGS_GRAD_STRIDE), (uint32_t)egs_hot_slots((size_t)P))
+    if (colors_only) EGS_BWD_LAUNCH(0);
+    else if (dL_ddepth || dL_dalpha) EGS_BWD_LAUNCH(2);
+    else EGS_BWD_LAUNCH(1);
+#undef EGS_BWD_LAUNCH
+    return hipGetLastError();
+}
+
+// MODE 0's second half: dL/dcolors_precomp[i] = the three colour sums of Gaussian i's accumulator line (+ its replica lines if it is hot).
+namespace {
+__global__ __launch_bounds__(256) void k_colors_from_acc(int P, const float* __restrict__ grad_acc, const float* __restrict__ hot_acc, size_t hot_slots,
+                                                         const uint8_t* __restrict__ clamped, const int32_t* __restrict__ radii,
+                                                         float* __restrict__ dcolors) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    if (radii[i] <= 0) {                                              // never blended; its `clamped` byte (the hot code) is not even written
+        dcolors[3 * (size_t)i] = 0.f; dcolors[3 * (size_t)i + 1] = 0.f; dcolors[3 * (size_t)i + 2] = 0.f;
+        return;
+    }
+    const float4* ga = reinterpret_cast<const float4*>(grad_acc + (size_t)i * EGS_GRAD_STRIDE);
+    const float4 a1 = ga[1], a2 = ga[2];
+    float r = a1.z, g = a1.w, b = a2.x;
+    const uint32_t code = (uint32_t)clamped[i] >> 3;
+    if (code) {
+        const float* hl = hot_acc + ((size_t)(i >> 8) * EGS_HOT_PER_BLOCK + (code - 1u)) * EGS_HOT_LINE;
+        for (unsigned rp = 0; rp < EGS_HOT_REPLICAS; rp++) {
+            const float4* h = reinterpret_cast<const float4*>(hl + (size_t)rp * hot_slots * EGS_HOT_LINE);
+            const float4 h1 = h[1], h2 = h[2];
+            r += h1.z; g += h1.w; b += h2.x;
+        }
+    }
+    dcolors[3 * (size_t)i] = r; dcolors[3 * (size_t)i + 1] = g; dcolors[3 * (size_t)i + 2] = b;
+}
+}  // namespace
+hipError_t egs_launch_colors_from_acc(int P, const float* grad_acc, const uint8_t* clamped, const int32_t* radii, float* dcolors, hipStream_t s) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_colors_from_acc, dim3((P + 255) / 256), dim3(256), 0, s, P, grad_acc, grad_acc + (size_t)P * EGS_GRAD_STRIDE,
+                       egs_hot_slots((size_t)P), clamped, radii, dcolors);
     return hipGetLastError();
 }

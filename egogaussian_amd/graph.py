@@ -287,12 +287,15 @@ class GraphedTrainStep:
         self._sets = None
         return self.capture(cam, gt, warmup=warmup, capacity_margin=capacity_margin, capacity_cams=capacity_cams)
 
-    def __call__(self, cam, gt=None, accum_R=None, gate=None):
+    def __call__(self, cam, gt=None, accum_R=None, gate=None, ready=None):
         """One training iteration (steps_per_replay of them): copy inputs in, replay.  Returns the (device, static) loss tensor of
         the last iteration (`self.losses` has all).  Either (camera, ground-truth image[, accum_R][, gate]) or packed frames from
-        pack_frame(): one for a single-iteration step, a [S, frame] tensor (one copy) or a list of S for steps_per_replay = S."""
+        pack_frame(): one for a single-iteration step, a [S, frame] tensor (one copy) or a list of S for steps_per_replay = S.
+        ready (double_buffer only): a torch.cuda.Event recorded after the packed frames were COMPLETELY written; the side-stream copy
+        waits for it.  Without it the copy waits for everything enqueued on the current stream so far -- always correct, but frames
+        produced on the current stream right before the call then serialise behind the replay that is still running."""
         if gt is None and self._sets is not None:
-            return self._call_double_buffered(cam)
+            return self._call_double_buffered(cam, ready)
         if gt is None:
             if isinstance(cam, (list, tuple)):
                 for k, fr in enumerate(cam):
@@ -318,22 +321,28 @@ class GraphedTrainStep:
             self.check()
         return self.loss
 
-    def _call_double_buffered(self, frames):
+    def _call_double_buffered(self, frames, ready=None):
         """Packed frames, two captured graphs: the copy into set b's static frames runs on a side stream as soon as set b's previous
-        replay has finished, i.e. under the replay of the other set that is still running."""
+        replay has finished, i.e. under the replay of the other set that is still running.  The copy reads the caller's tensors on
+        that side stream, so it must be ordered after whatever WROTE them: the caller's `ready` event, else the current stream as it
+        stands now; and the tensors are marked as used by the side stream so that the allocator does not recycle them under the copy."""
         b = self._calls & 1
         st = self._sets[b]
         main = torch.cuda.current_stream(st["frames"].device)
         if self._used[b]:
             self._copy_stream.wait_event(self._done[b])
+        if ready is not None:
+            self._copy_stream.wait_event(ready)
         else:
-            self._copy_stream.wait_stream(main)                      # first use: after whatever produced the frames / the capture
+            self._copy_stream.wait_stream(main)                      # whatever produced the frames (and, the first time, the capture)
         with torch.cuda.stream(self._copy_stream):
             if isinstance(frames, (list, tuple)):
                 for k, fr in enumerate(frames):
                     st["frames"][k].copy_(fr, non_blocking=True)
+                    fr.record_stream(self._copy_stream)
             else:
                 st["frames"].copy_(frames.view(st["frames"].shape), non_blocking=True)
+                frames.record_stream(self._copy_stream)
             self._copied[b].record(self._copy_stream)
         if getattr(self.pc, "model_version", 0) != self._model_version:
             raise RuntimeError("GraphedTrainStep: the model reallocated its arrays (CapacityGaussians.grow) after this step was captured; "

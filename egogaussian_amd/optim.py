@@ -31,12 +31,6 @@ class AdamSink:
         alone even if a gradient reached them (keep_grads)."""
         if self._opt is not None:
             for p in self._params:
-                if p in self._opt._sunk:
-                    # the sole-consumer precondition of egs_backward_adam (include/egs_raster.h), enforced where it can be seen: a second
-                    # rasterizer backward of the same iteration has just stepped this leaf again with its partial gradient
-                    raise RuntimeError("FusedAdam: a parameter took its Adam step inside two rasterizer backwards of one iteration (two renders "
-                                       "with optimizer= feed one loss); render all but one of them without optimizer=, or call optimizer.step() "
-                                       "between them")
                 self._opt._sunk[p] = bool(self.keep_grads)
             # k_adam's own per-workgroup step counters do not follow a step taken here (only state["step"] advances): the next
             # plain step() of this parameter re-seeds them.  Set on EVERY fused backward -- a cached sink (make_sink hit) after a
@@ -45,7 +39,16 @@ class AdamSink:
                 a["counter_stale"] = True
 
     def check(self, means3D, scales, rotations, sh, sh_rest, own_cov, colors):
-        """Called by _C.rasterize_gaussians_backward with the arrays it is about to pass: the owned leaves must be those arrays."""
+        """Called by _C.rasterize_gaussians_backward with the arrays it is about to pass, BEFORE anything is enqueued: the owned leaves
+        must be those arrays, and none of them may have taken a fused step already in this iteration (the sole-consumer precondition of
+        egs_backward_adam, include/egs_raster.h) -- raising here leaves parameters, moments and step counts untouched."""
+        if self._opt is not None:
+            for p in self._params:
+                if p in self._opt._sunk:
+                    raise RuntimeError("FusedAdam: a parameter would take its Adam step inside a second rasterizer backward since the last "
+                                       "optimizer.step() / zero_grad() (two renders with optimizer= feed one loss, or an iteration ran backward "
+                                       "without step() or zero_grad()); render all but one of them without optimizer=, or call "
+                                       "optimizer.step() / zero_grad() between them.  Nothing was enqueued: the state is unchanged")
         got = {_lib.SINK_MEANS3D: means3D, _lib.SINK_SCALES: scales, _lib.SINK_ROTATIONS: rotations, _lib.SINK_SH: sh, _lib.SINK_SH_REST: sh_rest}
         for leaf, t in got.items():
             if leaf in self.owned and (t is None or t.data_ptr() != self.ptrs[leaf]):
@@ -77,6 +80,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         """torch's zero_grad walks foreach / profiler machinery (~27 us for six parameters); dropping the gradients is a loop."""
+        self._sunk = WeakIdKeyDictionary()     # a new iteration: whatever the last backward stepped by itself is history (an iteration may
+                                               # legitimately end without step(): a skipped one, the last one, one that steps another optimizer)
         if not set_to_none:
             return super().zero_grad(set_to_none=False)
         for group in self.param_groups:

@@ -83,11 +83,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         if grad_alpha is None:
             grad_alpha = torch.empty(0, device=dev)
         split = sh_rest.numel() != 0
+        # autograd's view of who reads which gradient, for the library (include/egs_raster.h EGS_GRAD_*): inputs order of forward()
+        need = ctx.needs_input_grad
+        grad_mask = ((_C.GRAD_MEANS3D if need[0] else 0) | (_C.GRAD_MEANS2D if need[1] else 0) | (_C.GRAD_SH if (need[2] or need[10]) else 0) |
+                     (_C.GRAD_COLORS if need[3] else 0) | (_C.GRAD_OPACITY if need[4] else 0) | (_C.GRAD_SCALES if need[5] else 0) |
+                     (_C.GRAD_ROTATIONS if need[6] else 0) | (_C.GRAD_COV3D if need[7] else 0))
         grads = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos, geom,
             ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags, sh_rest if split else None, ctx.densify_stats, ctx.guard,
-            ctx.sink, ctx.prologue_scratch, ctx.object_rotation)
+            ctx.sink, ctx.prologue_scratch, ctx.object_rotation, grad_mask)
         ctx.prologue_scratch = None
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = grads[:8]
         none_if_absent = lambda g, x: g if (g is not None and x.numel() != 0) else None

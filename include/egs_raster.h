@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 3
+#define EGS_ABI_VERSION 4
 #define EGS_TILE 16                 /* tile edge in pixels; part of the parity contract */
 #define EGS_MAX_SH_DEGREE 3
 
@@ -231,6 +231,23 @@ int egs_forward_enqueue(
 int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts /*HOST*/);
 
 /* ---- backward  (upstream: render backward + computeCov2D backward + preprocess backward) ------- */
+/* grad_mask (ABI 4): which inputs' gradients the caller is going to read -- autograd's ctx.needs_input_grad.  EGS_GRAD_ALL (0) = all of
+ * them, the behaviour of ABI <= 3.  The library uses it to skip work; the one combination it acts on today is colors_precomp given and
+ * grad_mask == EGS_GRAD_COLORS -- the reference's label call, which detaches every geometric input
+ * (/root/reference/gaussian_renderer/render_helper.py:38-54; 30 000 times in /root/reference/trainers/train_static.py:105-109): the
+ * blend then accumulates w * dL/dC only (no dL/dalpha recurrence, no moments, no background term), the preprocess backward is not
+ * launched, ONLY dL_dcolors is written and every other dL_d* output may be NULL.  Any other mask: everything is computed and every
+ * output must be given as before. */
+#define EGS_GRAD_ALL        0
+#define EGS_GRAD_MEANS3D    1
+#define EGS_GRAD_MEANS2D    2
+#define EGS_GRAD_SH         4
+#define EGS_GRAD_COLORS     8
+#define EGS_GRAD_OPACITY    16
+#define EGS_GRAD_SCALES     32
+#define EGS_GRAD_ROTATIONS  64
+#define EGS_GRAD_COV3D      128
+#define EGS_GRAD_MASK_BITS  255
 int egs_backward(
     int P, int sh_degree, int sh_coeffs, int64_t R,
     const float* background, const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp,
@@ -251,6 +268,7 @@ int egs_backward(
      * (/root/reference/trainers/train_static.py:125).  Same arithmetic as egs_densify_stats, one launch less per iteration. */
     float* stat_grad_accum /*[P] in/out or NULL*/, float* stat_denom /*[P] in/out or NULL*/, float* stat_max_radii /*[P] in/out or NULL*/,
     const uint32_t* skip_flag /*device uint32[1] or NULL: non-zero = leave the three statistics untouched (overflowed frame)*/,
+    int grad_mask /*EGS_GRAD_* bits, 0 = all (see above)*/,
     void* scratch /* egs_backward_scratch_bytes(P) */, void* stream, int debug);
 
 /* ---- backward with the optimizer inside (ABI 2 addition; no upstream counterpart: upstream returns the gradients to autograd
@@ -309,6 +327,7 @@ int egs_backward_adam(
     const egs_adam_sink* sink /*HOST; NULL = no leaf is fused*/,
     int prologue_done /*non-zero: egs_l1_ssim_backward_ex carried this frame's egs_backward_prologue (same scratch, same sink)*/,
     const egs_object_rotation* rot /*HOST or NULL: as given to the forward*/,
+    int grad_mask /*as egs_backward; the colours-only path is taken only with sink == NULL*/,
     void* scratch, void* stream, int debug);
 
 /* ---- frustum test only  (upstream: markVisible) -------------------------------------------------- */

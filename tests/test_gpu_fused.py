@@ -464,24 +464,40 @@ def test_double_buffered_graph_step_matches_single_buffered():
         gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
     frames = torch.stack([pack_frame(c, g_) for c, g_ in zip(cams, gts)])
     res = {}
-    for db in (False, True):
+    for db in (False, True, "fresh", "fresh_event"):
         pc = SynthGaussians(student, device=DEV)
         opt = FusedAdam([{"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3}, {"params": [pc._opacity], "lr": 0.05},
                          {"params": [pc._scaling], "lr": 5e-3}, {"params": [pc._rotation], "lr": 1e-3}], lr=0.0, eps=1e-15, capturable=True)
-        step = GraphedTrainStep(pc, opt, bg, steps_per_replay=S, double_buffer=db).capture(cams[0], gts[0], warmup=2)
+        step = GraphedTrainStep(pc, opt, bg, steps_per_replay=S, double_buffer=bool(db)).capture(cams[0], gts[0], warmup=2)
         losses = []
+        producer = torch.cuda.Stream()
         for c in range(CALLS):
             k = (c * S) % (len(cams) - S + 1)
-            step(frames[k:k + S])
+            if db == "fresh":
+                # the frames are WRITTEN on the current stream right before the call and dropped right after it -- the side-stream
+                # copy must wait for the write and keep the allocation alive (a filler of the same size is allocated at once)
+                fr = torch.empty_like(frames[k:k + S]); fr.fill_(float("nan")); fr.copy_(frames[k:k + S])
+                step(fr); del fr
+                junk = torch.full_like(frames[k:k + S], float("nan")); del junk
+            elif db == "fresh_event":
+                producer.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(producer):
+                    fr = torch.empty_like(frames[k:k + S]); fr.fill_(float("nan")); fr.copy_(frames[k:k + S])
+                    ev = torch.cuda.Event(); ev.record(producer)
+                step(fr, ready=ev); fr.record_stream(torch.cuda.current_stream()); del fr
+            else:
+                step(frames[k:k + S])
             losses.append([l.clone() for l in step.losses])
         torch.cuda.synchronize()
         assert step.ok()
         res[db] = (pc, opt, [[float(l) for l in ls] for ls in losses], float(step.loss_sum))
-    (pa, oa, la, sa), (pb, ob, lb, sb) = res[False], res[True]
-    assert float(oa.state[pa._xyz]["step"]) == float(ob.state[pb._xyz]["step"]) == 2 + S * CALLS
-    for x, y in zip(la, lb):
-        assert all(abs(u - v) <= 2e-3 * abs(u) for u, v in zip(x, y)), (x, y)
-    assert abs(sa - sb) <= 2e-3 * abs(sa)
-    for a in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"):
-        u, v = getattr(pa, a).detach(), getattr(pb, a).detach()
-        assert float((u - v).abs().mean()) <= 2e-4 * float(u.abs().mean()) + 1e-7, a
+    (pa, oa, la, sa) = res[False]
+    for mode in (True, "fresh", "fresh_event"):
+        (pb, ob, lb, sb) = res[mode]
+        assert float(oa.state[pa._xyz]["step"]) == float(ob.state[pb._xyz]["step"]) == 2 + S * CALLS
+        for x, y in zip(la, lb):
+            assert all(abs(u - v) <= 2e-3 * abs(u) for u, v in zip(x, y)), (mode, x, y)
+        assert abs(sa - sb) <= 2e-3 * abs(sa)
+        for a in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"):
+            u, v = getattr(pa, a).detach(), getattr(pb, a).detach()
+            assert float((u - v).abs().mean()) <= 2e-4 * float(u.abs().mean()) + 1e-7, (mode, a)

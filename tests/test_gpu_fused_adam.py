@@ -177,10 +177,17 @@ def test_two_fused_consumers_in_one_iteration_are_refused():
     a = render(cams[0], pc, Pipe, bg, optimizer=opt)
     b = render(cams[1], pc, Pipe, bg, optimizer=opt)
     loss = l1_ssim_loss(a["render"], gts[0], 0.2) + l1_ssim_loss(b["render"], gts[1], 0.2)
-    with pytest.raises(RuntimeError, match="two rasterizer backwards"):
+    with pytest.raises(RuntimeError, match="second rasterizer backward"):
         loss.backward()
-    opt._sunk.clear(); opt.zero_grad(set_to_none=True)
     torch.cuda.synchronize()
+    # the refusal comes BEFORE the second launch -- exactly one step was taken (by the first of the two backwards to run)
+    assert all(float(opt.state[p]["step"]) == 1.0 for g in opt.param_groups for p in g["params"])
+    opt.zero_grad(set_to_none=True)                                   # a new iteration (no step() in between: zero_grad() is enough)
+    out = render(cams[2], pc, Pipe, bg, optimizer=opt)
+    l1_ssim_loss(out["render"], gts[2], 0.2).backward()               # an iteration that ends without step() ...
+    opt.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    assert all(float(opt.state[p]["step"]) == 2.0 for g in opt.param_groups for p in g["params"])
     # one fused consumer per iteration, iteration after iteration, is the supported use
     for k in range(2):
         out = render(cams[k], pc, Pipe, bg, optimizer=opt)
