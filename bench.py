@@ -185,6 +185,146 @@ def config_leg(dev, N, H, W, forward_only, iters=30, log_scale_shift=0.0, scene=
     return leg
 
 
+class _ReferenceSurface:
+    """A model seen through the attribute names the REFERENCE's render() and trainers use and nothing else
+    (/root/reference/gaussian_renderer/__init__.py:18-107, scene/gaussian_model.py:125-200): this package's render() finds none of its
+    optional hooks (raw parameters, split features, fused producers) and takes the reference's route -- get_covariance() ->
+    covariance_activation, get_opacity, get_features."""
+    _ALLOWED = ("get_xyz", "get_opacity", "get_scaling", "get_rotation", "get_features", "get_covariance", "get_rotated_covariance", "get_label",
+                "get_is_object", "active_sh_degree", "max_sh_degree", "_xyz", "_is_object", "_label")
+
+    def __init__(self, model):
+        object.__setattr__(self, "_m", model)
+
+    def __getattr__(self, name):
+        if name in _ReferenceSurface._ALLOWED:
+            return getattr(object.__getattribute__(self, "_m"), name)
+        raise AttributeError(name)
+
+
+def unchanged_trainer_legs(dev, N, H, W, steps, warmup):
+    """What a reference trainer gets WITHOUT editing its loop (bench line: `reference_shaped_step`, `label_phase_shape`).
+    The model is driven through the reference's attribute surface only (_ReferenceSurface), the loop is the reference's
+    (/root/reference/trainers/train_static.py:67-138): render(), hand-mask gradient hook, l1_loss + ssim composed with torch scalars,
+    loss.backward(), loss.item() EVERY iteration (the reference logs it), optimizer.step(), zero_grad.  `installed`: what
+    egogaussian_amd.install() puts behind those names -- HIP l1_loss / ssim, HIP covariance producers, FusedAdam (patching.py; the
+    reference itself is not on the GPU box, so the replacements are taken from the package directly); `import_swap_only`: PyTorch
+    ops behind them (the two import names swapped and nothing else: round 4's 240 it/s).
+    label_phase_shape: the object-label phase of the same loop (train_static.py:78,105-110): render() forward (its image is not part
+    of that phase's loss), get_render_label() forward, channel mean, hook, BCEWithLogits against the object mask, backward -- which is
+    the colours-only backward (egs_backward grad_mask == EGS_GRAD_COLORS) -- loss.item(), step."""
+    import torch.nn as nn
+    from egogaussian_amd import lib as egs_lib, _C, patching, losses
+    from egogaussian_amd.adapter import attach
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render, get_render_label
+    teacher = make_scene(N, H, W, seed=0)
+    bg = torch.zeros(3, device=dev)
+    n_fr = min(32, steps + warmup)
+    cams = [make_camera(k, H, W, device=dev) for k in range(n_fr)]
+    with torch.no_grad():
+        tpc = SynthGaussians(teacher, device=dev, requires_grad=False)
+        gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
+        del tpc
+    gen = torch.Generator().manual_seed(11)
+    hand = [(torch.rand(1, H, W, generator=gen) < 0.1).float().to(dev) for _ in range(4)]          # hand masks: 10 % of the pixels gated
+    objm = [(torch.rand(1, H, W, generator=gen) < 0.3).float().to(dev) for _ in range(4)]          # object masks
+    out = {}
+
+    def timed(step_fn):
+        for i in range(warmup):
+            step_fn(i)
+        torch.cuda.synchronize()
+        egs_lib.profile_begin(max_records=32 * (steps + 8))
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_fn(warmup + i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        st = egs_lib.profile_end()
+        return el, {k: (round(ms / n, 4), n) for k, (ms, n) in st.items() if n}
+
+    for mode in ("installed", "import_swap_only"):
+        model = SynthGaussians(perturb_student(teacher), device=dev, fused=False)                 # fused=False: PyTorch ops behind every getter
+        model.training_setup(optimizer_cls=torch.optim.Adam)
+        if mode == "installed":
+            l1_loss, ssim = patching.make_loss_functions()
+            model.covariance_activation = None
+            attach(model)                                                                          # covariance producers + FusedAdam (what install() does per model)
+            model.get_covariance = lambda m=1, _g=model: _g.covariance_activation(_g.get_scaling, m, _g._rotation)      # gaussian_model.py:167-168
+        else:
+            l1_loss, ssim = losses.l1_loss, losses.ssim
+        pc = _ReferenceSurface(model)
+        opt = model.optimizer
+
+        def train_step(i):
+            k = i % n_fr
+            pkg = render(cams[k], pc, Pipe, bg)
+            img = pkg["render"]
+            hm = hand[k % 4]
+            img.register_hook(lambda grad: grad * (1 - hm))
+            Ll1 = l1_loss(img, gts[k])
+            loss = (1.0 - 0.2) * Ll1 + 0.2 * (1.0 - ssim(img, gts[k]))
+            loss.backward()
+            loss.item()
+            opt.step(); opt.zero_grad(set_to_none=True)
+        el, st = timed(train_step)
+        key = "reference_shaped_step" if mode == "installed" else "import_swap_only_step"
+        out[key] = {"value": round(steps / el, 2), "unit": "iters/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": warmup,
+                    "host_ops": ("egogaussian_amd.install(): HIP l1_loss / ssim, HIP covariance producer, FusedAdam behind the reference's names" if mode == "installed"
+                                 else "PyTorch ops (only the two import names swapped)"),
+                    "loop": "the reference's, unchanged: render() through the reference's attribute surface, hand-mask hook, l1_loss + ssim, backward, loss.item() "
+                            "every iteration, optimizer.step(), zero_grad (/root/reference/trainers/train_static.py:67-138)",
+                    "rasterizer_stage_ms": {k_: v[0] for k_, v in st.items()}}
+        if mode == "installed":
+            # ---- label phase on the same model ----
+            model._label = torch.zeros(N, 1, device=dev).requires_grad_(True)
+            lab_opt = type(opt)([{"params": [model._label], "lr": 0.01, "name": "label"}], lr=0.0, eps=1e-15)
+            crit = nn.BCEWithLogitsLoss()
+
+            def label_step(i):
+                k = i % n_fr
+                render(cams[k], pc, Pipe, bg)                                                   # train_static.py:78 (not part of this phase's loss)
+                lab = torch.mean(get_render_label(cams[k], pc, bg), dim=0, keepdim=True)
+                hm = hand[k % 4]
+                lab.register_hook(lambda grad: grad * (1 - hm))
+                loss = crit(input=lab, target=objm[k % 4])
+                loss.backward()
+                loss.item()
+                lab_opt.step(); lab_opt.zero_grad(set_to_none=True)
+            el, st = timed(label_step)
+            # the label call's backward alone, colours-only against the full backward of the same frames (HIP events on the stream)
+            def bwd_ms(mask):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                tot, n = 0.0, 12
+                for i in range(n + 2):
+                    lab = get_render_label(cams[i % n_fr], pc, bg)
+                    up = torch.ones_like(lab)
+                    _C.COLORS_ONLY_BACKWARD = bool(mask)                 # False: the mask is withheld and the full backward runs
+                    try:
+                        ev[0].record(); lab.backward(up); ev[1].record()
+                    finally:
+                        _C.COLORS_ONLY_BACKWARD = True
+                    torch.cuda.synchronize()
+                    if i >= 2:
+                        tot += ev[0].elapsed_time(ev[1])
+                    model._label.grad = None
+                return tot / n
+            fast, full = bwd_ms(1), bwd_ms(0)
+            out["label_phase_shape"] = {"value": round(steps / el, 2), "unit": "iters/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": warmup,
+                                        "step": "render() fwd + get_render_label() fwd + channel mean + hand-mask hook + BCEWithLogits + backward (colours only) + "
+                                                "loss.item() + Adam on the labels; eager, the reference's loop",
+                                        "label_backward_ms": round(fast, 4), "label_backward_full_path_ms": round(full, 4),
+                                        "label_backward_ratio": round(fast / full, 3),
+                                        "label_backward_note": "loss.backward() of the label render alone between two HIP events on the stream (host launch gaps included), "
+                                                               "12 frames: egs_backward with grad_mask = EGS_GRAD_COLORS against the same call with the mask withheld",
+                                        "rasterizer_stage_ms": {k_: v[0] for k_, v in st.items()},
+                                        "reference": "/root/reference/trainers/train_static.py:78,105-110, gaussian_renderer/render_helper.py:38-64"}
+        del model, pc, opt
+        torch.cuda.empty_cache()
+    return out
+
+
 def footprint_legs(dev, train_iters=30000):
     """Heavier footprints than S(500k) (67 pairs per pixel, 918 instances per tile): the same scene with every splat three times
     larger (saturating pixels, long lists), and the model the reference's full schedule ends with on the synthetic scene -- 100k
@@ -689,17 +829,11 @@ def main():
                                           "steps 29.5 M parameters instead of 7 M"}
         except Exception as exc:                                   # the headline line must still come out
             out["sh_degree_3"] = {"error": f"{type(exc).__name__}: {exc}"}
-        # The step exactly as SURVEY.md section 8d words it -- get_covariance and the loss as PyTorch ops around the rasterizer, torch's
-        # own fused Adam, every kernel launched from Python (what a reference trainer gets by swapping the two import lines and nothing
-        # else): same workload, in a child process.
+        # The reference's trainer loop UNCHANGED (render through the reference's attribute surface, l1_loss + ssim by name, loss.item() every
+        # iteration): with what egogaussian_amd.install() puts behind those names, with PyTorch ops behind them (import swap only), and its
+        # label phase.  In this process, after the headline legs.
         try:
-            leg = subprocess.run([sys.executable, os.path.abspath(__file__), "--torch-host-ops", "--steps", str(min(args.steps, 60)), "--warmup", "10",
-                                  "--no-cpu-baseline", "--gaussians", str(N), "--height", str(H), "--width", str(W)],
-                                 capture_output=True, text=True, timeout=600)
-            j = json.loads(leg.stdout.strip().splitlines()[-1])
-            out["reference_shaped_step"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
-                                            "rasterizer_ms_per_step": j["rasterizer_ms_per_step"], "psnr_db": j["psnr_db"], "step": j["config"]["workload"].split("step = ")[-1],
-                                            "launch": j["config"]["launch"]}
+            out.update(unchanged_trainer_legs(dev, N, H, W, steps=min(args.steps, 100), warmup=10))
         except Exception as exc:
             out["reference_shaped_step"] = {"error": f"{type(exc).__name__}: {exc}"}
         # Between the two: every kernel launched from Python (no hipGraph), but with this package's host ops -- raw parameters into the

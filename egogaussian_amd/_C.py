@@ -215,6 +215,7 @@ ACT_LOG_SCALES, ACT_RAW_QUATS, ACT_LOGIT_OPACITY = 1, 2, 4      # include/egs_ra
 ACT_RAW_PARAMETERS = ACT_LOG_SCALES | ACT_RAW_QUATS | ACT_LOGIT_OPACITY
 # include/egs_raster.h: EGS_GRAD_* (which inputs' gradients the caller reads; 0 = all)
 GRAD_MEANS3D, GRAD_MEANS2D, GRAD_SH, GRAD_COLORS, GRAD_OPACITY, GRAD_SCALES, GRAD_ROTATIONS, GRAD_COV3D = 1, 2, 4, 8, 16, 32, 64, 128
+COLORS_ONLY_BACKWARD = True        # measurement switch (bench.py label_phase_shape): False withholds the mask, the full backward runs
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -372,7 +373,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     g_alpha = _opt(_f32c(dL_dout_alpha, "dL_dout_alpha"))
     sh_rest = _opt(_f32c(sh_rest, "sh_rest"))
     M = 0 if sh is None else sh.shape[1] + (0 if sh_rest is None else sh_rest.shape[1])
-    if P != 0 and grad_mask == GRAD_COLORS and colors is not None and sink is None and densify_stats is None and object_rotation is None:
+    if COLORS_ONLY_BACKWARD and P != 0 and grad_mask == GRAD_COLORS and colors is not None and sink is None and densify_stats is None and object_rotation is None:
         with _hip.device_ctx(dev):
             dcolors = torch.empty((P, 3), device=dev, dtype=torch.float32)
             scratch = prologue_scratch if prologue_scratch is not None else torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)

@@ -24,20 +24,11 @@ GeomLayout geom_layout(int P) {
     L.o.total = off;        off = egs_align(off + sizeof(uint64_t));
     L.bytes = off; return L;
 }
-// spine words: [0, sums) chunk sums of the two-walk bucketing | 32 scratch words | total (u64) | alloc (u64) | tile_start [n_tiles + 2]
-struct SpineWords { size_t flag, total, alloc, tile_start, end; };
-static SpineWords spine_words(size_t sums, size_t n_tiles) {
-    SpineWords w; w.flag = sums; w.total = (sums + 32 + 1) & ~(size_t)1; w.alloc = w.total + 2; w.tile_start = w.alloc + 2; w.end = w.tile_start + n_tiles + 2;
-    return w;
-}
 BinLayout bin_layout(int P, int64_t R, int W, int H) {
     BinLayout L; size_t off = 0; const size_t n = (size_t)(R > 0 ? R : 0);
     const size_t gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const size_t nblocks = egs_bin_blocks(P > 0 ? P : 0), stride = egs_table_stride((uint32_t)nblocks), tab = gx * gy * stride;
     const size_t sums = EGS_BIN_GROUPS * egs_table_chunks(gx * gy, (uint32_t)stride);
-    const EgsBinPlan plan = egs_bin_plan(P > 0 ? P : 0, R > 0 ? R : 0, (int)(gx * gy));
-    const size_t tab_new = ((size_t)plan.max_cols * plan.row * sizeof(uint16_t) + 255) / 256 * 256 + (size_t)plan.max_cols * sizeof(uint32_t);
-    const SpineWords sw = spine_words(sums, gx * gy);
     L.o.key_bits = egs_key_bits_for_tiles((int)(gx * gy));
     L.o.bin_blocks = (int)nblocks;
     L.o.table_stride = (int)stride;
@@ -46,9 +37,9 @@ BinLayout bin_layout(int P, int64_t R, int W, int H) {
     L.o.point_list = off; off = egs_align(off + n * sizeof(uint32_t));          // first: the backward needs nothing else
     L.o.pairs = off;      off = egs_align(off + n * sizeof(uint64_t));
     L.o.scratch = off;    off = egs_align(off + n * sizeof(uint64_t));
-    L.o.table = off;      off = egs_align(off + (n ? (tab * sizeof(uint32_t) > tab_new ? tab * sizeof(uint32_t) : tab_new) : 0));
-    L.o.spine = off;      off = egs_align(off + (n ? sw.end : 0) * sizeof(uint32_t));
-    L.o.total = L.o.spine + sw.total * sizeof(uint32_t);
+    L.o.table = off;      off = egs_align(off + (n ? tab : 0) * sizeof(uint32_t));
+    L.o.spine = off;      off = egs_align(off + (n ? sums + 64 + 4 : 0) * sizeof(uint32_t));
+    L.o.total = L.o.spine + ((sums + 32 + 1) & ~(size_t)1) * sizeof(uint32_t);
     L.bytes = off; return L;
 }
 ImgLayout img_layout(int W, int H) {
@@ -76,12 +67,6 @@ EgsBinPtrs bin_ptrs(void* buf, int P, int64_t R, int W, int H) {
     p.point_list = (uint32_t*)(b + L.o.point_list); p.table = (uint32_t*)(b + L.o.table); p.chunk_sum = (uint32_t*)(b + L.o.spine);
     p.total = (uint64_t*)(b + L.o.total);
     p.flag = (uint32_t*)p.total - 32;                                 // (the 32 words before `total`)
-    const size_t nt = (size_t)((W + EGS_TILE - 1) / EGS_TILE) * (size_t)((H + EGS_TILE - 1) / EGS_TILE);
-    const EgsBinPlan plan = egs_bin_plan(P > 0 ? P : 0, R > 0 ? R : 0, (int)nt);
-    p.alloc = (unsigned long long*)(p.total + 1);
-    p.tile_start = (uint32_t*)(p.total + 2);
-    p.rel = (uint16_t*)p.table;
-    p.colbase = (uint32_t*)((char*)p.table + ((size_t)plan.max_cols * plan.row * sizeof(uint16_t) + 255) / 256 * 256);
     return p;
 }
 EgsImgPtrs img_ptrs(void* buf, int W, int H) {
@@ -322,7 +307,6 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
         b_spec = bin_ptrs(binning_buffer, P, capacity, width, height);
         const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
         n_sums = EGS_BIN_GROUPS * egs_table_chunks(nt, egs_table_stride(egs_bin_blocks(P)));
-        if (!egs_bin_legacy) { b_spec.chunk_sum = (uint32_t*)b_spec.alloc; n_sums = 2; }     // the one-walk bucketing: its allocation word
     }
     // ... and carries the placement of the forward blend's tiles (backward_prologue.h), computed from the costs the image buffer holds
     EgsImgPtrs im_spec = img_ptrs(image_buffer, width, height);

@@ -27,11 +27,8 @@
 #include "egs_common.h"
 #include "blend_common.h"
 #include <atomic>
-#include <algorithm>
-#include <stdlib.h>
 
 int egs_tile_culling = 1;           // egs_debug_set_tile_culling: 0 keeps every instance of the reference's rectangles
-int egs_bin_legacy = getenv("EGS_BIN_LEGACY") ? atoi(getenv("EGS_BIN_LEGACY")) : 0;     // A/B measurements: 1 = the two-walk bucketing of rounds 1-4
 int egs_force_ballot_rank = 0;      // test hook (egs_debug_force_ballot_rank): exercise the fallback ranking
 
 namespace {
@@ -446,380 +443,6 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_scatter(int P, int gpr,
     });
 }
 
-// Counting into a handful of LDS words from a whole wave.  Lanes that hit the SAME word in one atomic instruction are served one after
-// the other (~2-4 cycles each): a unit's 64 slots are the consecutive tiles of a few rectangles, eight of which share a bin, and the
-// 1 024 threads of a partition workgroup share eight tile counters -- measured, the plain per-lane atomics made k_bin_emit 31 us (the
-// per-tile counters of the two-walk count pass: 18) and k_bin_partition 37 us.  So the wave sorts that out itself:
-//   wave_run_count    keys come in RUNS along the kept lanes (row-major tiles of a rectangle): the first lane of a run adds the run's
-//                     length, everybody gets (old value + position in the run): one atomic lane per run;
-//   wave_match_count  keys in any order but only `bits` wide: ballots build every lane's mask of equal-key lanes, its lowest lane adds
-//                     the population.
-__device__ __forceinline__ uint32_t wave_run_count(uint32_t* counter, uint32_t key, bool keep, uint64_t km, uint64_t lt, unsigned lane) {
-    const uint64_t below = km & lt;
-    const int prev = below ? 63 - __builtin_clzll(below) : 0;
-    const uint32_t pkey = (uint32_t)__shfl((int)key, prev, 64);
-    const bool head = keep && (below == 0ull || pkey != key);
-    const uint64_t hm = __ballot(head);
-    const uint64_t upto = lt | (1ull << lane);
-    const uint64_t hb = hm & upto;
-    const int myhead = hb ? 63 - __builtin_clzll(hb) : 0;             // first lane of my run (kept lanes only)
-    const uint64_t ha = hm & ~upto;
-    const uint64_t run = (ha ? ((1ull << __builtin_ctzll(ha)) - 1ull) : ~0ull) & ~lt;      // lanes [me, next head)
-    uint32_t base = 0;
-    if (head) base = atomicAdd(&counter[key], (uint32_t)__popcll(km & run));
-    base = (uint32_t)__shfl((int)base, myhead, 64);
-    return base + (uint32_t)__popcll(km & lt & ~((1ull << myhead) - 1ull));
-}
-template <bool RETURNS>
-__device__ __forceinline__ uint32_t wave_match_count(uint32_t* counter, uint32_t key, int bits, bool ok, uint64_t lt, unsigned lane) {
-    uint64_t peers = __ballot(ok);
-    for (int b = 0; b < bits; b++) {
-        const uint64_t m = __ballot((key >> b) & 1u);
-        peers &= ((key >> b) & 1u) ? m : ~m;
-    }
-    const int leader = peers ? __builtin_ctzll(peers) : 0;
-    uint32_t base = 0;
-    if (ok && (int)lane == leader) base = atomicAdd(&counter[key], (uint32_t)__popcll(peers));
-    if (!RETURNS) return 0u;
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    return base + (uint32_t)__popcll(peers & lt);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Round 5: the bucketing as ONE walk and two levels.
-//   k_bin_emit       a workgroup takes a ROUND of 512 consecutive Gaussians (8 groups of 64), walks their instance slots ONCE (set-up,
-//                    owner map, culling test as above) and parks every kept instance in LDS as a 4-byte (Gaussian of the round, tile)
-//                    word while an LDS histogram counts them per BIN (2^shift consecutive tiles).  At the end of the round (or when the
-//                    5 120-entry stage is full) it counting-sorts the stage by bin in LDS and writes the 8-byte pairs IN BIN ORDER --
-//                    512 contiguous bytes per wave-instruction -- into ITS region of the intermediate array, with the tile's position
-//                    inside its bin in the spare high bits of the index word, plus one row of 16-bit slice starts (rel[column][bin])
-//                    and the column's first slot.  The region of a round starts at the sum of the rectangle counts of the rounds before
-//                    it (the per-block sums k_preprocess left; what is kept never exceeds them), so nothing is allocated at run time:
-//                    no atomic, no scan kernel, and the capacity R covers it by definition.
-//   k_bin_partition  one workgroup per bin: its slices (one per column, a cache line's worth of pairs each; the bin's first slot is the
-//                    sum of its row of `rel`) are counted per tile, then read again and placed tile by tile into an LDS image of the
-//                    bin's span of `pairs`, which leaves as full lines; also writes tile_start[0 .. n_tiles] for the sort.
-// What it replaces (k_bin_count / k_table_scan / k_bin_scatter above) walked the slots twice, kept a [tile][workgroup] table of a million
-// words and left every pair as an 8-byte store of its own: a workgroup owned ~2 consecutive pairs of a tile's bucket, and the L2 forwards
-// partial lines -- 352 MB written for 72 MB of pairs at 1M Gaussians @ 1920x1080 (profiles/r4_config_D_traffic.txt).
-// ---------------------------------------------------------------------------------------------
-#define BE_GPR 8                        // groups of 64 Gaussians per round
-#define BE_ROUND (BE_GPR * 64)
-#define BE_CAP 5120                     // staged instances per column
-#define BE_MAX_BINS 1024
-#ifdef EGS_BIN_TIMING
-// measurement builds (tools/dev/emit_phases.py): thread 0 of every workgroup of k_bin_emit / k_bin_partition stamps s_memtime at its phase boundaries
-__device__ unsigned long long egs_emit_stamps[8192 * 8];
-__device__ unsigned long long egs_part_stamps[2048 * 8];
-#define EMIT_STAMP(ph) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 8192) egs_emit_stamps[blockIdx.x * 8 + (ph)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PART_STAMP(ph) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 2048) egs_part_stamps[blockIdx.x * 8 + (ph)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-extern "C" int egs_debug_emit_stamps(unsigned long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(egs_emit_stamps), sizeof(egs_emit_stamps)); }
-extern "C" int egs_debug_part_stamps(unsigned long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(egs_part_stamps), sizeof(egs_part_stamps)); }
-#else
-#define EMIT_STAMP(ph)
-#define PART_STAMP(ph)
-#endif
-struct BinEmitArgs {
-    int P, gx, n_tiles, W, H, cull, shift, n_bins, idx_bits;
-    uint32_t n_rounds, cap, max_cols, row;                            // row: 16-bit words per row of `rel` (even, >= n_bins + 1)
-    const uint32_t* tiles_touched; const uint2* rect; const float4* rec; const uint32_t* block_sums;   // block_sums: rectangle tiles per 256 Gaussians
-    uint32_t* counters;                                               // [0] columns beyond the static ones (ZERO before), [1] rectangle instances of the frame
-    uint16_t* rel; uint32_t* colbase; uint64_t* out;
-};
-
-__global__ __launch_bounds__(EGS_BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bin_emit(BinEmitArgs a) {
-    __shared__ uint32_t hist[BE_MAX_BINS];                             // instances per bin of the open column; cursors during a flush
-    __shared__ uint32_t span[BE_ROUND];
-    __shared__ uint2 rcs[BE_ROUND];
-    __shared__ uint32_t dbs[BE_ROUND];
-    __shared__ uint32_t units[32];
-    __shared__ float4 ell[BE_ROUND * 2];
-    __shared__ uint32_t packed[BE_ROUND], bm[BE_GPR * 128], bmpre[BE_ROUND];
-    __shared__ uint32_t stage[BE_CAP];                                 // (tile << 9 | Gaussian of the round), in arrival order
-    __shared__ uint16_t inv[BE_CAP];                                   // stage position of the p-th instance in bin order
-    __shared__ uint16_t rnk[BE_CAP];                                   // arrival rank of a staged instance inside its bin
-    __shared__ uint32_t stage_n, extra_col, wsum[EGS_BIN_WAVES], bsum[EGS_BIN_WAVES];
-    static_assert(EGS_BIN_THREADS == 1024 && BE_MAX_BINS <= EGS_BIN_THREADS && BE_ROUND == 512, "flush: one thread per bin; 9-bit Gaussian field");
-    const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint64_t lt = lanemask_lt();
-    const bool cull = a.cull != 0;
-    // The heavy rounds of a densified model are its LAST ones (clones and splits are appended, all on screen): they start first.
-    const uint32_t rb = a.n_rounds - 1u - blockIdx.x;
-    const uint32_t g_first = rb * BE_ROUND;                            // first Gaussian of the round
-    EMIT_STAMP(0);
-    if (tid < BE_MAX_BINS) hist[tid] = 0u;
-    if (tid == 0) stage_n = 0u;                                        // (the set-up barrier orders both)
-    // this round's region of `out` starts where the rounds before it end: sum of their 256-Gaussian blocks' rectangle counts
-    {
-        const uint32_t nb_before = rb * (BE_ROUND / 256), nb_all = ((uint32_t)a.P + 255u) / 256u;
-        uint32_t sum = 0;
-        for (uint32_t k = tid; k < nb_before; k += EGS_BIN_THREADS) sum += a.block_sums[k];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
-        if (lane == 0) bsum[w] = sum;
-        if (rb == a.n_rounds - 1u && tid == 0) {                       // the last round also reports what the frame needs room for
-            uint32_t own = 0;
-            for (uint32_t k = nb_before; k < nb_all; k++) own += a.block_sums[k];
-            units[31] = own;
-        }
-    }
-    uint32_t region = 0, written = 0;                                  // first slot of the round's region (after the barrier), slots used by earlier flushes
-
-    // Close the open column: n staged instances (uniform; a barrier has passed since the last append).  `last`: the round's final flush.
-    auto flush = [&](uint32_t n, bool last) {
-        if (!last && tid == 0) extra_col = a.n_rounds + atomicAdd(&a.counters[0], 1u);      // (a round of more than 5 120 instances: rare)
-        const uint32_t v = (int)tid < a.n_bins ? hist[tid] : 0u;
-        const uint32_t incl = wave_incl_scan(v);
-        if (lane == 63) wsum[w] = incl;
-        __syncthreads();
-        uint32_t base = 0;
-#pragma unroll
-        for (int k = 0; k < EGS_BIN_WAVES; k++) if (k < (int)w) base += wsum[k];
-        const uint32_t excl = base + incl - v;
-        const uint32_t col = last ? rb : extra_col;
-        const uint32_t first = region + written;
-        const bool stored = col < a.max_cols && (unsigned long long)first + n <= (unsigned long long)a.cap;   // else: the frame exceeds its capacity and will be redone
-        if ((int)tid < a.n_bins) hist[tid] = excl;
-        if (col < a.max_cols) {
-            if ((int)tid <= a.n_bins) a.rel[(size_t)col * a.row + tid] = (uint16_t)(stored ? ((int)tid < a.n_bins ? excl : n) : 0u);
-            if (tid == 0) a.colbase[col] = min(first, a.cap);
-        }
-        __syncthreads();
-        for (uint32_t e = tid; e < n; e += EGS_BIN_THREADS) inv[hist[(stage[e] >> 9) >> a.shift] + rnk[e]] = (uint16_t)e;
-        __syncthreads();
-        if (stored) {
-            const uint32_t tmask = (1u << a.shift) - 1u;
-            for (uint32_t p = tid; p < n; p += EGS_BIN_THREADS) {
-                const uint32_t ent = stage[inv[p]], g = ent & 511u, tile = ent >> 9;
-                a.out[first + p] = ((uint64_t)dbs[g] << 32) | (uint64_t)((g_first + g) | ((tile & tmask) << a.idx_bits));
-            }
-        }
-        written += n;
-        if (!last) {
-            if (tid < BE_MAX_BINS) hist[tid] = 0u;
-            if (tid == 0) stage_n = 0u;
-            __syncthreads();
-        }
-    };
-
-    if (w < BE_GPR) {
-        const int i = (int)(g_first + w * 64u + lane);
-        const bool have = i < a.P;
-        const int il = have ? i : 0;
-        uint32_t cnt = have ? a.tiles_touched[i] : 0u;
-        uint2 rc_l = a.rect[il];
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-        if (cull) { r0 = a.rec[(size_t)il * EGS_SPLAT_REC_F4]; r1 = a.rec[(size_t)il * EGS_SPLAT_REC_F4 + 1]; r2 = a.rec[(size_t)il * EGS_SPLAT_REC_F4 + 2]; }
-        else r2.y = a.rec[(size_t)il * EGS_SPLAT_REC_F4 + 2].y;
-        if (cull && cnt) {                                             // the tiles of the alpha >= 1/255 box, cut to the reference's rectangle (see for_each_instance)
-            const uint32_t bx = __float_as_uint(r2.z), by = __float_as_uint(r2.w);
-            const uint32_t px0 = bx & EGS_BOX_MASK, px1 = (bx >> 16) & EGS_BOX_MASK, py0 = by & EGS_BOX_MASK, py1 = by >> 16;
-            const uint32_t x0 = max(rc_l.x & 0xffffu, px0 / EGS_TILE), x1 = min(rc_l.x >> 16, px1 / EGS_TILE + 1u);
-            const uint32_t y0 = max(rc_l.y & 0xffffu, py0 / EGS_TILE), y1 = min(rc_l.y >> 16, py1 / EGS_TILE + 1u);
-            const bool some = px0 <= px1 && py0 <= py1 && x0 < x1 && y0 < y1;
-            cnt = some ? (x1 - x0) * (y1 - y0) : 0u;
-            rc_l = make_uint2(x0 | (x1 << 16), y0 | (y1 << 16));
-        }
-        const uint32_t incl = wave_incl_scan(cnt);
-        span[w * 64 + lane] = have ? incl - cnt : 0xffffffffu;
-        if (cnt) {
-            rcs[w * 64 + lane] = rc_l;
-            dbs[w * 64 + lane] = __float_as_uint(r2.y);
-            if (cull) { ell[2 * (w * 64 + lane)] = r0; ell[2 * (w * 64 + lane) + 1] = egs_ellipse_prep(r0.z, r0.w, r1.x, r1.y); }
-        }
-        if (lane == 63) { units[w] = (incl + 63u) >> 6; units[16 + w] = incl; }
-        {   // owner map of this group (one wave: its LDS operations execute in order)
-            const uint32_t excl_l = incl - cnt;
-            const uint64_t nzm = __ballot(cnt != 0);
-            if (cnt) packed[w * 64 + __popcll(nzm & lt)] = (excl_l << 6) | lane;
-            bm[w * 128 + lane] = 0u; bm[w * 128 + 64 + lane] = 0u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-            if (cnt && excl_l < BIN_MAP_SLOTS) atomicOr(&bm[w * 128 + (excl_l >> 5)], 1u << (excl_l & 31u));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-            const uint32_t pc = (uint32_t)__popc(*(volatile uint32_t*)&bm[w * 128 + 2 * lane]) + (uint32_t)__popc(*(volatile uint32_t*)&bm[w * 128 + 2 * lane + 1]);
-            bmpre[w * 64 + lane] = wave_incl_scan(pc) - pc;
-        }
-    }
-    EMIT_STAMP(1);
-    __syncthreads();
-    EMIT_STAMP(2);
-#pragma unroll
-    for (int k = 0; k < EGS_BIN_WAVES; k++) region += bsum[k];
-    if (rb == a.n_rounds - 1u && tid == 0) a.counters[1] = region + units[31];
-    const uint32_t un = lane < BE_GPR ? units[lane] : 0u, tot = lane < BE_GPR ? units[16 + lane] : 0u;
-    const uint32_t uincl = wave_incl_scan(un);
-    const uint32_t n_units = __shfl(uincl, 63, 64);
-    uint32_t cur = 0, u_begin = 0;                                     // staged so far (uniform), first unit not yet walked
-    while (u_begin < n_units) {
-        const uint32_t room = (BE_CAP - cur) >> 6, remaining = n_units - u_begin;
-        if (room < min((uint32_t)EGS_BIN_WAVES, remaining)) { flush(cur, false); cur = 0; continue; }
-        const uint32_t u_end = u_begin + min(room, remaining);
-        for (uint32_t u = u_begin + w; u < u_end; u += EGS_BIN_WAVES) {
-            const int k = __popcll(__ballot(uincl <= u && lane < BE_GPR));       // the group unit u falls in (uniform)
-            const uint32_t s = ((u - (__shfl(uincl, k, 64) - __shfl(un, k, 64))) << 6) + lane;
-            const uint32_t total = __shfl(tot, k, 64);
-            const uint32_t uu = s >> 6;
-            int lo; uint32_t ost;
-            if (uu < BIN_MAP_SLOTS / 64) {
-                const uint64_t B = *reinterpret_cast<const uint64_t*>(&bm[k * 128 + 2 * uu]);
-                const uint32_t R = bmpre[k * 64 + uu] + (uint32_t)__popcll(B & (lt | (1ull << lane))) - 1u;
-                const uint32_t pk = packed[k * 64 + (R & 63u)];
-                lo = (int)(pk & 63u); ost = pk >> 6;
-            } else {
-                const uint32_t excl = span[k * 64 + lane];
-                lo = 0;
-#pragma unroll
-                for (int step = 32; step >= 1; step >>= 1) {
-                    const int probe = lo + step;
-                    const uint32_t st = __shfl(excl, probe & 63, 64);
-                    if (probe < 64 && st <= s) lo = probe;
-                }
-                ost = __shfl(excl, lo, 64);
-            }
-            bool keep = false; uint32_t tile = 0;
-            if (s < total) {
-                const uint32_t kk = s - ost;
-                const uint2 orc = rcs[k * 64 + lo];
-                const uint32_t x0 = orc.x & 0xffffu, x1 = orc.x >> 16, y0 = orc.y & 0xffffu;
-                const uint32_t wd = x1 - x0;
-                uint32_t row = (uint32_t)((float)kk * __builtin_amdgcn_rcpf((float)wd));
-                uint32_t col = kk - row * wd;
-                if ((int)col < 0) { row--; col += wd; }
-                if (col >= wd) { row++; col -= wd; }
-                const uint32_t ty = y0 + row, tx = x0 + col;
-                keep = true;
-                if (cull) {
-                    const float4 e0 = ell[2 * (k * 64 + lo)], e1 = ell[2 * (k * 64 + lo) + 1];
-                    keep = egs_ellipse_hits_prepped(e0, e1, tx * EGS_TILE, min(tx * EGS_TILE + EGS_TILE - 1, (uint32_t)a.W - 1),
-                                                    ty * EGS_TILE, min(ty * EGS_TILE + EGS_TILE - 1, (uint32_t)a.H - 1));
-                }
-                tile = ty * (uint32_t)a.gx + tx;
-            }
-            const uint64_t km = __ballot(keep);
-            if (km) {                                                  // one LDS atomic per wave reserves the unit's stage slots
-                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)km) - 1);
-                uint32_t b0 = 0;
-                if ((int)lane == leader) b0 = atomicAdd(&stage_n, (uint32_t)__popcll(km));
-                b0 = __builtin_amdgcn_readlane(b0, leader);
-                const uint32_t rank = wave_run_count(hist, tile >> a.shift, keep, km, lt, lane);
-                if (keep) {
-                    const uint32_t e = b0 + (uint32_t)__popcll(km & lt);
-                    stage[e] = (tile << 9) | (uint32_t)(k * 64 + lo);
-                    rnk[e] = (uint16_t)rank;
-                }
-            }
-        }
-        EMIT_STAMP(3);
-        __syncthreads();
-        EMIT_STAMP(4);
-        cur = *(volatile uint32_t*)&stage_n;
-        u_begin = u_end;
-        if (u_begin < n_units) __syncthreads();                        // a longer round: nobody appends before everybody has read the count
-    }
-    flush(cur, true);                                                  // (an empty round still writes its row of `rel`: all zeros)
-    EMIT_STAMP(5);
-}
-
-struct BinPartArgs {
-    int n_tiles, shift, n_bins, idx_bits;
-    uint32_t cap, n_rounds, max_cols, row;
-    const uint32_t* counters; const uint16_t* rel; const uint32_t* colbase; const uint64_t* in;
-    uint64_t* pairs; uint32_t* tile_start; uint64_t* total;
-};
-#define BP_THREADS 1024
-#define BP_MAX_SHIFT 8
-#define BP_IMAGE 12288                  // pairs of a bin's span of `pairs` staged in LDS (96 KiB); what lies beyond goes out pair by pair
-#define BP_BATCH 8                      // pairs of a slice a thread has in flight at once
-__global__ __launch_bounds__(BP_THREADS) void k_bin_partition(BinPartArgs a) {
-    __shared__ uint64_t image[BP_IMAGE];
-    __shared__ uint32_t cnt[1 << BP_MAX_SHIFT], wsum[BP_THREADS / 64];
-    const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const unsigned per = (a.n_bins + 7) / 8;
-    const unsigned bin = (blockIdx.x % 8) * per + blockIdx.x / 8;       // an XCD takes consecutive bins: neighbouring slices share lines
-    if (bin >= (unsigned)a.n_bins) return;
-    const uint32_t n_cols = min(a.n_rounds + a.counters[0], a.max_cols);
-    const uint32_t tl_n = 1u << a.shift;
-    PART_STAMP(0);
-    if (tid < tl_n) cnt[tid] = 0u;
-    __syncthreads();
-    // ---- pass 1: instances per tile of the bin (only the index words are read) and the bin's first slot ----
-    uint32_t before = 0;
-    const uint64_t lt = lanemask_lt();
-    const uint32_t n_cols_up = (n_cols + 63u) & ~63u;                  // whole waves walk the columns (the counting is a wave operation)
-    for (uint32_t c = tid; c < n_cols_up; c += BP_THREADS) {
-        const bool real = c < n_cols;
-        const uint32_t o0 = real ? a.rel[(size_t)c * a.row + bin] : 0u, o1 = real ? a.rel[(size_t)c * a.row + bin + 1] : 0u;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.in + (real ? a.colbase[c] : 0u));
-        before += o0;
-        uint32_t lw[BP_BATCH];
-#pragma unroll
-        for (int k = 0; k < BP_BATCH; k++) lw[k] = o0 + k < o1 ? src[2 * (o0 + k)] : 0u;
-#pragma unroll
-        for (int k = 0; k < BP_BATCH; k++) wave_match_count<false>(cnt, a.shift ? lw[k] >> a.idx_bits : 0u, a.shift, o0 + k < o1, lt, lane);
-        for (uint32_t j = o0 + BP_BATCH; __any(j < o1); j++)            // (a slice of more than eight pairs: the whole wave goes along)
-            wave_match_count<false>(cnt, (a.shift && j < o1) ? src[2 * j] >> a.idx_bits : 0u, a.shift, j < o1, lt, lane);
-    }
-    PART_STAMP(1);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
-    if (lane == 0) wsum[w] = before;
-    __syncthreads();
-    PART_STAMP(2);
-    uint32_t start = 0;
-#pragma unroll
-    for (int k = 0; k < BP_THREADS / 64; k++) start += wsum[k];
-    // exclusive scan of the bin's tile counts (<= 256 tiles: the first four waves)
-    const uint32_t v = tid < tl_n ? cnt[tid] : 0u;
-    const uint32_t incl = wave_incl_scan(v);
-    __syncthreads();                                                   // wsum is read by everybody above
-    if (lane == 63 && w < 4) wsum[w] = incl;
-    __syncthreads();
-    uint32_t n_bin = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) n_bin += wsum[k];
-    if (tid < tl_n) {
-        uint32_t base = 0;
-        for (unsigned k = 0; k < w; k++) base += wsum[k];
-        const uint32_t ex = base + incl - v;
-        cnt[tid] = ex;                                                 // cursor, relative to the bin's first slot
-        const uint32_t tile = (bin << a.shift) + tid;
-        if (tile <= (uint32_t)a.n_tiles) a.tile_start[tile] = start + ex;      // (the entry behind the last tile: the end of its bucket)
-        if (tile + 1 == (uint32_t)a.n_tiles && tid == tl_n - 1) {
-            a.tile_start[a.n_tiles] = start + ex + v;
-        }
-    }
-    if (bin == (unsigned)a.n_bins - 1 && tid == 0) *a.total = (uint64_t)start + n_bin;      // instances bucketed (after culling)
-    __syncthreads();
-    // ---- pass 2: the same slices again (L2), every pair to its tile's cursor inside the LDS image of [start, start + n_bin) ----
-    const uint32_t imask = (a.idx_bits >= 32 || a.shift == 0) ? 0xffffffffu : (1u << a.idx_bits) - 1u;
-    auto place = [&](uint64_t r, bool ok) {
-        const uint32_t lo = (uint32_t)r;
-        const uint32_t pos = wave_match_count<true>(cnt, (a.shift && ok) ? lo >> a.idx_bits : 0u, a.shift, ok, lt, lane);
-        const uint64_t clean = (r & 0xffffffff00000000ull) | (uint64_t)(lo & imask);
-        if (ok) {
-            if (pos < BP_IMAGE) image[pos] = clean;
-            else if (start + pos < a.cap) a.pairs[start + pos] = clean;
-        }
-    };
-    for (uint32_t c = tid; c < n_cols_up; c += BP_THREADS) {
-        const bool real = c < n_cols;
-        const uint32_t o0 = real ? a.rel[(size_t)c * a.row + bin] : 0u, o1 = real ? a.rel[(size_t)c * a.row + bin + 1] : 0u;
-        const uint64_t* src = a.in + (real ? a.colbase[c] : 0u);
-        uint64_t r[BP_BATCH];
-#pragma unroll
-        for (int k = 0; k < BP_BATCH; k++) r[k] = o0 + k < o1 ? src[o0 + k] : 0ull;
-#pragma unroll
-        for (int k = 0; k < BP_BATCH; k++) place(r[k], o0 + k < o1);
-        for (uint32_t j = o0 + BP_BATCH; __any(j < o1); j++) place(j < o1 ? src[j] : 0ull, j < o1);
-    }
-    PART_STAMP(3);
-    __syncthreads();
-    PART_STAMP(4);
-    const uint32_t n_img = min(n_bin, (uint32_t)BP_IMAGE);
-    for (uint32_t i = tid; i < n_img; i += BP_THREADS) if (start + i < a.cap) a.pairs[start + i] = image[i];
-    PART_STAMP(5);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Per-tile sort of (depth<<32 | index) pairs.  LSD radix with 9-bit digits over only the bits that can differ:
 //   depth   the tile's smallest depth word is subtracted first (positive floats order like their bit patterns), so a
@@ -968,8 +591,8 @@ extern "C" int egs_debug_sort_stamps(unsigned long long* host_out) { return (int
 #define SORT_STAMP(ph)
 #endif
 template <bool RANK_ATOMIC, int TS_WAVES, int TS_CAP, uint32_t N_MIN>
-__global__ __launch_bounds__(64 * TS_WAVES) __attribute__((amdgpu_waves_per_eu(TS_WAVES == 4 ? 8 : 5, 8))) void k_tile_sort(int n_tiles, uint32_t stride, const uint32_t* __restrict__ table_scanned, int ends_in_table,
-                                                    const uint32_t* __restrict__ need, const uint64_t* __restrict__ total, uint64_t* __restrict__ running_max,
+__global__ __launch_bounds__(64 * TS_WAVES) __attribute__((amdgpu_waves_per_eu(TS_WAVES == 4 ? 8 : 5, 8))) void k_tile_sort(int n_tiles, uint32_t stride, const uint32_t* __restrict__ table_scanned,
+                                                    const uint64_t* __restrict__ total, uint64_t* __restrict__ running_max,
                                                     uint32_t* __restrict__ overflow_flag, int solo,
                                                     uint32_t R /* capacity */,
                                                     int index_passes, uint64_t* __restrict__ pairs,
@@ -986,15 +609,12 @@ __global__ __launch_bounds__(64 * TS_WAVES) __attribute__((amdgpu_waves_per_eu(T
     const int tile = blockIdx.x;
     SORT_STAMP(0);
     const uint32_t beg = table_scanned[(size_t)tile * stride];
-    const uint32_t end = (tile + 1 < n_tiles || ends_in_table) ? table_scanned[(size_t)(tile + 1) * stride] : (uint32_t)*total;
+    const uint32_t end = tile + 1 < n_tiles ? table_scanned[(size_t)(tile + 1) * stride] : (uint32_t)*total;
     const uint32_t n = end > R ? 0u : end - beg;                     // end > capacity: speculative launch that overflowed
     if (N_MIN == 0) {                                                // the first of the two launches also publishes the bookkeeping
-        // what the frame needed room for: the instances bucketed, or (one-walk bucketing, whose regions are laid out by rectangle counts) the
-        // rectangle instances
-        const uint64_t wanted = need ? max(*total, (uint64_t)*need) : *total;
-        if (running_max && tile == 0 && threadIdx.x == 0 && wanted > *running_max) *running_max = wanted;   // for hipGraph replays (api.hip)
+        if (running_max && tile == 0 && threadIdx.x == 0 && *total > *running_max) *running_max = *total;   // for hipGraph replays (api.hip)
         if (overflow_flag && tile == 0 && threadIdx.x == 0) {          // include/egs_raster.h: [0] this frame was clipped, [1] its instance count
-            overflow_flag[0] = wanted > (uint64_t)R ? 1u : 0u; overflow_flag[1] = (uint32_t)min(wanted, (uint64_t)0xffffffffu);
+            overflow_flag[0] = *total > (uint64_t)R ? 1u : 0u; overflow_flag[1] = (uint32_t)min(*total, (uint64_t)0xffffffffu);
         }
         if (threadIdx.x == 0) ranges[tile] = n ? make_uint2(beg, end) : make_uint2(0u, 0u);
     }
@@ -1286,32 +906,6 @@ hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int 
 int egs_bin_gpb(int P) { const int k = (P + 64 * EGS_BIN_TARGET_BLOCKS - 1) / (64 * EGS_BIN_TARGET_BLOCKS); return 64 * (k > 1 ? k : 1); }
 uint32_t egs_bin_blocks(int P) { const int g = egs_bin_gpb(P); return (uint32_t)((P + g - 1) / g); }
 
-// One-walk bucketing: how many tiles share a bin.  A column (one round of 512 Gaussians, or a full stage) is cut into n_bins slices; a slice
-// should be a cache line's worth of pairs (EGS_BIN_SLICE_PAIRS, ~8), so n_bins ~ pairs per column / 8 -- but not so few that
-// k_bin_partition (one workgroup per bin) leaves CUs idle.  R is the capacity (>= the rectangle count, ~2 x what survives the culling).
-#ifndef EGS_BIN_SLICE_PAIRS
-#define EGS_BIN_SLICE_PAIRS 6
-#endif
-EgsBinPlan egs_bin_plan(int P, int64_t R, int n_tiles) {
-    EgsBinPlan pl;
-    const uint32_t groups = ((uint32_t)P + 63u) / 64u;
-    pl.nblocks = (groups + BE_GPR - 1) / BE_GPR; if (pl.nblocks == 0) pl.nblocks = 1;
-    pl.idx_bits = 0; while (P > 1 && (((unsigned)(P - 1)) >> pl.idx_bits) != 0) pl.idx_bits++;
-    const int64_t per_col = std::min<int64_t>(BE_CAP, std::max<int64_t>(1, (R / 2) / (int64_t)pl.nblocks));
-    const int64_t want_bins = std::max<int64_t>(1, per_col / EGS_BIN_SLICE_PAIRS);
-    static const int forced = getenv("EGS_BIN_SHIFT") ? atoi(getenv("EGS_BIN_SHIFT")) : -1;
-    int s = 0;
-    auto bins = [&](int sh) { return (n_tiles + (1 << sh) - 1) >> sh; };
-    while (s < BP_MAX_SHIFT && pl.idx_bits + s < 32 && bins(s) > want_bins) s++;
-    while (s > 0 && bins(s) < 224 && bins(s - 1) <= BE_MAX_BINS) s--;                    // keep one partition workgroup per CU busy where the image allows
-    while (bins(s) > BE_MAX_BINS && s < BP_MAX_SHIFT && pl.idx_bits + s < 32) s++;
-    if (forced >= 0 && forced <= BP_MAX_SHIFT && pl.idx_bits + forced <= 32 && bins(forced) <= BE_MAX_BINS) s = forced;
-    pl.shift = s; pl.n_bins = bins(s);
-    pl.max_cols = pl.nblocks + (uint32_t)(R / (BE_CAP - 64 * EGS_BIN_WAVES)) + 2u;      // one per round + one per full stage
-    pl.row = ((uint32_t)pl.n_bins + 2u) & ~1u;
-    return pl;
-}
-
 hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
                               uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, hipStream_t s, int debug) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
@@ -1323,76 +917,51 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     const uint32_t R = (uint32_t)R64;
     const uint32_t nblocks = egs_bin_blocks(P);
     int cull = egs_tile_culling;
+    // per-tile counters, then (16-byte aligned) the round's set-up block; fewer groups per round, then no culling, when
+    // the counters leave too little of the 160 KiB (beyond ~28k tiles)
+    const size_t counters = (size_t)((n_tiles + 3) & ~3) * sizeof(uint32_t), room = 160 * 1024 - counters;
+    // the slot walk's owner map (16 KiB at 16 groups) is used where it costs neither groups per round nor the culling: up to ~21k tiles
+    const bool use_map = bin_round_words(EGS_BIN_WAVES, cull != 0, true) * sizeof(uint32_t) <= room;
+    auto fits = [&](int groups, bool with_cull) { return bin_round_words(groups, with_cull, use_map) * sizeof(uint32_t) <= room; };
+    int gpr = EGS_BIN_WAVES;
+    if (cull) {
+        while (gpr > 4 && !fits(gpr, true)) gpr >>= 1;
+        if (!fits(gpr, true)) { cull = 0; gpr = EGS_BIN_WAVES; }
+    }
+    if (!cull) while (gpr > 1 && !fits(gpr, false)) gpr >>= 1;
+    // Two workgroups per CU (all ~489 resident at once, 32 waves per CU to hide the loads behind) beat one with twice the groups per
+    // round: 1M Gaussians @ 1920x1080 (32 KiB of counters) count pass 90.6 -> 77.3 us with 8 groups per round; 4 lose again (84.7).
+    {
+        const bool c = cull != 0;
+        if (gpr == EGS_BIN_WAVES && counters + bin_round_words(gpr, c, use_map) * sizeof(uint32_t) > 80 * 1024 &&
+            counters + bin_round_words(gpr / 2, c, use_map) * sizeof(uint32_t) <= 80 * 1024) gpr /= 2;
+    }
+    const size_t lds = counters + bin_round_words(gpr, cull != 0, use_map) * sizeof(uint32_t);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t stride = egs_table_stride(nblocks), n_chunks = (uint32_t)egs_table_chunks((size_t)n_tiles, stride);
+    egs_prof_start(EGS_K_DUPLICATE, s);
+    if (!sums_zeroed) {
+        hipError_t e0 = egs_launch_zero_u32(b.chunk_sum, (size_t)EGS_BIN_GROUPS * n_chunks, s);
+        if (e0 != hipSuccess) return e0;
+    }
+    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, use_map ? 1 : 0, W, H,
+                       b.table, stride, b.chunk_sum);
+    EGS_DBG(s);
+    const int prefixed = n_chunks >= EGS_CHUNK_PREFIX_MIN;
+    if (prefixed) hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, s, b.chunk_sum, n_chunks);
+    hipLaunchKernelGGL(k_table_scan, dim3(n_chunks), dim3(EGS_SCAN_THREADS), 0, s, b.table, (size_t)n_tiles * stride, stride, nblocks, b.chunk_sum, n_chunks, b.total, prefixed);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
+                       cull, use_map ? 1 : 0, W, H, b.table, stride, R, b.pairs);
+    egs_prof_stop(EGS_K_DUPLICATE, s);
+    EGS_DBG(s);
     int index_bits = 0; while (((unsigned)(P - 1) >> index_bits) != 0) index_bits++;
-    static std::atomic<int> lds_rank_ok{-1};
-    uint32_t stride = 1; const uint32_t* sort_table = b.tile_start;   // where the sort finds a tile's bucket: tile_start[tile], or the scanned table's first column
-    const int ends_in_table = egs_bin_legacy ? 0 : 1;
-    const uint32_t* need = egs_bin_legacy ? nullptr : (const uint32_t*)b.alloc + 1;     // rectangle instances of the frame: what the capacity must hold
-    if (!egs_bin_legacy) {
-        const EgsBinPlan pl = egs_bin_plan(P, R64, n_tiles);
-        if (pl.n_bins > BE_MAX_BINS || pl.idx_bits + pl.shift > 32) return hipErrorInvalidValue;      // (P >= 2^27 with > 16k tiles)
-        egs_prof_start(EGS_K_DUPLICATE, s);
-        if (!sums_zeroed) { hipError_t e0 = egs_launch_zero_u32((uint32_t*)b.alloc, 2, s); if (e0 != hipSuccess) return e0; }
-        BinEmitArgs ea;
-        ea.P = P; ea.gx = gx; ea.n_tiles = n_tiles; ea.W = W; ea.H = H; ea.cull = cull; ea.shift = pl.shift; ea.n_bins = pl.n_bins; ea.idx_bits = pl.idx_bits;
-        ea.n_rounds = pl.nblocks; ea.cap = R; ea.max_cols = pl.max_cols; ea.row = pl.row;
-        ea.tiles_touched = g.offsets; ea.rect = g.rect; ea.rec = g.rec; ea.block_sums = g.scan_scratch;
-        ea.counters = (uint32_t*)b.alloc; ea.rel = b.rel; ea.colbase = b.colbase; ea.out = b.scratch;
-        hipLaunchKernelGGL(k_bin_emit, dim3(pl.nblocks), dim3(EGS_BIN_THREADS), 0, s, ea);
-        EGS_DBG(s);
-        BinPartArgs pa;
-        pa.n_tiles = n_tiles; pa.shift = pl.shift; pa.n_bins = pl.n_bins; pa.idx_bits = pl.idx_bits; pa.cap = R; pa.n_rounds = pl.nblocks; pa.max_cols = pl.max_cols; pa.row = pl.row;
-        pa.counters = (const uint32_t*)b.alloc; pa.rel = b.rel; pa.colbase = b.colbase; pa.in = b.scratch; pa.pairs = b.pairs; pa.tile_start = b.tile_start; pa.total = b.total;
-        hipLaunchKernelGGL(k_bin_partition, dim3((((unsigned)pl.n_bins + 7) / 8) * 8), dim3(BP_THREADS), 0, s, pa);
-        egs_prof_stop(EGS_K_DUPLICATE, s);
-        EGS_DBG(s);
-    }
-    else {
-        // per-tile counters, then (16-byte aligned) the round's set-up block; fewer groups per round, then no culling, when
-        // the counters leave too little of the 160 KiB (beyond ~28k tiles)
-        const size_t counters = (size_t)((n_tiles + 3) & ~3) * sizeof(uint32_t), room = 160 * 1024 - counters;
-        // the slot walk's owner map (16 KiB at 16 groups) is used where it costs neither groups per round nor the culling: up to ~21k tiles
-        const bool use_map = bin_round_words(EGS_BIN_WAVES, cull != 0, true) * sizeof(uint32_t) <= room;
-        auto fits = [&](int groups, bool with_cull) { return bin_round_words(groups, with_cull, use_map) * sizeof(uint32_t) <= room; };
-        int gpr = EGS_BIN_WAVES;
-        if (cull) {
-            while (gpr > 4 && !fits(gpr, true)) gpr >>= 1;
-            if (!fits(gpr, true)) { cull = 0; gpr = EGS_BIN_WAVES; }
-        }
-        if (!cull) while (gpr > 1 && !fits(gpr, false)) gpr >>= 1;
-        // Two workgroups per CU (all ~489 resident at once, 32 waves per CU to hide the loads behind) beat one with twice the groups per
-        // round: 1M Gaussians @ 1920x1080 (32 KiB of counters) count pass 90.6 -> 77.3 us with 8 groups per round; 4 lose again (84.7).
-        {
-            const bool c = cull != 0;
-            if (gpr == EGS_BIN_WAVES && counters + bin_round_words(gpr, c, use_map) * sizeof(uint32_t) > 80 * 1024 &&
-                counters + bin_round_words(gpr / 2, c, use_map) * sizeof(uint32_t) <= 80 * 1024) gpr /= 2;
-        }
-        const size_t lds = counters + bin_round_words(gpr, cull != 0, use_map) * sizeof(uint32_t);
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        stride = egs_table_stride(nblocks); sort_table = b.table;
-        const uint32_t n_chunks = (uint32_t)egs_table_chunks((size_t)n_tiles, stride);
-        egs_prof_start(EGS_K_DUPLICATE, s);
-        if (!sums_zeroed) {
-            hipError_t e0 = egs_launch_zero_u32(b.chunk_sum, (size_t)EGS_BIN_GROUPS * n_chunks, s);
-            if (e0 != hipSuccess) return e0;
-        }
-        hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, use_map ? 1 : 0, W, H,
-                           b.table, stride, b.chunk_sum);
-        EGS_DBG(s);
-        const int prefixed = n_chunks >= EGS_CHUNK_PREFIX_MIN;
-        if (prefixed) hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, s, b.chunk_sum, n_chunks);
-        hipLaunchKernelGGL(k_table_scan, dim3(n_chunks), dim3(EGS_SCAN_THREADS), 0, s, b.table, (size_t)n_tiles * stride, stride, nblocks, b.chunk_sum, n_chunks, b.total, prefixed);
-        hipLaunchKernelGGL(k_bin_scatter, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks,
-                           cull, use_map ? 1 : 0, W, H, b.table, stride, R, b.pairs);
-        egs_prof_stop(EGS_K_DUPLICATE, s);
-        EGS_DBG(s);
-    }
     // One-time device check of the LDS lane-order property the fast ranking relies on (see wave_digit_rank).
+    static std::atomic<int> lds_rank_ok{-1};
     int fast = lds_rank_ok.load();
     if (fast < 0) {
         uint32_t* flag = b.flag;
@@ -1416,16 +985,16 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     // global-memory path.
     const int solo = (uint64_t)R <= 2048ull * (uint64_t)n_tiles ? 1 : 0;
     if (fast) {
-        hipLaunchKernelGGL((k_tile_sort<true, 4, TS_SMALL_CAP, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, sort_table, ends_in_table, need, b.total, running_max, overflow_flag, solo, R,
+        hipLaunchKernelGGL((k_tile_sort<true, 4, TS_SMALL_CAP, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, solo, R,
                            ip, b.pairs, b.scratch, b.point_list, im.ranges);
         if (!solo)
-            hipLaunchKernelGGL((k_tile_sort<true, 8, 4096, TS_SMALL_CAP + 1u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, sort_table, ends_in_table, need, b.total, running_max, overflow_flag, 0, R,
+            hipLaunchKernelGGL((k_tile_sort<true, 8, 4096, TS_SMALL_CAP + 1u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, 0, R,
                                ip, b.pairs, b.scratch, b.point_list, im.ranges);
     } else {
-        hipLaunchKernelGGL((k_tile_sort<false, 4, TS_SMALL_CAP, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, sort_table, ends_in_table, need, b.total, running_max, overflow_flag, solo, R,
+        hipLaunchKernelGGL((k_tile_sort<false, 4, TS_SMALL_CAP, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, solo, R,
                            ip, b.pairs, b.scratch, b.point_list, im.ranges);
         if (!solo)
-            hipLaunchKernelGGL((k_tile_sort<false, 8, 4096, TS_SMALL_CAP + 1u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, sort_table, ends_in_table, need, b.total, running_max, overflow_flag, 0, R,
+            hipLaunchKernelGGL((k_tile_sort<false, 8, 4096, TS_SMALL_CAP + 1u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, 0, R,
                                ip, b.pairs, b.scratch, b.point_list, im.ranges);
     }
     egs_prof_stop(EGS_K_SORT, s);

@@ -69,17 +69,7 @@ struct EgsBinPtrs {
     uint32_t* chunk_sum;    // [EGS_BIN_GROUPS][chunks] sums of the table's 2048-entry scan chunks, accumulated by k_bin_count; ZERO before it
     uint32_t* flag;         // [32] scratch words
     uint64_t* total;        // [1] number of instances found by the scan (== R)
-    // one-walk bucketing (binning.hip, k_bin_emit / k_bin_partition)
-    unsigned long long* alloc;  // [1] columns << 40 | pairs handed out; ZERO before k_bin_emit
-    uint16_t* rel;          // [max_cols][row] start of every bin's slice inside the column (entry n_bins: the column's length)
-    uint32_t* colbase;      // [max_cols] first slot of the column in `scratch`
-    uint32_t* tile_start;   // [n_tiles + 1] first slot of every tile's bucket in `pairs`
 };
-// Geometry of the one-walk bucketing for (P Gaussians, capacity R, n_tiles): workgroups of k_bin_emit, tiles per bin = 1 << shift, bits of
-// a Gaussian index, table rows (columns) and their length in 16-bit words.
-struct EgsBinPlan { uint32_t nblocks; int shift, n_bins, idx_bits; uint32_t max_cols, row; };
-EgsBinPlan egs_bin_plan(int P, int64_t R, int n_tiles);
-extern int egs_bin_legacy;          // A/B switch (egs_debug_set_bin_legacy): 1 = the two-walk bucketing of rounds 1-4
 #define EGS_BIN_GROUPS 8            // partial accumulators per scan chunk (a same-address atomic chain is bin_blocks / 8 long)
 static inline uint32_t egs_table_stride(uint32_t bin_blocks) { uint32_t s = 4; while (s < bin_blocks) s <<= 1; return s; }   // power of two <= 2048
 static inline size_t egs_table_chunks(size_t n_tiles, uint32_t stride) { const size_t rpc = 2048 / stride; return (n_tiles + rpc - 1) / rpc; }

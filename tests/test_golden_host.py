@@ -72,7 +72,8 @@ def test_covariance_matches_reference():
     g = load("covariance.npz")
     ls, q, w = T(g["log_scale"]).requires_grad_(True), T(g["quat"]).requires_grad_(True), T(g["wcov"])
     cov = covariance_from_scaling_rotation(torch.exp(ls), 1.0, q)
-    assert np.allclose(cov.detach().numpy(), g["cov"], rtol=1e-5, atol=1e-9)
+    # (off-diagonal terms cancel: on other host CPUs -- the GPU box's -- the last bits of small elements move; the bar is relative to the largest element)
+    assert np.allclose(cov.detach().numpy(), g["cov"], rtol=1e-5, atol=1e-6 * float(np.abs(g["cov"]).max()))
     (cov * w).sum().backward()
     assert np.allclose(ls.grad.numpy(), g["g_scaling"], rtol=1e-4, atol=1e-7)
     assert np.allclose(q.grad.numpy(), g["g_rotation"], rtol=1e-4, atol=1e-6)
@@ -80,14 +81,14 @@ def test_covariance_matches_reference():
     ls.grad = None; q.grad = None
     R, is_obj = T(g["accum_R"]), T(g["is_object"])
     rc = rotated_covariance_from_scaling_rotation(torch.exp(ls), 1.0, q, R, is_obj, 1)
-    assert np.allclose(rc.detach().numpy(), g["rcov"], rtol=1e-5, atol=1e-9)
+    assert np.allclose(rc.detach().numpy(), g["rcov"], rtol=1e-5, atol=1e-6 * float(np.abs(g["rcov"]).max()))
     (rc * w).sum().backward()
     assert np.allclose(ls.grad.numpy(), g["rg_scaling"], rtol=1e-4, atol=1e-7)
     assert np.allclose(q.grad.numpy(), g["rg_rotation"], rtol=1e-4, atol=1e-6)
     assert np.allclose(rotated_covariance_from_scaling_rotation(torch.exp(ls), 1.0, q, torch.eye(3), is_obj, 1).detach().numpy(),
-                       g["rcov_identity"], rtol=1e-5, atol=1e-9)
+                       g["rcov_identity"], rtol=1e-5, atol=1e-6 * float(np.abs(g["rcov_identity"]).max()))
     assert np.allclose(rotated_covariance_from_scaling_rotation(torch.exp(ls), 1.0, q, R, is_obj, None).detach().numpy(),
-                       g["rcov_all"], rtol=1e-5, atol=1e-9)
+                       g["rcov_all"], rtol=1e-5, atol=1e-6 * float(np.abs(g["rcov_all"]).max()))
 
 
 def _model_from_boundary(g, device="cpu"):
