@@ -43,7 +43,7 @@ class StepGuard:
         self.overflows = 0                    # frames of this guard that were clipped (found at the following forward / check())
         self.frames = 0
         self.last_R = 0                       # rectangle instances of the last CHECKED frame
-        self._pending = []                    # frames not checked yet, oldest first: (page-locked counts, P, capacity, device index)
+        self._pending = []                    # frames not checked yet, oldest first: (page-locked counts, P, capacity, device index, event behind its copies)
         self._pinned = [None] * _DEFER_RING
 
     def check(self):
@@ -60,13 +60,13 @@ def _settle(guard, wait=False):
     word tells); raise the capacity hint when one did not fit.  Never waits for the GPU unless `wait` or the ring is full: a host
     that runs ahead of the GPU (no synchronisation in its loop) checks a frame a few forwards later instead."""
     while guard._pending:
-        pinned, P, cap, key = guard._pending[0]
+        pinned, P, cap, key, ev = guard._pending[0]
         nb = (P + 255) // 256
         tail = pinned[nb:nb + 2]
         if int(tail[0]) == -1:                # the copy that ends the frame's chain has not landed yet (the sentinel is still there)
             if not (wait or len(guard._pending) >= _DEFER_RING - 1):
                 return
-            torch.cuda.synchronize(key)
+            ev.synchronize()                  # THIS frame's copies only: later frames and other streams keep running
         guard._pending.pop(0)
         R = int(_lib.load().egs_sum_counts(int(P), C.c_void_p(pinned.data_ptr())))
         clipped, kept = int(tail[0]), int(tail[1]) & 0xffffffff
@@ -289,7 +289,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
                 _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), C.c_void_p(pin.data_ptr()), _ptr(guard.running_max),
                 _ptr(active_count), _ptr(guard.overflow), _ptr(place), rot_arg, _stream(dev)))
-            guard._pending.append((pin, P, cap, key))
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))             # behind the frame's last copy (egs_forward_enqueue queued it on this stream)
+            guard._pending.append((pin, P, cap, key, ev))
             guard.frames += 1
             R = C.c_int64(cap)                      # layout size, as under capture; the frame's own count is read at the next call
             rc = 0

@@ -563,17 +563,11 @@ int egs_backward_adam(int P, int sh_degree, int sh_coeffs, int64_t R, const floa
                          skip_flag, sink, prologue_done, rot, grad_mask, scratch, stream, debug);
 }
 
-int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
-                            const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
-                            const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
-                            float* loss_running_sum, const egs_backward_prologue* side, void* stream) {
-    if (!side)
-        return egs_launch_l1_ssim_backward(channels, height, width, img, gt, lambda_dssim, upstream_grad, gate, dm_dmu1, dm_dexx, dm_dexy, dL_dimg,
-                                           deferred_partial_sums, deferred_loss, loss_running_sum, nullptr, (hipStream_t)stream);
+// egs_backward_prologue (HOST struct) -> the side jobs a loss backward launch carries
+static int prologue_args(const egs_backward_prologue* side, EgsPrologueArgs& pa) {
     int rc = check_dims(side->P, side->width, side->height); if (rc) return rc;
     if (side->P <= 0 || !side->image_buffer || !side->scratch) return EGS_ERR_ARG;
     EgsImgPtrs im = img_ptrs(side->image_buffer, side->width, side->height);
-    EgsPrologueArgs pa = {};
     pa.n_tiles = ((side->width + EGS_TILE - 1) / EGS_TILE) * ((side->height + EGS_TILE - 1) / EGS_TILE);
     pa.quad_work = im.quad_work; pa.tile_order = im.tile_order;
     if (side->geom_buffer && misaligned(side->geom_buffer)) return EGS_ERR_ARG;
@@ -585,8 +579,31 @@ int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* im
         sink_to_kernel_args(side->sink, side->skip_flag, ks, pa.tick);
         pa.has_tick = 1;
     }
+    return 0;
+}
+
+int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
+                            const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
+                            const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
+                            float* loss_running_sum, const egs_backward_prologue* side, void* stream) {
+    if (!side)
+        return egs_launch_l1_ssim_backward(channels, height, width, img, gt, lambda_dssim, upstream_grad, gate, dm_dmu1, dm_dexx, dm_dexy, dL_dimg,
+                                           deferred_partial_sums, deferred_loss, loss_running_sum, nullptr, (hipStream_t)stream);
+    EgsPrologueArgs pa = {};
+    int rc = prologue_args(side, pa); if (rc) return rc;
     return egs_launch_l1_ssim_backward(channels, height, width, img, gt, lambda_dssim, upstream_grad, gate, dm_dmu1, dm_dexx, dm_dexy, dL_dimg,
                                        deferred_partial_sums, deferred_loss, loss_running_sum, &pa, (hipStream_t)stream);
+}
+
+int egs_l1_ssim_pair_backward(int channels, int height, int width, const float* img, const float* gt, const float* upstream_l1,
+                              const float* upstream_ssim, const float* gate, const float* dm_dmu1, const float* dm_dexx, const float* dm_dexy,
+                              float* dL_dimg, const egs_backward_prologue* side, void* stream) {
+    if (!upstream_l1 || !upstream_ssim) return EGS_ERR_ARG;
+    EgsPrologueArgs pa = {};
+    if (side) { int rc = prologue_args(side, pa); if (rc) return rc; }
+    // d(mean SSIM) = -d(1 - mean SSIM): weight -1 on the kernel's (1 - SSIM) term, each term times its own upstream scalar (read on the device)
+    return egs_launch_l1_ssim_backward_w(channels, height, width, img, gt, 1.f, -1.f, 0.f, upstream_l1, upstream_ssim, gate, dm_dmu1, dm_dexx, dm_dexy, dL_dimg,
+                                         nullptr, nullptr, nullptr, side ? &pa : nullptr, (hipStream_t)stream);
 }
 
 int egs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

@@ -199,6 +199,12 @@ __device__ __forceinline__ void egs_prologue_job(const EgsPrologueArgs& a, const
 }
 
 // loss.hip: the image loss's backward, optionally carrying the jobs above (side != NULL)
+// the same launch with the two terms weighed apart: w_l1_n / w_ssim_n = weights of mean|x - y| and of (1 - mean SSIM) before the division by
+// the element count; upstream_ssim != NULL: each term times its own upstream scalar (egs_l1_ssim_pair_backward)
+int egs_launch_l1_ssim_backward_w(int channels, int height, int width, const float* img, const float* gt, float w_l1_n, float w_ssim_n, float lambda_dssim,
+                                  const float* upstream_grad, const float* upstream_ssim, const float* gate, const float* dm_dmu1, const float* dm_dexx,
+                                  const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
+                                  float* loss_running_sum, const EgsPrologueArgs* side, hipStream_t stream);
 int egs_launch_l1_ssim_backward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
                                 const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
                                 const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,

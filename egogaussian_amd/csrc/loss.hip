@@ -324,7 +324,8 @@ __device__ __forceinline__ void wave_finish_loss(size_t nblocks, const float* __
 template <bool SIDE>
 __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_backward(int H, int W, int strips_x, int strips_y, const float* __restrict__ img,
                                                                 const float* __restrict__ gt, float w_l1, float w_ssim,
-                                                                const float* __restrict__ upstream, const float* __restrict__ gate,
+                                                                const float* __restrict__ upstream, const float* __restrict__ upstream_ssim,
+                                                                const float* __restrict__ gate,
                                                                 const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dexx,
                                                                 const float* __restrict__ dm_dexy, float* __restrict__ dimg,
                                                                 const float* __restrict__ fin_partial, size_t fin_n, float fin_lambda,
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_backward(int H, int W, int
     BwdCtx c;
     c.H = H; c.W = W; c.lane = lane; c.img = img; c.gt = gt; c.m0 = dm_dmu1; c.m1 = dm_dexx; c.m2 = dm_dexy; c.gate = gate; c.dimg = dimg;
     c.rows = lds[wv]; c.plane = (size_t)plane_z * H * W; c.w_l1 = w_l1; c.w_ssim = w_ssim; c.up = upstream[0];
+    if (upstream_ssim) { c.w_l1 *= c.up; c.w_ssim *= upstream_ssim[0]; c.up = 1.f; }      // the two terms with an upstream scalar each (egs_l1_ssim_pair_backward)
     const int sx = strip % strips_x, sy = strip / strips_x;
     c.gx = sx * SW - HALO + (int)lane;
     c.col_ok = c.gx >= 0 && c.gx < W;
@@ -404,10 +406,39 @@ __global__ __launch_bounds__(1024) void k_l1_ssim_finish(size_t nblocks, const f
     }
 }
 
+// the two means as two values (egs_l1_ssim_pair_forward)
+__global__ __launch_bounds__(1024) void k_l1_ssim_finish_pair(size_t nblocks, const float* __restrict__ partial, float inv_n, float* __restrict__ l1_out,
+                                                               float* __restrict__ ssim_out) {
+    __shared__ float red[2][16];
+    float a = 0.f, b = 0.f;
+    for (size_t i = threadIdx.x; i < nblocks; i += 1024) { const float2 v = reinterpret_cast<const float2*>(partial)[i]; a += v.x; b += v.y; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ta = 0.f, tb = 0.f;
+        for (int k = 0; k < 16; k++) { ta += red[0][k]; tb += red[1][k]; }
+        l1_out[0] = inv_n * ta; ssim_out[0] = inv_n * tb;
+    }
+}
+
 }  // namespace
 
+int egs_launch_l1_ssim_backward_w(int channels, int height, int width, const float* img, const float* gt, float w_l1_n, float w_ssim_n, float lambda_dssim,
+                                const float* upstream_grad, const float* upstream_ssim, const float* gate, const float* dm_dmu1, const float* dm_dexx,
+                                const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
+                                float* loss_running_sum, const EgsPrologueArgs* side, hipStream_t stream);
 int egs_launch_l1_ssim_backward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
                                 const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
+                                const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
+                                float* loss_running_sum, const EgsPrologueArgs* side, hipStream_t stream) {
+    return egs_launch_l1_ssim_backward_w(channels, height, width, img, gt, 1.f - lambda_dssim, lambda_dssim, lambda_dssim, upstream_grad, nullptr, gate, dm_dmu1,
+                                     dm_dexx, dm_dexy, dL_dimg, deferred_partial_sums, deferred_loss, loss_running_sum, side, stream);
+}
+// w_l1_n, w_ssim_n: the weights of mean|x - y| and of (1 - mean SSIM) BEFORE the division by the element count
+int egs_launch_l1_ssim_backward_w(int channels, int height, int width, const float* img, const float* gt, float w_l1_n, float w_ssim_n, float lambda_dssim,
+                                const float* upstream_grad, const float* upstream_ssim, const float* gate, const float* dm_dmu1, const float* dm_dexx,
                                 const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
                                 float* loss_running_sum, const EgsPrologueArgs* side, hipStream_t stream) {
     if (channels <= 0 || height <= 0 || width <= 0 || !img || !gt || !upstream_grad || !dm_dmu1 || !dm_dexx || !dm_dexy || !dL_dimg)
@@ -423,7 +454,7 @@ int egs_launch_l1_ssim_backward(int channels, int height, int width, const float
     const unsigned spare = main_pad + EGS_XCDS + 1 + 32 <= 1024 ? 1024 - main_pad - EGS_XCDS - 1 : 32;
     const unsigned side_jobs = side ? egs_prologue_jobs(side->n4, side->has_tick, 64 * WPB, spare) : 0u;
     EgsPrologueArgs none = {};
-#define LB_ARGS height, width, strips_x, strips_y, img, gt, (1.f - lambda_dssim) / n, lambda_dssim / n, upstream_grad, gate, dm_dmu1, dm_dexx, \
+#define LB_ARGS height, width, strips_x, strips_y, img, gt, w_l1_n / n, w_ssim_n / n, upstream_grad, upstream_ssim, gate, dm_dmu1, dm_dexx, \
                 dm_dexy, dL_dimg, deferred_partial_sums, (size_t)strips_x * strips_y * channels, lambda_dssim, deferred_loss,            \
                 deferred_partial_sums ? loss_running_sum : nullptr, per_plane, main_wgs, side_jobs
     if (side) hipLaunchKernelGGL(k_l1_ssim_backward<true>, dim3(side_jobs + main_pad), dim3(64 * WPB), 0, stream, LB_ARGS, *side);
@@ -455,6 +486,17 @@ int egs_l1_ssim_forward(int channels, int height, int width, const float* img, c
     if (loss)                                       // loss == NULL: the value is assembled by egs_l1_ssim_backward (deferred)
         hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, (size_t)strips_x * strips_y * channels, partial_sums,
                            (1.f - lambda_dssim) / n, lambda_dssim / n, lambda_dssim, loss, loss_running_sum);
+    return (int)hipGetLastError();
+}
+
+int egs_l1_ssim_pair_forward(int channels, int height, int width, const float* img, const float* gt, float* partial_sums, float* dm_dmu1,
+                             float* dm_dexx, float* dm_dexy, float* l1_out, float* ssim_out, void* stream) {
+    if (!l1_out || !ssim_out) return EGS_ERR_ARG;
+    const int rc = egs_l1_ssim_forward(channels, height, width, img, gt, 0.f, partial_sums, dm_dmu1, dm_dexx, dm_dexy, nullptr, nullptr, stream);
+    if (rc) return rc;
+    const int strips_x = (width + SW - 1) / SW, strips_y = (height + SR - 1) / SR;
+    hipLaunchKernelGGL(k_l1_ssim_finish_pair, dim3(1), dim3(1024), 0, (hipStream_t)stream, (size_t)strips_x * strips_y * channels, partial_sums,
+                       1.f / ((float)channels * (float)height * (float)width), l1_out, ssim_out);
     return (int)hipGetLastError();
 }
 

@@ -180,6 +180,60 @@ class _L1SSIM(torch.autograd.Function):
         return dimg, None, None, None, None, None, None
 
 
+class _L1SSIMPair(torch.autograd.Function):
+    """(mean|img - gt|, mean SSIM(img, gt)) from one forward launch; one backward launch for both upstream scalars
+    (include/egs_raster.h egs_l1_ssim_pair_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, img, gt, raster_node=None):
+        L = _lib.load()
+        img, gt = _need_hip(img, "image"), _need_hip(gt, "gt")
+        assert img.dim() == 3 and img.shape == gt.shape
+        Cc, H, W = img.shape
+        dev = img.device
+        partial = torch.empty(L.egs_l1_ssim_partial_count(Cc, H, W), device=dev)
+        maps = torch.empty((3, Cc, H, W), device=dev)
+        vals = torch.empty(2, device=dev)
+        ctx.raster_node = raster_node
+        with _hip.device_ctx(dev):
+            _lib.check(L.egs_l1_ssim_pair_forward(Cc, H, W, _p(img), _p(gt), _p(partial), _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(vals[0:1]),
+                                                  _p(vals[1:2]), _stream(dev)))
+        ctx.save_for_backward(img, gt, maps)
+        return vals[0], vals[1]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim):
+        L = _lib.load()
+        img, gt, maps = ctx.saved_tensors
+        Cc, H, W = img.shape
+        ups = torch.zeros(2, device=img.device) if (g_l1 is None or g_ssim is None) else None
+        up = lambda g, k: (ups[k:k + 1] if g is None else g.reshape(1).float().contiguous())
+        u1, u2 = up(g_l1, 0), up(g_ssim, 1)
+        dimg = torch.empty_like(img)
+        side = None
+        if ctx.raster_node is not None:
+            from .rasterizer import backward_prologue_of
+            side = backward_prologue_of(ctx.raster_node)
+        with _hip.device_ctx(img.device):
+            _lib.check(L.egs_l1_ssim_pair_backward(Cc, H, W, _p(img), _p(gt), _p(u1), _p(u2), None, _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(dimg),
+                                                   C.byref(side) if side is not None else None, _stream(img.device)))
+        return dimg, None, None
+
+
+def l1_and_ssim(image, gt, raster_prologue=True):
+    """-> (mean |image - gt|, mean SSIM(image, gt)) as two differentiable scalars from ONE HIP launch each way: the reference's
+    l1_loss(x, gt) and ssim(x, gt) (/root/reference/utils/loss_utils.py:57-58,79-107) when a loop combines them itself.
+    raster_prologue: when `image` is the rasterizer's output itself, the backward launch also carries the preparation of the rasterizer's
+    backward (as l1_ssim_loss(raster_prologue=True)): one launch less per iteration, results unchanged (a gradient hook on the image,
+    the reference's hand mask, sits between the two backwards and is unaffected)."""
+    node = None
+    if raster_prologue:
+        fn = image.grad_fn
+        if fn is not None and getattr(fn, "egs_raster_node", False):
+            node = fn
+    return _L1SSIMPair.apply(image, gt, node)
+
+
 def l1_ssim_loss(image, gt, lambda_dssim=0.2, grad_gate=None, running_sum=None, defer_value=False, raster_prologue=False):
     """(1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)).  `grad_gate` [H,W] multiplies d loss / d image
     per pixel (the reference's `render_image.register_hook(lambda grad: grad * (1 - hand_mask))`).

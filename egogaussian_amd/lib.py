@@ -81,6 +81,9 @@ SIGNATURES = {
     "egs_l1_ssim_partial_count": (C.c_size_t, [i32, i32, i32]),
     "egs_l1_ssim_forward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     "egs_l1_ssim_backward": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "egs_l1_ssim_pair_forward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+
+    "egs_l1_ssim_pair_backward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(BackwardPrologue), vp]),
     "egs_l1_ssim_backward_ex": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(BackwardPrologue), vp]),
     "egs_adam_step": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
     "egs_adam_workgroups": (C.c_int64, [i64]),
@@ -152,6 +155,10 @@ def load():
     # runtime live in the process.  That works as long as TORCH's copy is the one that opened the device first; the other way round --
     # this library loaded (its kernels registered) before torch's first HIP call -- every launch of ours then fails with
     # hipErrorNoDevice (found by running build() and smoke() in one process).  So: bring torch's runtime up first when a device exists.
+    # ... and, since this creates the HIP context, first export what a later multi-process RCCL group needs from the environment while
+    # it can still be set (dist.REQUIRED_ENV; dmabuf-only hosts fail with hipIpcGetMemHandle otherwise) -- only if the caller left it unset.
+    for k, v in (("HSA_ENABLE_IPC_MODE_LEGACY", "0"),):
+        os.environ.setdefault(k, v)
     try:
         import torch
         if torch.cuda.is_available():

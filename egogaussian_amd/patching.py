@@ -15,8 +15,8 @@ before the trainers are imported is enough -- no reference file is edited, none 
 
 What is replaced (by attribute; each replacement falls back to the original for anything it does not cover -- CPU tensors,
 batched images, other window sizes):
-  utils.loss_utils.l1_loss     -> fused.l1_ssim_loss(x, gt, lambda = 0): mean |x - gt|, one HIP launch each way
-  utils.loss_utils.ssim        -> 1 - fused.l1_ssim_loss(x, gt, lambda = 1): the 11x11 sigma-1.5 SSIM mean, one HIP launch each way
+  utils.loss_utils.l1_loss     -> mean |x - gt|          } fused.l1_and_ssim(x, gt): called one after the other on the same pair (as the trainers
+  utils.loss_utils.ssim        -> the 11x11 SSIM mean    } do), ONE HIP launch each way serves both; alone, one launch each
   scene.gaussian_model.GaussianModel.setup_functions -> the original, then adapter.attach(self, optimizer=False): the covariance
                                   producers the reference's render() calls (`covariance_activation`, `covariance_activation_w_rot`)
   scene.gaussian_model.GaussianModel.training_setup  -> the original, then adapter.attach(self): its torch.optim.Adam becomes a
@@ -61,17 +61,30 @@ def make_loss_functions(orig_l1=None, orig_ssim=None):
     orig_l1 = orig_l1 or losses.l1_loss
     orig_ssim = orig_ssim or (lambda a, b, window_size=11, size_average=True: losses.ssim(a, b))
 
+    # The trainers call l1_loss(x, gt) and ssim(x, gt) on the SAME pair one after the other (train_static.py:92-95): the first call runs
+    # the fused kernel once for both values, the second takes its half -- and one backward launch serves both (fused.l1_and_ssim).
+    pending = {}
+
+    def _pair(a, b, want):
+        key = (id(a), a._version, b.data_ptr(), b._version)
+        hit = pending.pop("pair", None)
+        if hit is not None and hit[0] == key and hit[1] is a and hit[2] != want:
+            return hit[3]
+        l1v, ssv = fused.l1_and_ssim(a, b.detach())
+        pending["pair"] = (key, a, want, ssv if want == "l1" else l1v)     # the other half, for the call that follows
+        return l1v if want == "l1" else ssv
+
     def l1_loss(network_output, gt):
-        if _hip_image_pair(network_output, gt):
+        if _hip_image_pair(network_output, gt) and not gt.requires_grad:
             calls["l1_loss"] += 1
-            return fused.l1_ssim_loss(network_output, gt.detach(), 0.0)
+            return _pair(network_output, gt, "l1")
         calls["l1_loss_fallback"] += 1
         return orig_l1(network_output, gt)
 
     def ssim(img1, img2, window_size=11, size_average=True):
         if window_size == 11 and size_average and _hip_image_pair(img1, img2) and not img2.requires_grad:
             calls["ssim"] += 1
-            return 1.0 - fused.l1_ssim_loss(img1, img2, 1.0)
+            return _pair(img1, img2, "ssim")
         calls["ssim_fallback"] += 1
         return orig_ssim(img1, img2, window_size, size_average)
     l1_loss.__wrapped__, ssim.__wrapped__ = orig_l1, orig_ssim

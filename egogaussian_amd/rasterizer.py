@@ -42,6 +42,16 @@ class _RasterizeGaussians(torch.autograd.Function):
                 activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None, optimizer=None,
                 object_rotation=None):
         rs = raster_settings
+        if guard is not None and getattr(guard, "deferred", False) and any(ctx.needs_input_grad) and not getattr(optimizer, "capturable", False) \
+                and not getattr(guard, "_warned", False):
+            # a deferred frame that turns out clipped is voided ON THE DEVICE -- by the statistics and the Adam step that read the overflow
+            # word, i.e. a FusedAdam(capturable=True) taking its step inside this backward or launched with this guard.  Any other optimizer
+            # would apply the clipped frame's gradient unnoticed.
+            import warnings
+            guard._warned = True
+            warnings.warn("StepGuard(deferred=True) without a FusedAdam(capturable=True) behind it: a frame that exceeds the instance capacity is "
+                          "only counted (guard.overflows), its clipped gradient is NOT voided -- pass optimizer=FusedAdam(..., capturable=True) "
+                          "with guard set on it, or check guard.overflows before optimizer.step()", RuntimeWarning)
         ctx.object_rotation = object_rotation     # (M, selected, multiplier): constants of the loss (include/egs_raster.h egs_object_rotation)
         # optimizer (extension): a FusedAdam(capturable=True) whose leaves among THIS call's inputs take their step inside the backward
         ctx.sink = None if (optimizer is None or not any(ctx.needs_input_grad)) else optimizer.make_sink(

@@ -377,6 +377,13 @@ int egs_l1_ssim_forward(int channels, int height, int width, const float* img /*
                         float lambda_dssim, float* partial_sums /*scratch*/, float* dm_dmu1, float* dm_dexx, float* dm_dexy,
                         float* loss /*device [1] out, or NULL: deferred*/, float* loss_running_sum /*device [1] in/out or NULL*/,
                         void* stream);
+/* ABI 4: the two terms as two values, for a loop that combines them itself -- the reference's trainers call l1_loss(x, gt) and
+ * ssim(x, gt) (/root/reference/utils/loss_utils.py:57-58,79-107) and weigh them in Python (trainers/train_static.py:92-95).  ONE forward
+ * launch (+ a one-workgroup reduction) yields mean|x - gt| and mean SSIM; ONE backward launch takes an upstream scalar for each, read on
+ * the device (autograd hands them over as tensors).  Same kernels and maps as egs_l1_ssim_forward / _backward; the backward is declared
+ * behind egs_backward_prologue below (it can carry a rasterizer backward's preparation like egs_l1_ssim_backward_ex). */
+int egs_l1_ssim_pair_forward(int channels, int height, int width, const float* img, const float* gt, float* partial_sums, float* dm_dmu1,
+                             float* dm_dexx, float* dm_dexy, float* l1_out /*[1]*/, float* ssim_out /*[1]*/, void* stream);
 int egs_l1_ssim_backward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
                          const float* upstream_grad /*device [1]*/, const float* gate /*[H,W] or NULL*/,
                          const float* dm_dmu1, const float* dm_dexx, const float* dm_dexy, float* dL_dimg /*[C,H,W] out*/,
@@ -399,6 +406,9 @@ typedef struct egs_backward_prologue {
     const void* geom_buffer;         /* ABI 3: of that call's forward, or NULL.  With it only the accumulator lines in use are cleared
                                       * (the replica lines of the frame's hot Gaussians, csrc/egs_common.h); NULL: all of them */
 } egs_backward_prologue;
+int egs_l1_ssim_pair_backward(int channels, int height, int width, const float* img, const float* gt, const float* upstream_l1 /*[1]*/,
+                              const float* upstream_ssim /*[1]*/, const float* gate /*[H,W] or NULL*/, const float* dm_dmu1, const float* dm_dexx,
+                              const float* dm_dexy, float* dL_dimg, const egs_backward_prologue* side /*HOST or NULL*/, void* stream);
 int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
                             const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
                             const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,

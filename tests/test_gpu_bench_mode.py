@@ -84,16 +84,16 @@ def test_config_C_bench_mode_vs_oracle():
     grads_or = dict(xyz=gb["dL_dmeans3D"], f_dc=gb["dL_dsh"].reshape(N, 1, 3), opacity=leaf["opacity"].grad.numpy(),
                     scaling=leaf["scaling"].grad.numpy(), rotation=leaf["rotation"].grad.numpy())
     e_img, f_img = rel_err(img_hip, st["color"]), outlier_fraction(img_hip, st["color"], TOL)
-    flips = int((np.abs(img_hip - st["color"]) > TOL * np.abs(st["color"]).max()).any(0).sum())
-    print(f"\n  config C, benched mode: R = {st['R']}, image max rel err {e_img:.2e}, pixels off by more than {TOL:g}: {flips}")
+    from tests.common import flip_pixels, check_grads_isolating_flips
+    # (the transmittance plane of the REPLAYED frame: the captured forward's image buffer, which every replay rewrites)
+    final_T_hip = _C.image_views(_C.stats["image_buffer"], W, H)["final_T"].cpu().numpy()
+    flip_px = flip_pixels(img_hip, final_T_hip, st)
+    print(f"\n  config C, benched mode: R = {st['R']}, image max rel err {e_img:.2e}, pixels off by more than float noise: {int(flip_px.sum())}")
     assert f_img <= 1e-4 and e_img < 2e-2
-    for k in grads_or:
-        e, f = rel_err(grads_hip[k], grads_or[k]), outlier_fraction(grads_hip[k], grads_or[k], TOL)
-        print(f"    d/d{k}: max rel err {e:.2e}, entries off by more than {TOL:g}: {f:.1e}")
-        if flips == 0:
-            assert e < TOL, k
-        else:
-            assert f <= 2e-4 and e < 5e-3, k
+    keys = list(grads_or)
+    rep, _, _ = check_grads_isolating_flips(keys, [grads_hip[k] for k in keys], {k: np.asarray(grads_or[k]) for k in keys}, st, flip_px, TOL,
+                                            what="config C benched mode", halo=10, far_frac=1e-4, far_cap=10.0)     # (each side's upstream gradient comes from ITS image through the 11x11 SSIM window, forward and backward: 10 pixels)
+    print("    " + rep)
 
 
 def test_training_psnr_parity_300_steps_float_and_8bit():
@@ -183,3 +183,32 @@ def test_bench_two_ranks_plain_launch():
     fa = j["fine_all_shape"]
     assert fa["n_gpus"] == 2 and fa["value"] > 0 and fa["launch"].startswith("one hipGraph") and math.isfinite(fa["psnr_db"])
     assert j["roofline"]["pairs_Q"] > 0 and j["roofline"]["visits"] > 0
+
+
+def test_bench_eight_ranks_share_one_device():
+    """`python bench.py --gpus 8` as the driver's 8-GPU run launches it, rehearsed on the one GPU of the test box: eight ranks on device 0
+    over gloo (EGS_BENCH_SHARE_DEVICE0; RCCL refuses several ranks on one device).  Everything but RCCL itself is what the 8-GPU node
+    will run: the frame sharding (rank r takes frames r, r + 8, ...), equal replicas at the start, per-rank graph-replayed steps, the
+    barriers, the max-over-ranks time and the reduced scalars.  No scaling curve comes out of this -- eight ranks share one GPU."""
+    env = dict(os.environ, EGS_BENCH_SHARE_DEVICE0="1", EGS_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    W8, steps, warm = 8, 4, 2
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(W8), "--steps", str(steps), "--warmup", str(warm), "--gaussians", "30000", "--height", "180",
+           "--width", "320", "--no-cpu-baseline", "--no-sh3-leg", "--no-fine-all-leg", "--verify-ranks", "--steps-per-replay", "2"]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-3000:]
+    j = json.loads([l for l in run.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == W8 and j["steps"] == steps and j["scaling"] == "weak" and j["value"] > 0 and j["collective"] == "gloo"
+    ranks = sorted(j["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == list(range(W8))
+    seen = set()
+    for r in ranks:
+        assert r["frames"] == list(range(r["rank"], W8 * (steps + warm), W8)), r           # round-robin shard, warm-up + timed frames
+        assert not (seen & set(r["frames"])); seen |= set(r["frames"])
+        assert r["param_checksum_start"] == ranks[0]["param_checksum_start"]                # equal replicas
+        assert r["graph"] and r["overflow"]["ok"] and r["loss_sum"] > 0
+        assert r["setup_s"] < 600, r                                                        # bounded set-up per rank (eight processes share one GPU here)
+    assert len({r["loss_sum"] for r in ranks}) == W8                                        # different frames, different losses
+    assert abs(j["mean_loss"] - sum(r["loss_sum"] for r in ranks) / (W8 * steps)) < 1e-6    # the all-reduced scalar
+    assert abs(j["value"] - W8 * steps / (j["ms_per_step"] * steps * 1e-3)) < 1e-3 * j["value"]      # whole-job rate = all ranks' steps / max-over-ranks time

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import make_inputs, seeded_grads, rel_err, outlier_fraction, tile_culling
+from tests.common import flip_pixels, make_inputs, seeded_grads, rel_err, outlier_fraction, tile_culling
 from tests.test_gpu_parity import hip_forward, hip_backward, oracle_forward, _dev, TOL
 
 pytestmark = pytest.mark.gpu
@@ -31,20 +31,10 @@ def _hot_codes(geom, N, radii):
     return np.where(radii.cpu().numpy() > 0, ((bx >> 15) & 1) | ((bx >> 30) & 2) | ((by >> 13) & 4), 0)
 
 
-def _check_grads(hb, gb, flips, what):
-    rep = []
-    for name, h in zip(NAMES, hb):
-        ora = gb.get(name)
-        if ora is None or h.numel() == 0:
-            continue
-        e = rel_err(h.cpu().numpy().reshape(ora.shape), ora)
-        f = outlier_fraction(h.cpu().numpy().reshape(ora.shape), ora, TOL)
-        rep.append(f"{name} {e:.1e}")
-        if flips == 0:
-            assert e < TOL, f"{what} {name}: max rel err {e} with no threshold flip"
-        else:
-            assert f <= 2e-4 and e < 5e-3, f"{what} {name}: {f} of entries off, max rel err {e} ({flips} flipped pixels)"
-    return "; ".join(rep)
+def _check_grads(hb, gb, st, flip_px, what):
+    """Gaussians away from every threshold flip at 1e-4, the ones in a flipped pixel's tile list by a pair's share (tests/common.py)."""
+    from tests.common import check_grads_isolating_flips
+    return check_grads_isolating_flips(NAMES, hb, gb, st, flip_px, TOL, what=what)[0]
 
 
 @pytest.mark.parametrize("cull", [False, True], ids=["reference-lists", "tile-culling"])
@@ -76,12 +66,9 @@ def test_hot_gaussians_accumulate_through_replica_lines(cull):
     iv = _C.image_views(out[7], W, H)
     for name, hip, ora in (("color", out[1], st["color"]), ("depth", out[2], st["depth"]), ("alpha", out[3], st["alpha"])):
         assert outlier_fraction(hip.cpu().numpy(), ora, TOL) <= 1e-4, name
-    flips = int(((np.abs(out[1].cpu().numpy() - st["color"]) > TOL * np.abs(st["color"]).max()).any(0) |
-                 (np.abs(iv["final_T"].cpu().numpy() - st["final_T"]) > TOL)).sum())
-    if not cull:
-        flips += int((iv["n_contrib"].cpu().numpy().view(np.uint32) != st["n_contrib"]).sum())
+    flip_px = flip_pixels(out[1].cpu().numpy(), iv["final_T"].cpu().numpy(), st, None if cull else iv["n_contrib"].cpu().numpy().view(np.uint32))
     gb = o.backward(st, *grads)
-    print("\n   hot replica lines: " + _check_grads(hb, gb, flips, "hot") + f"; flips {flips}")
+    print("\n   hot replica lines: " + _check_grads(hb, gb, st, flip_px, "hot"))
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
@@ -121,12 +108,9 @@ def test_random_hot_layouts_vs_oracle(seed):
     iv = _C.image_views(out[7], W, H)
     for name, hip, ora in (("color", out[1], st["color"]), ("depth", out[2], st["depth"]), ("alpha", out[3], st["alpha"])):
         assert outlier_fraction(hip.cpu().numpy(), ora, TOL) <= 1e-4, name
-    flips = int(((np.abs(out[1].cpu().numpy() - st["color"]) > TOL * np.abs(st["color"]).max()).any(0) |
-                 (np.abs(iv["final_T"].cpu().numpy() - st["final_T"]) > TOL)).sum())
-    if not cull:
-        flips += int((iv["n_contrib"].cpu().numpy().view(np.uint32) != st["n_contrib"]).sum())
+    flip_px = flip_pixels(out[1].cpu().numpy(), iv["final_T"].cpu().numpy(), st, None if cull else iv["n_contrib"].cpu().numpy().view(np.uint32))
     gb = o.backward(st, *grads)
-    print(f"\n   [{N}@{W}x{H} {mode} cull={cull}] {len(big)} large splats, {int((code != 0).sum())} hot: " + _check_grads(hb, gb, flips, "random hot") + f"; flips {flips}")
+    print(f"\n   [{N}@{W}x{H} {mode} cull={cull}] {len(big)} large splats, {int((code != 0).sum())} hot: " + _check_grads(hb, gb, st, flip_px, "random hot"))
 
 
 def _trained_inputs():
@@ -171,8 +155,7 @@ def test_trained_scene_vs_oracle():
     iv = _C.image_views(out[7], W, H)
     for name, hip, ora in (("color", out[1], st["color"]), ("depth", out[2], st["depth"]), ("alpha", out[3], st["alpha"])):
         assert outlier_fraction(hip.cpu().numpy(), ora, TOL) <= 1e-4, name
-    flips = int(((np.abs(out[1].cpu().numpy() - st["color"]) > TOL * np.abs(st["color"]).max()).any(0) |
-                 (np.abs(iv["final_T"].cpu().numpy() - st["final_T"]) > TOL)).sum())
+    flip_px = flip_pixels(out[1].cpu().numpy(), iv["final_T"].cpu().numpy(), st)
     gb = o.backward(st, *grads)
     n_list = int((iv["ranges"][:, 1] - iv["ranges"][:, 0]).sum())
-    print(f"\n   trained scene: R {out[0]}, kept {n_list}, hot Gaussians {n_hot}; " + _check_grads(hb, gb, max(flips, 1), "trained") + f"; flips {flips}")
+    print(f"\n   trained scene: R {out[0]}, kept {n_list}, hot Gaussians {n_hot}; " + _check_grads(hb, gb, st, flip_px, "trained"))

@@ -122,6 +122,7 @@ def test_replacement_losses_match_the_reference_fixture_on_the_gpu():
     a = torch.tensor(g["a"], device=dev).requires_grad_(True); b = torch.tensor(g["b"], device=dev)
     n0 = dict(patching.calls)
     v_l1, v_ss = l1(a, b), ss(a, b)
+    assert v_l1.grad_fn is not None and v_l1.grad_fn is v_ss.grad_fn          # ONE autograd node (one launch each way) behind the two calls
     assert patching.calls["l1_loss"] == n0["l1_loss"] + 1 and patching.calls["ssim"] == n0["ssim"] + 1      # the HIP path ran
     assert abs(float(v_l1) - float(g["l1"])) <= 1e-6 * abs(float(g["l1"])) + 1e-8
     assert abs(float(v_ss) - float(g["ssim"])) <= 2e-6

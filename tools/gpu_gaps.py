@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Idle gaps of the GPU between consecutive kernels, from a rocprofv3 --kernel-trace database: which kernel the GPU waited for,
-how long, per training step (a step = one k_render_backward launch).   python tools/gpu_gaps.py results.db"""
+how long, per training step (a step = one k_render_backward launch).   python tools/gpu_gaps.py results.db [budget.json]
+budget.json (optional): {"_source_hash", "wall_us_per_step", "kernels_us": {kernel: us per launch}} -- bench.py reads it (profiles/
+graph_step_budget.json) for the roofline of the REPLAYED step while the hash is the library's."""
 import collections, sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
@@ -31,3 +33,12 @@ for n, (t, k) in sorted(per.items(), key=lambda kv: -kv[1][0])[:24]:
 
 for n, g in big.items():
     print(f"  gaps > 3 us before {n}: {len(g)} (mean {sum(g) / len(g):.1f} us, max {max(g):.1f} us)")
+
+if len(sys.argv) > 2:
+    import json, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from egogaussian_amd import lib as _lib
+    json.dump({"_source_hash": _lib.kernel_source_hash(), "steps": steps, "wall_us_per_step": round(wall / steps / 1e3, 2),
+               "idle_us_per_step": round((wall - busy) / steps / 1e3, 2),
+               "kernels_us": {n: round(t / k / 1e3, 3) for n, (t, k) in per.items()},
+               "launches_per_step": {n: round(k / steps, 3) for n, (t, k) in per.items()}}, open(sys.argv[2], "w"), indent=1)
