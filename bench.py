@@ -765,7 +765,7 @@ def main():
     replay_kernel = {"render_backward": "k_render_backward", "render_forward": "k_render_forward"}.get(dominant)
     replay_us = None
     if budget and replay_kernel and head["use_graph"] and key == "500000@960x540":
-        replay_us = next((v for k_, v in budget["kernels_us"].items() if k_.startswith(replay_kernel)), None)
+        replay_us = next((v for k_, v in budget["kernels_us"].items() if replay_kernel in k_), None)     # (the trace may hold mangled names)
     if replay_us:
         d = dict(d); d["ms_per_launch_eager_events"] = d["ms_per_launch"]; d["ms_per_launch"] = round(replay_us * 1e-3, 5)
         d["alg_GBps"] = round(d["alg_MB"] * 1e6 / (replay_us * 1e-6) / 1e9, 1)

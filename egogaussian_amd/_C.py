@@ -220,8 +220,9 @@ COLORS_ONLY_BACKWARD = True        # measurement switch (bench.py label_phase_sh
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, activation_flags=0, sh_rest=None, active_count=None, guard=None, object_rotation=None):
+                        prefiltered, debug, activation_flags=0, sh_rest=None, active_count=None, guard=None, object_rotation=None, color_only=False):
     """-> (num_rendered, color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer)
+    color_only (extension, ABI 4): depth and alpha are not produced (None) -- the blend skips their sums and planes.
     active_count (extension): int32[1] device tensor, the number of live rows of a capacity-sized model (include/egs_raster.h);
     guard (extension): a StepGuard whose words a captured forward writes.
     object_rotation (extension): (M, selected, row-0 gradient multiplier) -- the `fine_all` call shape's rotated covariance built
@@ -250,8 +251,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         key = dev.index if dev.index is not None else torch.cuda.current_device()
         cap = _capacity_hint.get(key, 0)
         gb, ib, bb, total_off = _buffer_sizes(L, P, W, H, cap)
-        planes = torch.empty((5, H, W), device=dev, dtype=torch.float32)       # colour, depth, alpha: one allocation, three contiguous views
-        out_color, out_depth, out_alpha = planes[0:3], planes[3:4], planes[4:5]
+        planes = torch.empty((3 if color_only else 5, H, W), device=dev, dtype=torch.float32)       # colour, depth, alpha: one allocation, three contiguous views
+        out_color, out_depth, out_alpha = planes[0:3], (None if color_only else planes[3:4]), (None if color_only else planes[4:5])
         radii = torch.empty((P,), device=dev, dtype=torch.int32)
         state = torch.empty((gb + ib + bb,), device=dev, dtype=torch.uint8)    # the three opaque buffers (their sizes are multiples of 256 bytes)
         geom, img, binning = state[:gb], state[gb:gb + ib], state[gb + ib:]

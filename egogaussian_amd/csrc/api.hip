@@ -280,7 +280,7 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     int rc = check_dims(P, width, height); if (rc) return rc;
     if (!num_rendered || capacity < 0 || capacity >= (1ll << 31)) return EGS_ERR_ARG;
     *num_rendered = 0;
-    if (!background || !image_buffer || !out_color || !out_depth || !out_alpha) return EGS_ERR_ARG;
+    if (!background || !image_buffer || !out_color || ((out_depth != nullptr) != (out_alpha != nullptr))) return EGS_ERR_ARG;     // (depth and alpha: both or neither, ABI 4)
     if (misaligned(geom_buffer, binning_buffer, image_buffer)) return EGS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) return egs_forward_render(0, 0, background, width, height, geom_buffer, binning_buffer, image_buffer, out_color,
@@ -385,7 +385,7 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
                        void* stream, int debug) {
     int rc = check_dims(P, width, height); if (rc) return rc;
     if (R < 0 || R >= (1ll << 31)) return EGS_ERR_RANGE;
-    if (!background || !image_buffer || !out_color || !out_depth || !out_alpha) return EGS_ERR_ARG;
+    if (!background || !image_buffer || !out_color || ((out_depth != nullptr) != (out_alpha != nullptr))) return EGS_ERR_ARG;     // (depth and alpha: both or neither, ABI 4)
     if (P > 0 && !geom_buffer) return EGS_ERR_ARG;
     if (R > 0 && !binning_buffer) return EGS_ERR_ARG;
     if (misaligned(geom_buffer, binning_buffer, image_buffer)) return EGS_ERR_ARG;

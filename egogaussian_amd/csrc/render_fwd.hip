@@ -41,6 +41,9 @@ namespace {
 #define EGS_FWD_LRPT3 128
 #endif
 
+// DA = false (ABI 4: out_depth == out_alpha == NULL): the caller reads the colour image only -- the training step's loss -- so the depth and
+// alpha sums (two of the ~26 vector instructions per visit) and their two planes are left out.
+template <bool DA>
 __global__ __launch_bounds__(256) void k_render_forward(
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
             const bool cont = test >= 0.0001f;                    /* false: this splat stops the pixel (or already stopped) */       \
             const float w = cont ? a * Tl : 0.f;                                                                                    \
             C0 = fmaf(S1.z, w, C0); C1 = fmaf(S1.w, w, C1); C2 = fmaf(S2.x, w, C2);                                                  \
-            Dacc = fmaf(S2.y, w, Dacc); Aacc += w;                                                                                  \
+            if (DA) { Dacc = fmaf(S2.y, w, Dacc); Aacc += w; }                                                                      \
             Tf = cont ? test : Tf;                                                                                                  \
             Tl = cont ? test : 0.f;                                                                                                 \
             const bool used = w > 0.f;                                                                                              \
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void k_render_forward(
         final_T[pix] = T; n_contrib[pix] = last;
         out_color[pix] = fmaf(T, bg[0], C0); out_color[HW + pix] = fmaf(T, bg[1], C1);
         out_color[2 * HW + pix] = fmaf(T, bg[2], C2);
-        out_depth[pix] = Dacc; out_alpha[pix] = Aacc;
+        if (DA) { out_depth[pix] = Dacc; out_alpha[pix] = Aacc; }
         EGS_FWD_TIMELINE()
     }
 }
@@ -215,8 +218,10 @@ hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs 
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_render_forward, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles,
-                       im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, im.quad_work, im.quad_pairs,
-                       placed ? im.fwd_order : (const uint32_t*)nullptr, im.fwd_cost);
+#define EGS_FWD_LAUNCH(DA) hipLaunchKernelGGL(k_render_forward<DA>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles, \
+                       im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, im.quad_work, im.quad_pairs, \
+                       placed ? im.fwd_order : (const uint32_t*)nullptr, im.fwd_cost)
+    if (out_depth && out_alpha) EGS_FWD_LAUNCH(true); else EGS_FWD_LAUNCH(false);
+#undef EGS_FWD_LAUNCH
     return hipGetLastError();
 }

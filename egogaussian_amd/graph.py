@@ -140,7 +140,7 @@ class GraphedTrainStep:
         if self.dynamic:
             kw.update(rot_cov=True, accum_R=f["accum_R"], which_object=self.which_object, during_training=False)
         out = render(f["cam"], self.pc, self.pipe, self.bg, fused_densify_stats=self.densify_stats, guard=self.guard,
-                     optimizer=self.opt if self.fuse_optimizer else None, **kw)
+                     optimizer=self.opt if self.fuse_optimizer else None, color_only=True, **kw)      # (the loss reads the colour image only)
         # the loss value and the running sum are produced by the loss BACKWARD kernel (nothing reads them before): two launches less
         loss = l1_ssim_loss(out["render"], f["gt"], self.lam, grad_gate=f["gate"] if self.gated else None, running_sum=self.loss_sum,
                             defer_value=True, raster_prologue=True)

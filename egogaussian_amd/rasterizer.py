@@ -40,7 +40,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                 activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None, optimizer=None,
-                object_rotation=None):
+                object_rotation=None, color_only=False):
         rs = raster_settings
         if guard is not None and getattr(guard, "deferred", False) and any(ctx.needs_input_grad) and not getattr(optimizer, "capturable", False) \
                 and not getattr(guard, "_warned", False):
@@ -63,7 +63,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
-            rs.campos, rs.prefiltered, rs.debug, activation_flags, sh_rest, active_count, guard, object_rotation)
+            rs.campos, rs.prefiltered, rs.debug, activation_flags, sh_rest, active_count, guard, object_rotation, color_only)
         ctx.guard = guard
         ctx.egs_raster_node = True                  # fused.l1_ssim_loss(raster_prologue=True) recognises its input's grad_fn by this
         ctx.prologue_scratch = None
@@ -109,7 +109,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         return (g_means3D, g_means2D, none_if_absent(g_sh, sh), none_if_absent(g_colors, colors_precomp),
                 g_opac, none_if_absent(g_scales, scales),
                 none_if_absent(g_rots, rotations), none_if_absent(g_cov3D, cov3Ds_precomp), None, None,
-                grads[8] if split else None, None, None, None, None, None)
+                grads[8] if split else None, None, None, None, None, None, None)
 
 
 def backward_prologue_of(node):
@@ -142,12 +142,12 @@ def backward_prologue_of(node):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None, optimizer=None,
-                        object_rotation=None):
+                        object_rotation=None, color_only=False):
     """-> (color, radii, depth, alpha, visible); upstream's function returns the first four, `visible` (bool[P] = radii > 0) is an
     extension GaussianRasterizer keeps for render()."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, activation_flags, sh_rest, densify_stats, active_count, guard, optimizer,
-                                     object_rotation)
+                                     object_rotation, color_only)
 
 
 class GaussianRasterizer(nn.Module):
@@ -163,7 +163,7 @@ class GaussianRasterizer(nn.Module):
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, raw_parameters=False, densify_stats=None, active_count=None, guard=None, optimizer=None,
-                object_rotation=None):
+                object_rotation=None, color_only=False):
         """Same call as upstream's.  raw_parameters=True (an extension): `scales`, `rotations` and `opacities` are the model's RAW
         parameters (log-scales, unnormalised quaternions, opacity logits); the activations run inside the preprocess kernel and
         the gradients come back w.r.t. the raw tensors (include/egs_raster.h, EGS_ACT_*).
@@ -178,6 +178,8 @@ class GaussianRasterizer(nn.Module):
         # optimizer (an extension): a FusedAdam(capturable=True).  Every input of this call that IS one of its parameters takes its
         # Adam step inside the backward (its .grad stays None and optimizer.step() skips it) -- only valid when this call is the
         # sole consumer of those parameters in the backward pass (optim.FusedAdam.make_sink)
+        # color_only (an extension): depth and alpha come back as None and the blend leaves their sums and planes out (a training step
+        # whose loss reads the colour image only)
         # After the call `self.visible` holds radii > 0 as a bool view the preprocess kernel wrote (no compare launch); it aliases
         # state saved for the backward and, under hipGraph replay, follows every replay -- clone it to keep or edit it.
         shs_rest = None
@@ -200,5 +202,5 @@ class GaussianRasterizer(nn.Module):
             raise Exception("GaussianRasterizer: raw_parameters / object_rotation need `scales` and `rotations`, not `cov3D_precomp`")
         color, radii, depth, alpha, self.visible = rasterize_gaussians(
             means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, self.raster_settings,
-            _C.ACT_RAW_PARAMETERS if raw_parameters else 0, shs_rest, densify_stats, active_count, guard, optimizer, object_rotation)
+            _C.ACT_RAW_PARAMETERS if raw_parameters else 0, shs_rest, densify_stats, active_count, guard, optimizer, object_rotation, color_only)
         return color, radii, depth, alpha

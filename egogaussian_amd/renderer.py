@@ -37,7 +37,7 @@ def _screenspace_leaf(xyz):
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, rot_cov=False,
-           accum_R=None, which_object=None, during_training=False, fused_densify_stats=False, guard=None, optimizer=None):
+           accum_R=None, which_object=None, during_training=False, fused_densify_stats=False, guard=None, optimizer=None, color_only=False):
     """Extensions (defaults = the reference's behaviour):
     fused_densify_stats  the backward of this render also updates pc.xyz_gradient_accum, pc.denom and pc.max_radii2D in place
                          (the trainer then skips add_densification_stats / the max_radii2D update for this iteration);
@@ -45,6 +45,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     optimizer            a FusedAdam(capturable=True): the model parameters this render hands to the rasterizer as they are stored
                          (xyz, and with the raw-parameter hooks scaling / rotation / opacity / features_dc) take their Adam step
                          inside the rasterizer's backward -- valid when this render is their only use in the iteration's loss;
+    color_only           "depth" and "alpha" of the result are None and the blend does not compute them (GraphedTrainStep: the loss reads
+                         the colour image only);
     a model with an `active_count` attribute (int32[1] device tensor; capacity.CapacityGaussians) renders only its live rows.
     `visibility_filter` is radii > 0 as written by the preprocess kernel: a fresh tensor in eager calls; while a hipGraph is being
     captured it is a VIEW of the rasterizer's saved state that follows every replay (no launch) -- clone it to keep or edit it."""
@@ -106,7 +108,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
                                             **({"active_count": pc.active_count} if getattr(pc, "active_count", None) is not None else {}),
                                             **({"guard": guard} if guard is not None else {}),
                                             **({"optimizer": optimizer} if optimizer is not None else {}),
-                                            **({"object_rotation": object_rotation} if object_rotation is not None else {}))
+                                            **({"object_rotation": object_rotation} if object_rotation is not None else {}),
+                                            **({"color_only": True} if color_only else {}))
     visible = rasterizer.visible                           # radii > 0 from the preprocess kernel of THIS call (returned, not shared state)
     if visible is None:
         visible = radii > 0

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 4
+#define EGS_ABI_VERSION 4          /* 4: grad_mask on the backwards, egs_l1_ssim_pair_*, out_depth / out_alpha may both be NULL on every forward (colour only) */
 #define EGS_TILE 16                 /* tile edge in pixels; part of the parity contract */
 #define EGS_MAX_SH_DEGREE 3
 

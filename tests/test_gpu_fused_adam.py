@@ -294,7 +294,7 @@ def test_c_abi_rejects_inconsistent_sinks():
                                    None if use_cov else vp(rots), vp(cov) if use_cov else None, 0, vp(cam), vp(cam), vp(pos), W, H, 1.0, 1.0,
                                    vp(radii), vp(geom), None, vp(img), vp(gcol), None, None, vp(z(P, 3)), vp(z(P, 3)), vp(z(P, 1)), vp(z(P, 3)),
                                    vp(z(P, 6)) if use_cov else None, vp(z(P, 1, 3)), None, None if use_cov else vp(z(P, 3)),
-                                   None if use_cov else vp(z(P, 4)), None, None, None, None, C.byref(sink), 0, None, vp(scratch), None, 0)
+                                   None if use_cov else vp(z(P, 4)), None, None, None, None, C.byref(sink), 0, None, 0, vp(scratch), None, 0)
 
     def sink_for(leaf, param, moments=True):
         s = lib.AdamSink()

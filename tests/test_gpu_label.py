@@ -128,6 +128,34 @@ def test_colors_only_backward_properties_at_bench_size(what):
     final_T = _C.image_views(img, W, H)["final_T"]
     lhs = (g["colors_precomp"].double() * dc1.double()).sum().item()
     rhs = (g1.to(dev).double() * (color.double() - final_T.double()[None] * g["bg"].double()[:, None, None])).sum().item()
-    print(f"\n[{what}] R={R}  sum c.dL/dc = {lhs:.6f}, sum dL/dC.(C - T bg) = {rhs:.6f}; hot Gaussians {int((_C.geom_views(geom, d['means3D'].shape[0])['clamped'] >> 3 != 0).sum())}")
+    print(f"\n[{what}] R={R}  sum c.dL/dc = {lhs:.6f}, sum dL/dC.(C - T bg) = {rhs:.6f}; hot Gaussians {int(((_C.geom_views(geom, d['means3D'].shape[0])['clamped'] >> 3 != 0) & (radii > 0)).sum())}")
     assert abs(lhs - rhs) <= 2e-5 * abs(rhs)
     assert float(dc1[radii <= 0].abs().max()) == 0.0
+
+
+def test_color_only_forward_changes_no_colour_bit():
+    """render(..., color_only=True) (ABI 4: out_depth == out_alpha == NULL; what GraphedTrainStep renders with): the colour image, radii,
+    transmittance and contributor counts are those of the full forward bit for bit, depth and alpha are not produced, and the gradients
+    of a colour-only loss are the same sums."""
+    from egogaussian_amd import _C
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.scene_synth import make_scene, make_camera, SynthGaussians, Pipe
+    dev = _dev()
+    N, H, W = 60000, 270, 480
+    scene = make_scene(N, H, W, 4); scene["log_scale"] += np.log(1.5).astype(np.float32)
+    cam, bg = make_camera(11, H, W, device=dev), torch.tensor([0.2, 0.1, 0.3], device=dev)
+    up = seeded_grads(H, W, 8)[0].to(dev)
+    res = {}
+    for co in (False, True):
+        pc = SynthGaussians(scene, device=dev)
+        out = render(cam, pc, Pipe, bg, color_only=co)
+        iv = _C.image_views(_C.stats["image_buffer"], W, H)
+        (out["render"] * up).sum().backward()
+        torch.cuda.synchronize()
+        res[co] = (out, iv["final_T"].clone(), iv["n_contrib"].clone(), [p.grad.clone() for p in (pc._xyz, pc._features_dc, pc._opacity, pc._scaling, pc._rotation)])
+    full, only = res[False], res[True]
+    assert only[0]["depth"] is None and only[0]["alpha"] is None and full[0]["depth"] is not None
+    assert torch.equal(full[0]["render"], only[0]["render"]) and torch.equal(full[0]["radii"], only[0]["radii"])
+    assert torch.equal(full[1], only[1]) and torch.equal(full[2], only[2])
+    for a, b in zip(full[3], only[3]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
