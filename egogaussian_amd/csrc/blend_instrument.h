@@ -10,6 +10,7 @@
 //                3  forward with exp2 replaced by a polynomial stub     4  forward without the LDS prefetch of the next record
 //                5  backward without the cross-lane reduction and the atomic (the pair arithmetic alone)
 //                6  backward with the atomic replaced by a plain store
+//                8  backward publishing nothing       9  backward publishing every second visit (request-count ablations, round 5)
 //                7  backward without the accumulation of splats whose box covers >= EGS_ABL7_AREA pixels (hot accumulator lines)
 //   EGS_NO_LRPT     no issue-priority steps (s_setprio) in either kernel
 #pragma once
@@ -96,6 +97,10 @@
 #endif
 #if EGS_ABL == 6                       // the reduction kept, the atomic replaced by a plain store to the same word
 #define EGS_BWD_ACCUM(PTR, VAL) (*(PTR) = (VAL))
+#elif EGS_ABL == 8                     // the reduction kept, NOTHING published (a request-free floor; sums wrong on purpose)
+#define EGS_BWD_ACCUM(PTR, VAL) do { if ((VAL) == 12345.678f) *(PTR) = (VAL); } while (0)
+#elif EGS_ABL == 9                     // every second visit publishes (half the accumulator requests, all of the arithmetic)
+#define EGS_BWD_ACCUM(PTR, VAL) do { if ((j & 1) || (VAL) == 12345.678f) unsafeAtomicAdd((PTR), (VAL)); } while (0)
 #else
 #define EGS_BWD_ACCUM(PTR, VAL) unsafeAtomicAdd((PTR), (VAL))
 #endif
