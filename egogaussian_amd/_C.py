@@ -93,6 +93,12 @@ def set_tile_culling(on):
     return bool(_lib.load().egs_debug_set_tile_culling(int(bool(on))))
 
 
+def set_fused_count(on):
+    """The count pass of the tile bucketing inside the preprocess launch (include/egs_raster.h, egs_debug_set_fused_count): on by default
+    whenever a forward has a placement buffer; off = the separate k_bin_count launch.  Returns the previous setting."""
+    return bool(_lib.load().egs_debug_set_fused_count(int(bool(on))))
+
+
 def last_instance_count(device=None, P=None):
     """R (rectangle instances) of the most recent EAGER forward on `device`, summed from the page-locked per-workgroup counts
     that call copied out.  Captured forwards skip the copy; they are checked through set_running_max / stats["total_view"]."""
@@ -155,7 +161,12 @@ def placement_buffer(dev, W, H):
     t = _placement.get(key)
     if t is None:
         # (never dropped: a captured hipGraph keeps the address; 40 KB per resolution and stream at 960x540)
-        t = _placement[key] = torch.zeros((_lib.load().egs_placement_bytes(int(W), int(H)),), device=dev, dtype=torch.uint8)
+        L = _lib.load()
+        t = _placement[key] = torch.zeros((L.egs_placement_bytes(int(W), int(H)),), device=dev, dtype=torch.uint8)
+        # (ABI 5) registers the address: its sums region is zero, the first forward need not clear it again (under hipGraph capture that
+        # clearing launch would be captured into every replay)
+        if not torch.cuda.is_current_stream_capturing():
+            _lib.check(L.egs_placement_init(t.data_ptr(), int(W), int(H), _hip.stream_of(dev)))
     return t
 
 

@@ -6,6 +6,9 @@
 #include "backward_prologue.h"
 #include <string.h>
 #include <vector>
+#include <mutex>
+#include <unordered_set>
+#include <stdlib.h>
 
 namespace {
 
@@ -67,6 +70,7 @@ EgsBinPtrs bin_ptrs(void* buf, int P, int64_t R, int W, int H) {
     p.point_list = (uint32_t*)(b + L.o.point_list); p.table = (uint32_t*)(b + L.o.table); p.chunk_sum = (uint32_t*)(b + L.o.spine);
     p.total = (uint64_t*)(b + L.o.total);
     p.flag = (uint32_t*)p.total - 32;                                 // (the 32 words before `total`)
+    p.zero_after = nullptr; p.zero_after_n = 0;
     return p;
 }
 EgsImgPtrs img_ptrs(void* buf, int W, int H) {
@@ -162,6 +166,12 @@ int egs_abi_version(void) { return EGS_ABI_VERSION; }
 const char* egs_source_hash(void) { return EGS_SOURCE_HASH; }
 
 int egs_debug_set_tile_culling(int on) { const int old = egs_tile_culling; egs_tile_culling = on ? 1 : 0; return old; }
+static int g_fused_count = -1;       // -1: not decided yet (EGS_NO_FUSED_COUNT=1 in the environment turns it off)
+static bool fused_count_on() {
+    if (g_fused_count < 0) { const char* e = getenv("EGS_NO_FUSED_COUNT"); g_fused_count = (e && e[0] && e[0] != '0') ? 0 : 1; }
+    return g_fused_count != 0;
+}
+int egs_debug_set_fused_count(int on) { const int old = fused_count_on() ? 1 : 0; g_fused_count = on ? 1 : 0; return old; }
 int egs_debug_force_ballot_rank(int on) { const int old = egs_force_ballot_rank; egs_force_ballot_rank = on ? 1 : 0; return old; }
 
 const char* egs_error_string(int code) {
@@ -197,10 +207,35 @@ int egs_get_binning_layout(int P, int64_t R, int width, int height, egs_binning_
     if (!out || P < 0 || R < 0 || width <= 0 || height <= 0) return EGS_ERR_ARG;
     *out = bin_layout(P, R, width, height).o; return 0;
 }
+// placement buffer: [4 n_tiles] quadrant costs, [egs_blocks_for_tiles] the forward's tile order, then (256-byte aligned, ABI 5) the chunk sums
+// of a fused count pass: EGS_BIN_GROUPS x n_tiles words (a table row never spans more than one scan chunk: n_chunks <= n_tiles)
+static size_t placement_sums_offset(size_t nt) { return egs_align((nt * 4 + (size_t)egs_blocks_for_tiles((int)nt)) * sizeof(uint32_t)); }
+static size_t placement_sums_words(size_t nt) { return (size_t)EGS_BIN_GROUPS * nt; }
 size_t egs_placement_bytes(int width, int height) {
     if (width <= 0 || height <= 0) return 0;
     const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
-    return egs_align((nt * 4 + (size_t)egs_blocks_for_tiles((int)nt)) * sizeof(uint32_t));
+    return egs_align(placement_sums_offset(nt) + placement_sums_words(nt) * sizeof(uint32_t));
+}
+// Which placement buffers hold ZERO chunk sums (egs_placement_init, or a complete fused chain of this library): the first fused forward
+// that meets an unknown address clears the sums with a launch of its own.
+static std::mutex g_placement_mu;
+static std::unordered_set<const void*> g_placement_clean;
+int egs_placement_init(void* placement, int width, int height, void* stream) {
+    if (!placement || check_dims(0, width, height)) return EGS_ERR_ARG;
+    const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
+    EGS_TRY(egs_launch_zero_u32((uint32_t*)((char*)placement + placement_sums_offset(nt)), placement_sums_words(nt), (hipStream_t)stream));
+    std::lock_guard<std::mutex> lk(g_placement_mu);
+    g_placement_clean.insert(placement);
+    return 0;
+}
+// -> the sums region if the fused count pass may use it now (cleared first when the address is new)
+static int placement_sums(void* placement, int width, int height, hipStream_t s, uint32_t** sums, uint32_t* words) {
+    const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
+    bool known;
+    { std::lock_guard<std::mutex> lk(g_placement_mu); known = g_placement_clean.count(placement) != 0; }
+    if (!known) { const int rc = egs_placement_init(placement, width, height, (void*)s); if (rc) return rc; }
+    *sums = (uint32_t*)((char*)placement + placement_sums_offset(nt)); *words = (uint32_t)placement_sums_words(nt);
+    return 0;
 }
 int egs_order_words(int width, int height) {
     if (width <= 0 || height <= 0) return 0;
@@ -311,6 +346,15 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     // ... and carries the placement of the forward blend's tiles (backward_prologue.h), computed from the costs the image buffer holds
     EgsImgPtrs im_spec = img_ptrs(image_buffer, width, height);
     placement_ptrs(placement, width, height, im_spec);
+    // With a persistent placement buffer the count pass of the bucketing rides in the preprocess launch (k_preprocess_count) and adds its
+    // chunk sums into that buffer's sums region, which is zero between frames (egs_common.h EgsBinPtrs); egs_debug_set_fused_count: A/B switch
+    const bool fuse = capacity > 0 && placement && fused_count_on() && egs_can_fuse_count(P, width, height);
+    if (fuse) {
+        rc = placement_sums(placement, width, height, s, &b_spec.chunk_sum, &b_spec.zero_after_n); if (rc) return rc;
+        b_spec.zero_after = b_spec.chunk_sum;
+        EGS_TRY(egs_launch_preprocess_count(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
+                                            rotations, activation_flags, cov3D_precomp, cam, radii, g, b_spec, active_count, &im_spec, orot, s));
+    } else
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
                                   rotations, activation_flags, cov3D_precomp, cam, radii, g, capacity > 0 ? b_spec.chunk_sum : nullptr, n_sums,
                                   active_count, (capacity > 0 && placement) ? &im_spec : nullptr, orot, s));
@@ -322,7 +366,7 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     if (capacity > 0) {                                              // speculative: sized by the caller's guess
         EgsBinPtrs b = b_spec;
         EgsImgPtrs im = im_spec;
-        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, overflow_flag, 1, s, 0));
+        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, overflow_flag, 1, fuse ? 1 : 0, s, 0));
         egs_prof_start(EGS_K_RENDER_FWD, s);
         EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, placement ? 1 : 0, s));
         egs_prof_stop(EGS_K_RENDER_FWD, s);
@@ -393,7 +437,7 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
     EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
     EgsBinPtrs b = bin_ptrs(binning_buffer, P, R, width, height);
     EgsImgPtrs im = img_ptrs(image_buffer, width, height);
-    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, nullptr, nullptr, 0, s, debug));
+    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, nullptr, nullptr, 0, 0, s, debug));
     const uint32_t* point_list = b.point_list;
     egs_prof_start(EGS_K_RENDER_FWD, s);
     EGS_TRY(egs_launch_render_forward(width, height, background, g, point_list, im, out_color, out_depth, out_alpha, 0, s));

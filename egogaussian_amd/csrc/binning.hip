@@ -26,6 +26,7 @@
 // group's lowest lane.
 #include "egs_common.h"
 #include "blend_common.h"
+#include "bin_walk.h"
 #include <atomic>
 
 int egs_tile_culling = 1;           // egs_debug_set_tile_culling: 0 keeps every instance of the reference's rectangles
@@ -33,26 +34,9 @@ int egs_force_ballot_rank = 0;      // test hook (egs_debug_force_ballot_rank): 
 
 namespace {
 
-__device__ __forceinline__ unsigned lane_id() {
-    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}
-__device__ __forceinline__ uint64_t lanemask_lt() {
-    const unsigned lane = lane_id();
-    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
-}
-
 // ---------------------------------------------------------------------------------------------
 // u32 scan: block-level reduce -> spine scan (recursive) -> block-level scan with carry-in.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t n = __shfl_up(v, d, 64);
-        if ((int)lane_id() >= d) v += n;
-    }
-    return v;
-}
-
 // Exclusive scan of one value per thread across a 256-thread block; returns the block total via *total.
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds4, uint32_t* total) {
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -213,183 +197,6 @@ __global__ __launch_bounds__(EGS_SCAN_THREADS) void k_table_scan(uint32_t* __res
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == EGS_SCAN_THREADS - 1) *total = run;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Tile bucketing.  The Gaussians are cut into groups of 64 consecutive ones; group j belongs to workgroup j % nblocks, so a
-// run of heavy groups (the clones and splits densification appends at the end of the arrays are all on screen and close to
-// the camera that asked for them) is spread over all workgroups instead of landing in the last few.  A workgroup (16 waves)
-// takes `gpr` of its groups per round:
-//   set-up  wave w < gpr owns group w: loads the rectangles' tile counts, scans them into per-Gaussian span starts and parks
-//           those, the rectangles, the depth words and (when culling) the ellipse parameters in LDS;
-//   deal    the round's instance slots are cut into units of 64 consecutive slots of ONE group and unit u goes to wave
-//           u % 16, whichever wave set the group up -- the waves of a workgroup finish within one unit of each other however
-//           uneven the rectangles are.  Inside a unit slot s is mapped back to its Gaussian by a 6-step shuffle search over
-//           the group's span starts.
-// `body(tile, gaussian_index, depth_bits)` runs once per instance.  The order in which a workgroup's instances reach a
-// tile's bucket is not defined (its waves share the LDS cursors); the per-tile sort orders by (depth, index), which is unique.
-// ---------------------------------------------------------------------------------------------
-// Workgroup b runs on XCD b % 8 (observed, used for speed only).  The bucketed array interleaves, inside every tile's
-// region, the slices of consecutive table columns; giving each XCD a contiguous run of columns lets its private L2
-// merge the 8-byte stores of neighbouring slices into full lines before they leave for HBM.
-__device__ __forceinline__ unsigned bin_logical_block(unsigned nblocks) {
-    const unsigned per = (nblocks + 7) / 8;
-    const unsigned l = (blockIdx.x % 8) * per + blockIdx.x / 8;
-    return l;                                                       // >= nblocks for the padding blocks of the grid
-}
-
-//
-// Tile culling (`cull`): the rectangle is the reference's 3-sigma bounding square, so many of its tiles hold no pixel the
-// splat can reach with alpha >= 1/255 (corners of elongated splats, faint splats).  Such an instance can never
-// contribute -- the reference skips it at every pixel -- so dropping it here changes no output bit; it only shortens the
-// sort and the lists the blend kernels scan (config C: 2.94M -> 1.87M instances).  The test is the exact, conservative
-// ellipse-vs-block test the blend kernels apply per 8x8 quadrant (blend_common.h), on the whole 16x16 tile; each slot-lane
-// reads its Gaussian's prepared ellipse parameters from the LDS block the set-up wave wrote.
-#ifdef EGS_BIN_TIMING
-// measurement builds (tools/bin_phases.py): every wave of every workgroup of k_bin_count stamps s_memtime at its phase boundaries
-__device__ unsigned long long egs_bin_stamps[512 * 16 * 6];
-__device__ unsigned long long egs_bin_unit_stamps[8 * 6];
-#define BIN_USTAMP(ph) do { __builtin_amdgcn_sched_barrier(0); if (!need_depth && threadIdx.x == 0 && bid == 7 && ucount < 8) egs_bin_unit_stamps[ucount * 6 + (ph)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define BIN_STAMP(ph) do { __builtin_amdgcn_sched_barrier(0); if (!need_depth && (threadIdx.x & 63) == 0 && bid < 512) egs_bin_stamps[(bid * 16 + (threadIdx.x >> 6)) * 6 + (ph)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define BIN_STAMP(ph)
-#define BIN_USTAMP(ph)
-#endif
-#define EGS_BIN_WAVES (EGS_BIN_THREADS / 64)
-// LDS behind the per-tile counters, for a round of `gpr` groups (words): span starts, rectangles, depth words, 16 unit counts +
-// 16 group totals, then (culling only, 16-byte aligned) two float4 per Gaussian.
-// + per group the owner map of the slot walk (see for_each_instance): 64 packed (span start << 6 | lane) words of the Gaussians that have
-// tiles, a 4096-bit map of the slots at which a span starts and 64 prefix counts of it.
-#define BIN_MAP_SLOTS 4096
-__host__ __device__ inline size_t bin_round_words(int gpr, bool cull, bool map) {
-    return (size_t)gpr * 64 * 4 + 32 + (cull ? (size_t)gpr * 64 * 8 : 0) + (map ? (size_t)gpr * 256 : 0);
-}
-
-template <typename Body>
-__device__ __forceinline__ void for_each_instance(unsigned bid, unsigned nblocks, int gpr, int P, const uint32_t* __restrict__ tiles_touched,
-                                                  const uint2* __restrict__ rect, const float4* __restrict__ rec, int gx,
-                                                  bool need_depth, bool cull, bool use_map, int W, int H, uint32_t* __restrict__ round_lds, Body body) {
-    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t* span = round_lds;                                        // [gpr * 64] exclusive slot offset inside the group
-    uint2* rcs = reinterpret_cast<uint2*>(span + gpr * 64);            // [gpr * 64]
-    uint32_t* dbs = span + gpr * 64 * 3;                               // [gpr * 64]
-    uint32_t* units = dbs + gpr * 64;                                  // [16] 64-slot units per group, [16] slots per group
-    float4* stage = reinterpret_cast<float4*>(units + 32);             // [gpr * 64][2]
-    // Owner map (which Gaussian of the group does slot s belong to?).  A 6-step binary search over the span starts by ds_bpermute was
-    // 1 000 of the 2 400 cycles a wave spends per 64-slot unit (tools/bin_phases.py); instead the set-up wave leaves, per group,
-    //   packed[r]   (span start << 6 | lane) of the r-th Gaussian that has tiles,
-    //   bm          one bit per slot < BIN_MAP_SLOTS at which a span starts,      bmpre[u] = span starts before slot 64 u,
-    // and a slot's owner is packed[bmpre[u] + popcount(bm[u] & bits up to the slot) - 1]: two LDS round trips, the first at a uniform
-    // address.  Units beyond the map (a group covering more than 4 096 tiles) keep the search, and so does everything when the per-tile
-    // counters of a large image leave no room for the map (`use_map`).
-    uint32_t* packed = reinterpret_cast<uint32_t*>(stage + (cull ? (size_t)gpr * 64 * 2 : 0));   // [gpr * 64]
-    uint32_t* bm = packed + gpr * 64;                                  // [gpr][128]
-    uint32_t* bmpre = bm + gpr * 128;                                  // [gpr][64]
-    const unsigned groups = ((unsigned)P + 63u) / 64u;
-    const unsigned per_block = (groups + nblocks - 1) / nblocks;       // groups of the busiest workgroup
-    for (unsigned g0 = 0; g0 < per_block; g0 += (unsigned)gpr) {
-        if (g0) __syncthreads();                                       // the previous round's readers are done
-        if ((int)w < gpr) {
-            const unsigned j = bid + nblocks * (g0 + w);
-            const int i = (int)(j * 64u + lane);
-            const bool have = g0 + w < per_block && j < groups && i < P;
-            // Everything a Gaussian contributes is requested at once -- the rectangle and the record words do not wait for the tile
-            // count to come back (a culled Gaussian's words are loaded for nothing; the set-up phase was two dependent round trips
-            // of ~2 us each in a workgroup that does nothing else meanwhile, tools/bin_phases.py).
-            const int il = have ? i : 0;
-            uint32_t cnt = have ? tiles_touched[i] : 0u;
-            uint2 rc_l = rect[il];
-            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-            if (cull) { r0 = rec[(size_t)il * EGS_SPLAT_REC_F4]; r1 = rec[(size_t)il * EGS_SPLAT_REC_F4 + 1]; r2 = rec[(size_t)il * EGS_SPLAT_REC_F4 + 2]; }
-            else if (need_depth) r2.y = rec[(size_t)il * EGS_SPLAT_REC_F4 + 2].y;
-            if (cull && cnt) {
-                // Only the tiles of the record's alpha >= 1/255 box (egs_common.h) can pass the ellipse test: walk the box's tile
-                // rectangle cut to the reference's instead of the reference's 3-sigma rectangle.  On a trained scene most splats are
-                // faint -- the box is a fraction of the rectangle, or empty (opacity < 1/255: nothing to walk): 4.06 M rectangle slots
-                // -> 1.24 M there.  `tiles_touched` and R stay the reference's; with culling off the full rectangle is walked.
-                const uint32_t bx = __float_as_uint(r2.z), by = __float_as_uint(r2.w);
-                const uint32_t px0 = bx & EGS_BOX_MASK, px1 = (bx >> 16) & EGS_BOX_MASK, py0 = by & EGS_BOX_MASK, py1 = by >> 16;
-                const uint32_t x0 = max(rc_l.x & 0xffffu, px0 / EGS_TILE), x1 = min(rc_l.x >> 16, px1 / EGS_TILE + 1u);
-                const uint32_t y0 = max(rc_l.y & 0xffffu, py0 / EGS_TILE), y1 = min(rc_l.y >> 16, py1 / EGS_TILE + 1u);
-                const bool some = px0 <= px1 && py0 <= py1 && x0 < x1 && y0 < y1;
-                cnt = some ? (x1 - x0) * (y1 - y0) : 0u;
-                rc_l = make_uint2(x0 | (x1 << 16), y0 | (y1 << 16));
-            }
-            const uint32_t incl = wave_incl_scan(cnt);
-            span[w * 64 + lane] = have ? incl - cnt : 0xffffffffu;   // invalid lanes sort to the end
-            if (cnt) {
-                rcs[w * 64 + lane] = rc_l;
-                if (need_depth) dbs[w * 64 + lane] = __float_as_uint(r2.y);
-                if (cull) { stage[2 * (w * 64 + lane)] = r0; stage[2 * (w * 64 + lane) + 1] = egs_ellipse_prep(r0.z, r0.w, r1.x, r1.y); }
-            }
-            if (lane == 63) { units[w] = (incl + 63u) >> 6; units[16 + w] = incl; }
-            if (use_map) {   // owner map of this group (one wave: its LDS operations execute in order)
-                const uint32_t excl_l = incl - cnt;
-                const uint64_t nzm = __ballot(cnt != 0);
-                if (cnt) packed[w * 64 + __popcll(nzm & lanemask_lt())] = (excl_l << 6) | lane;       // (a group has < 2^24 slots)
-                bm[w * 128 + lane] = 0u; bm[w * 128 + 64 + lane] = 0u;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                if (cnt && excl_l < BIN_MAP_SLOTS) atomicOr(&bm[w * 128 + (excl_l >> 5)], 1u << (excl_l & 31u));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                const uint32_t pc = (uint32_t)__popc(*(volatile uint32_t*)&bm[w * 128 + 2 * lane]) + (uint32_t)__popc(*(volatile uint32_t*)&bm[w * 128 + 2 * lane + 1]);
-                bmpre[w * 64 + lane] = wave_incl_scan(pc) - pc;
-            }
-        }
-        BIN_STAMP(1);
-        __syncthreads();
-        BIN_STAMP(2);
-        const uint32_t un = (int)lane < gpr ? units[lane] : 0u, tot = (int)lane < gpr ? units[16 + lane] : 0u;
-        const uint32_t uincl = wave_incl_scan(un);
-        const uint32_t n_units = __shfl(uincl, 63, 64);
-        int ucount = -1; (void)ucount;
-        for (uint32_t u = w; u < n_units; u += EGS_BIN_WAVES) {
-            ucount++;
-            BIN_USTAMP(0);
-            const int k = __popcll(__ballot(uincl <= u && (int)lane < gpr));       // the group unit u falls in (uniform)
-            const uint32_t s = ((u - (__shfl(uincl, k, 64) - __shfl(un, k, 64))) << 6) + lane;
-            const uint32_t total = __shfl(tot, k, 64);
-            const uint32_t uu = s >> 6;                                // unit inside the group (uniform)
-            int lo; uint32_t ost;
-            if (use_map && uu < BIN_MAP_SLOTS / 64) {
-                const uint64_t B = *reinterpret_cast<const uint64_t*>(&bm[k * 128 + 2 * uu]);
-                const uint32_t R = bmpre[k * 64 + uu] + (uint32_t)__popcll(B & (lanemask_lt() | (1ull << lane))) - 1u;
-                const uint32_t pk = packed[k * 64 + (R & 63u)];        // (lanes past the group's last slot read a valid word and are masked below)
-                lo = (int)(pk & 63u); ost = pk >> 6;
-            } else {
-                const uint32_t excl = span[k * 64 + lane];
-                lo = 0;                                                  // last lane whose span starts at or before s
-#pragma unroll
-                for (int step = 32; step >= 1; step >>= 1) {
-                    const int probe = lo + step;
-                    const uint32_t st = __shfl(excl, probe & 63, 64);
-                    if (probe < 64 && st <= s) lo = probe;
-                }
-                ost = __shfl(excl, lo, 64);                            // (all lanes take part: outside the branch)
-            }
-            BIN_USTAMP(1);
-            if (s < total) {
-                const uint32_t kk = s - ost;
-                const uint2 orc = rcs[k * 64 + lo];
-                const uint32_t x0 = orc.x & 0xffffu, x1 = orc.x >> 16, y0 = orc.y & 0xffffu;
-                const uint32_t wd = x1 - x0;
-                uint32_t row = (uint32_t)((float)kk * __builtin_amdgcn_rcpf((float)wd));      // k < 2^24: off by at most one
-                uint32_t col = kk - row * wd;
-                if ((int)col < 0) { row--; col += wd; }
-                if (col >= wd) { row++; col -= wd; }
-                const uint32_t ty = y0 + row, tx = x0 + col;
-                bool keep = true;
-                BIN_USTAMP(2);
-                if (cull) {
-                    const float4 e0 = stage[2 * (k * 64 + lo)], e1 = stage[2 * (k * 64 + lo) + 1];   // (x, y, qa, qb), (qc, need, sy, sx)
-                    keep = egs_ellipse_hits_prepped(e0, e1, tx * EGS_TILE, min(tx * EGS_TILE + EGS_TILE - 1, (uint32_t)W - 1),
-                                                    ty * EGS_TILE, min(ty * EGS_TILE + EGS_TILE - 1, (uint32_t)H - 1));
-                }
-                BIN_USTAMP(3);
-                if (keep) body(ty * (uint32_t)gx + tx, (bid + nblocks * (g0 + (unsigned)k)) * 64u + (unsigned)lo, need_depth ? dbs[k * 64 + lo] : 0u);
-            }
-            BIN_USTAMP(4);
-        }
-    }
-}
-
 extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
 
 
@@ -409,16 +216,7 @@ __global__ __launch_bounds__(EGS_BIN_THREADS) void k_bin_count(int P, int gpr, c
     BIN_STAMP(3);
     __syncthreads();
     BIN_STAMP(4);
-    for (int t = threadIdx.x; t < n_tiles; t += EGS_BIN_THREADS) table[(size_t)t * stride + bid] = hist[t];    // tile-major
-    // This workgroup's share of every scan chunk of the table (2048 entries = 2048 / stride whole rows), added to one of
-    // EGS_BIN_GROUPS partial accumulators: the scan then needs no reduction pass of its own (one launch less; the atomics return nothing)
-    const int rpc = 2048 / (int)stride, n_chunks = (n_tiles + rpc - 1) / rpc;
-    uint32_t* sums = chunk_sum + (size_t)(blockIdx.x % EGS_BIN_GROUPS) * n_chunks;
-    for (int c = threadIdx.x; c < n_chunks; c += EGS_BIN_THREADS) {
-        uint32_t sum = 0;
-        for (int t = c * rpc; t < min((c + 1) * rpc, n_tiles); t++) sum += hist[t];
-        if (sum) atomicAdd(&sums[c], sum);
-    }
+    bin_flush_counts(hist, n_tiles, bid, stride, table, chunk_sum, blockIdx.x);
     BIN_STAMP(5);
 }
 
@@ -597,7 +395,7 @@ __global__ __launch_bounds__(64 * TS_WAVES) __attribute__((amdgpu_waves_per_eu(T
                                                     uint32_t R /* capacity */,
                                                     int index_passes, uint64_t* __restrict__ pairs,
                                                     uint64_t* __restrict__ scratch, uint32_t* __restrict__ point_list,
-                                                    uint2* __restrict__ ranges) {
+                                                    uint2* __restrict__ ranges, uint32_t* __restrict__ zero_after, uint32_t zero_after_n) {
     constexpr int TS_THREADS = 64 * TS_WAVES, TS_ITEMS = TS_CAP / TS_THREADS;
     static_assert(TS_CAP * 2 >= TS_WAVES * TS_DIGITS, "the oversize path keeps its counters in the exchange buffer");
     constexpr int TS_NB = TS_WAVES * 128;                              // depth buckets of the one-pass path (512 for the four-wave instantiation)
@@ -607,6 +405,10 @@ __global__ __launch_bounds__(64 * TS_WAVES) __attribute__((amdgpu_waves_per_eu(T
     __shared__ uint32_t lds8[2 * TS_WAVES];
     uint32_t (*cnt)[256] = reinterpret_cast<uint32_t (*)[256]>(bkt);
     const int tile = blockIdx.x;
+    // End of the bucketing chain: the chunk sums a fused count pass accumulated into the caller's placement buffer have been consumed
+    // by k_table_scan -- cleared here, they are ZERO again when the next frame's k_preprocess_count starts adding (egs_common.h).
+    if (N_MIN == 0 && zero_after)
+        for (uint32_t k = blockIdx.x * (uint32_t)TS_THREADS + threadIdx.x; k < zero_after_n; k += gridDim.x * (uint32_t)TS_THREADS) zero_after[k] = 0u;
     SORT_STAMP(0);
     const uint32_t beg = table_scanned[(size_t)tile * stride];
     const uint32_t end = tile + 1 < n_tiles ? table_scanned[(size_t)(tile + 1) * stride] : (uint32_t)*total;
@@ -897,29 +699,24 @@ hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int 
 
 // The count table has one column per bucketing workgroup and one row per tile; its scan and the strided column accesses grow
 // with (tiles x workgroups), which at 2M Gaussians @ 3840x2160 (32 400 tiles) made the bucketing 2.3 ms with 1024 Gaussians per
-// workgroup.  The workgroup count is therefore kept near 512 (two per CU) whatever P is: gpb = 64 x ceil(P / (64 x 512)) -- whole
-// 64-Gaussian groups; 1024 at 500k Gaussians, 256 at 100k (98 workgroups of 1024 Gaussians left most CUs idle while each walked
+// workgroup.  The workgroup count is therefore kept near 512 (two per CU) whatever P is: gpb = 256 x ceil(P / (256 x 512)) -- whole
+// 256-Gaussian blocks; 1024 at 500k Gaussians, 256 at 100k (98 workgroups of 1024 Gaussians left most CUs idle while each walked
 // four times the slots: BASELINE config 2's bucketing 28.9 us), 512 on the 253k-Gaussian trained scene.
 #ifndef EGS_BIN_TARGET_BLOCKS
 #define EGS_BIN_TARGET_BLOCKS 512
 #endif
-int egs_bin_gpb(int P) { const int k = (P + 64 * EGS_BIN_TARGET_BLOCKS - 1) / (64 * EGS_BIN_TARGET_BLOCKS); return 64 * (k > 1 ? k : 1); }
+int egs_bin_gpb(int P) { const int k = (P + 256 * EGS_BIN_TARGET_BLOCKS - 1) / (256 * EGS_BIN_TARGET_BLOCKS); return 256 * (k > 1 ? k : 1); }      // whole 256-Gaussian blocks (bin_walk.h)
 uint32_t egs_bin_blocks(int P) { const int g = egs_bin_gpb(P); return (uint32_t)((P + g - 1) / g); }
 
-hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
-                              uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, hipStream_t s, int debug) {
-    const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
-    const int n_tiles = gx * gy;
-    if (R64 == 0 || P == 0) {
-        if (overflow_flag) { hipError_t e = egs_launch_zero_u32(overflow_flag, 2, s); if (e != hipSuccess) return e; }
-        return egs_launch_zero_u32((uint32_t*)im.ranges, 2 * (size_t)n_tiles, s);
-    }
-    const uint32_t R = (uint32_t)R64;
-    const uint32_t nblocks = egs_bin_blocks(P);
+// Launch geometry of the bucketing kernels for a model of P Gaussians at W x H (also used by preprocess.hip's fused count pass).
+EgsBinGeometry egs_bin_geometry(int P, int W, int H) {
+    EgsBinGeometry q;
+    q.gx = (W + EGS_TILE - 1) / EGS_TILE; q.n_tiles = q.gx * ((H + EGS_TILE - 1) / EGS_TILE);
+    q.nblocks = egs_bin_blocks(P);
     int cull = egs_tile_culling;
     // per-tile counters, then (16-byte aligned) the round's set-up block; fewer groups per round, then no culling, when
     // the counters leave too little of the 160 KiB (beyond ~28k tiles)
-    const size_t counters = (size_t)((n_tiles + 3) & ~3) * sizeof(uint32_t), room = 160 * 1024 - counters;
+    const size_t counters = (size_t)((q.n_tiles + 3) & ~3) * sizeof(uint32_t), room = 160 * 1024 - counters;
     // the slot walk's owner map (16 KiB at 16 groups) is used where it costs neither groups per round nor the culling: up to ~21k tiles
     const bool use_map = bin_round_words(EGS_BIN_WAVES, cull != 0, true) * sizeof(uint32_t) <= room;
     auto fits = [&](int groups, bool with_cull) { return bin_round_words(groups, with_cull, use_map) * sizeof(uint32_t) <= room; };
@@ -936,22 +733,42 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
         if (gpr == EGS_BIN_WAVES && counters + bin_round_words(gpr, c, use_map) * sizeof(uint32_t) > 80 * 1024 &&
             counters + bin_round_words(gpr / 2, c, use_map) * sizeof(uint32_t) <= 80 * 1024) gpr /= 2;
     }
-    const size_t lds = counters + bin_round_words(gpr, cull != 0, use_map) * sizeof(uint32_t);
+    q.gpr = gpr; q.cull = cull; q.use_map = use_map ? 1 : 0;
+    q.lds = counters + bin_round_words(gpr, cull != 0, use_map) * sizeof(uint32_t);
+    q.stride = egs_table_stride(q.nblocks); q.n_chunks = (uint32_t)egs_table_chunks((size_t)q.n_tiles, q.stride);
+    return q;
+}
+
+// counted: the table and the chunk sums of this frame are in place already (preprocess.hip's k_preprocess_count walked the rectangles)
+hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
+                              uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, int counted, hipStream_t s, int debug) {
+    const EgsBinGeometry q = egs_bin_geometry(P, W, H);
+    const int gx = q.gx, n_tiles = q.n_tiles;
+    if (R64 == 0 || P == 0) {
+        if (overflow_flag) { hipError_t e = egs_launch_zero_u32(overflow_flag, 2, s); if (e != hipSuccess) return e; }
+        return egs_launch_zero_u32((uint32_t*)im.ranges, 2 * (size_t)n_tiles, s);
+    }
+    const uint32_t R = (uint32_t)R64;
+    const uint32_t nblocks = q.nblocks;
+    const int cull = q.cull, gpr = q.gpr; const bool use_map = q.use_map != 0;
+    const size_t lds = q.lds;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const uint32_t stride = egs_table_stride(nblocks), n_chunks = (uint32_t)egs_table_chunks((size_t)n_tiles, stride);
+    const uint32_t stride = q.stride, n_chunks = q.n_chunks;
     egs_prof_start(EGS_K_DUPLICATE, s);
-    if (!sums_zeroed) {
-        hipError_t e0 = egs_launch_zero_u32(b.chunk_sum, (size_t)EGS_BIN_GROUPS * n_chunks, s);
-        if (e0 != hipSuccess) return e0;
+    if (!counted) {
+        if (!sums_zeroed) {
+            hipError_t e0 = egs_launch_zero_u32(b.chunk_sum, (size_t)EGS_BIN_GROUPS * n_chunks, s);
+            if (e0 != hipSuccess) return e0;
+        }
+        hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, use_map ? 1 : 0, W, H,
+                           b.table, stride, b.chunk_sum);
+        EGS_DBG(s);
     }
-    hipLaunchKernelGGL(k_bin_count, dim3(((nblocks + 7) / 8) * 8), dim3(EGS_BIN_THREADS), lds, s, P, gpr, g.offsets, g.rect, g.rec, gx, n_tiles, nblocks, cull, use_map ? 1 : 0, W, H,
-                       b.table, stride, b.chunk_sum);
-    EGS_DBG(s);
     const int prefixed = n_chunks >= EGS_CHUNK_PREFIX_MIN;
     if (prefixed) hipLaunchKernelGGL(k_chunk_prefix, dim3(1), dim3(1024), 0, s, b.chunk_sum, n_chunks);
     hipLaunchKernelGGL(k_table_scan, dim3(n_chunks), dim3(EGS_SCAN_THREADS), 0, s, b.table, (size_t)n_tiles * stride, stride, nblocks, b.chunk_sum, n_chunks, b.total, prefixed);
@@ -986,16 +803,16 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
     const int solo = (uint64_t)R <= 2048ull * (uint64_t)n_tiles ? 1 : 0;
     if (fast) {
         hipLaunchKernelGGL((k_tile_sort<true, 4, TS_SMALL_CAP, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, solo, R,
-                           ip, b.pairs, b.scratch, b.point_list, im.ranges);
+                           ip, b.pairs, b.scratch, b.point_list, im.ranges, b.zero_after, b.zero_after_n);
         if (!solo)
             hipLaunchKernelGGL((k_tile_sort<true, 8, 4096, TS_SMALL_CAP + 1u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, 0, R,
-                               ip, b.pairs, b.scratch, b.point_list, im.ranges);
+                               ip, b.pairs, b.scratch, b.point_list, im.ranges, b.zero_after, b.zero_after_n);
     } else {
         hipLaunchKernelGGL((k_tile_sort<false, 4, TS_SMALL_CAP, 0u>), dim3(n_tiles), dim3(256), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, solo, R,
-                           ip, b.pairs, b.scratch, b.point_list, im.ranges);
+                           ip, b.pairs, b.scratch, b.point_list, im.ranges, b.zero_after, b.zero_after_n);
         if (!solo)
             hipLaunchKernelGGL((k_tile_sort<false, 8, 4096, TS_SMALL_CAP + 1u>), dim3(n_tiles), dim3(512), 0, s, n_tiles, stride, b.table, b.total, running_max, overflow_flag, 0, R,
-                               ip, b.pairs, b.scratch, b.point_list, im.ranges);
+                               ip, b.pairs, b.scratch, b.point_list, im.ranges, b.zero_after, b.zero_after_n);
     }
     egs_prof_stop(EGS_K_SORT, s);
     EGS_DBG(s);

@@ -69,6 +69,9 @@ struct EgsBinPtrs {
     uint32_t* chunk_sum;    // [EGS_BIN_GROUPS][chunks] sums of the table's 2048-entry scan chunks, accumulated by k_bin_count; ZERO before it
     uint32_t* flag;         // [32] scratch words
     uint64_t* total;        // [1] number of instances found by the scan (== R)
+    // Fused count pass (preprocess.hip k_preprocess_count): chunk_sum then points into the caller's PERSISTENT placement buffer, whose sums
+    // region is zero between frames -- the first per-tile sort launch of a frame clears these words again (NULL: nothing to clear)
+    uint32_t* zero_after; uint32_t zero_after_n;
 };
 #define EGS_BIN_GROUPS 8            // partial accumulators per scan chunk (a same-address atomic chain is bin_blocks / 8 long)
 static inline uint32_t egs_table_stride(uint32_t bin_blocks) { uint32_t s = 4; while (s < bin_blocks) s <<= 1; return s; }   // power of two <= 2048
@@ -92,6 +95,8 @@ static inline size_t egs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 #define EGS_MAX_TILES 36864                                    // one 4-byte LDS counter per tile must fit in 160 KiB
 uint32_t egs_bin_blocks(int P);
 int egs_bin_gpb(int P);                                          // Gaussians per bucketing workgroup for a model of P Gaussians
+struct EgsBinGeometry { uint32_t nblocks, stride, n_chunks; int gpr, cull, use_map, n_tiles, gx; size_t lds; };
+EgsBinGeometry egs_bin_geometry(int P, int W, int H);           // launch geometry of the bucketing kernels (binning.hip)
 #define EGS_SCAN_THREADS 256
 #define EGS_SCAN_ITEMS 8
 #define EGS_SCAN_EPB (EGS_SCAN_THREADS * EGS_SCAN_ITEMS)      // elements per block
@@ -177,8 +182,16 @@ hipError_t egs_launch_mark_visible(int P, const float* means3D, const float* vie
 hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int inclusive, uint32_t* scratch,
                                uint64_t* total, hipStream_t s);
 // sums_zeroed: b.chunk_sum was cleared by this frame's preprocess launch (else a zero-fill launch comes first)
+// counted: b.table and b.chunk_sum were filled by egs_launch_preprocess_count (the count pass is not launched)
 hipError_t egs_launch_binning(int P, int64_t R, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
-                              uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, hipStream_t s, int debug);
+                              uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, int counted, hipStream_t s, int debug);
+// k_preprocess + the count pass of the tile bucketing in ONE launch (preprocess.hip); b.chunk_sum must be ZERO (see EgsBinPtrs).
+// -> false when the launch geometry does not allow it (fewer than four groups per round: very large images)
+bool egs_can_fuse_count(int P, int W, int H);
+hipError_t egs_launch_preprocess_count(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
+                                       const float* opac, const float* scales, float mod, const float* rots, int act,
+                                       const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, EgsBinPtrs b,
+                                       const int32_t* active_count, const EgsImgPtrs* place, EgsObjRot rot, hipStream_t s);
 // placed: im.fwd_order holds this frame's placement (the preprocess launch carried the ordering job); else the static mapping
 hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                      EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha, int placed,

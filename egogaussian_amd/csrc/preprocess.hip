@@ -13,6 +13,8 @@
 // This translation unit is compiled with -ffp-contract=off and every expression follows the order of
 // oracle/raster_oracle.c, so radii, tile rectangles and depth bits are bit-identical to the oracle.
 #include "egs_common.h"
+#include <stdlib.h>
+#include "bin_walk.h"              // the count pass of the tile bucketing, carried by k_preprocess_count
 #include "backward_prologue.h"
 
 namespace {
@@ -136,6 +138,7 @@ __device__ __forceinline__ float sh_channel(int deg, const float* sh, int ch, fl
     return v + 0.5f;
 }
 
+struct PreOut { uint2 rect; float4 r0, r1, r2; };
 // Returns the number of tiles the Gaussian touches (0 = culled).
 __device__ __forceinline__ uint32_t preprocess_one(
     int i, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -144,7 +147,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
     const float* __restrict__ PM, const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint2* __restrict__ rect_out,
     uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped_out, uint8_t* __restrict__ visible, const EgsObjRot rot,
-    bool& hot) {
+    bool& hot, PreOut* out = nullptr /*the rectangle and the record as written (left alone when culled, i.e. on a zero return): k_preprocess_count walks them*/) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     radii[i] = 0; tiles_touched[i] = 0; visible[i] = 0;
 
@@ -232,9 +235,11 @@ __device__ __forceinline__ uint32_t preprocess_one(
     rect_out[i] = make_uint2((uint32_t)rx0 | ((uint32_t)rx1 << 16), (uint32_t)ry0 | ((uint32_t)ry1 << 16));
     clamped_out[i] = (uint8_t)cl;
     float4* r = rec + (size_t)i * EGS_SPLAT_REC_F4;
-    r[0] = make_float4(px, py, (-0.5f * EGS_LOG2E) * conA, -EGS_LOG2E * conB);
-    r[1] = make_float4((-0.5f * EGS_LOG2E) * conC, o, rgb[0], rgb[1]);
-    r[2] = make_float4(rgb[2], e.t[2], __uint_as_float(bbx), __uint_as_float(bby));
+    const float4 q0 = make_float4(px, py, (-0.5f * EGS_LOG2E) * conA, -EGS_LOG2E * conB);
+    const float4 q1 = make_float4((-0.5f * EGS_LOG2E) * conC, o, rgb[0], rgb[1]);
+    const float4 q2 = make_float4(rgb[2], e.t[2], __uint_as_float(bbx), __uint_as_float(bby));
+    r[0] = q0; r[1] = q1; r[2] = q2;
+    if (out) { out->rect = make_uint2((uint32_t)rx0 | ((uint32_t)rx1 << 16), (uint32_t)ry0 | ((uint32_t)ry1 << 16)); out->r0 = q0; out->r1 = q1; out->r2 = q2; }
     return (uint32_t)((rx1 - rx0) * (ry1 - ry0));
 }
 
@@ -285,6 +290,91 @@ __global__ __launch_bounds__(256) void k_preprocess(
             clamped_out[i] = (uint8_t)((clamped_out[i] & EGS_CLAMP_MASK) | ((rank + 1u) << 3));   // where the backward looks for it
         }
     }
+}
+
+// k_preprocess and the COUNT pass of the tile bucketing (binning.hip k_bin_count) in one launch.  The count pass's workgroup is a chain
+// of latencies -- launch, set-up loads (~4 us with every workgroup asking at once), walk, flush -- of which the first two only fetch
+// what k_preprocess had in registers a launch earlier (profiles/r5_bucketing_experiments.md); here wave w of a 16-wave workgroup
+// projects one 64-Gaussian group of the round and parks rectangle, box and conic in the walk's LDS block directly.  The walk, the
+// [tile][workgroup] table and the chunk sums are bin_walk.h's, so the lists stay what k_bin_scatter + k_tile_sort made of them before.
+// Blocks of 256 Gaussians are dealt to workgroups (bin_walk.h): the per-block instance and hot counts are those of k_preprocess
+// (block B = Gaussians 256 B .. 256 B + 255; waves 4 m .. 4 m + 3 of a round hold one block).  Needs gpr % 4 == 0 (egs_can_fuse_count).
+// PLACE: the first eight workgroups order the forward blend's tiles instead (as in k_preprocess), in the dynamic LDS block.
+struct EgsPreArgs {
+    int P, D, M; const float* means3D; const float* shs; const float* colors; const float* opac; const float* scales; float mod;
+    const float* rots; const float* cov3D_in; int act; const float* V; const float* PM; const float* campos; int W, H; float tanfovx, tanfovy;
+    int32_t* radii; float4* rec; uint2* rect_out; uint32_t* tiles_touched; uint8_t* clamped_out; uint8_t* visible;
+    uint32_t* block_sums; uint32_t* block_hot; const int32_t* active_count;
+};
+struct EgsCountArgs { int gpr, gx, n_tiles; uint32_t nblocks; int cull, use_map; uint32_t* table; uint32_t stride; uint32_t* chunk_sum; };
+extern __shared__ __attribute__((aligned(16))) uint32_t pc_dyn_lds[];
+// ONE_ROUND: every workgroup's groups fit one round (no loop: what the projection loads is dead before the walk starts -- inside a loop the
+// camera matrices and the argument pointers stayed live through it and the kernel needed 105 VGPRs; 64 keep the 16-wave workgroups two per CU).
+template <bool PLACE, bool ONE_ROUND>
+__global__ __launch_bounds__(EGS_BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_preprocess_count(EgsPreArgs a, EgsCountArgs c, EgsPrologueArgs place, EgsObjRot rot) {
+    __shared__ uint32_t wsum[EGS_BIN_WAVES], whot[EGS_BIN_WAVES];
+    if (PLACE) {
+        if (blockIdx.x < EGS_XCDS) { egs_order_band<EGS_BIN_THREADS>(place, (int)blockIdx.x, *reinterpret_cast<EgsOrderLds*>(pc_dyn_lds)); return; }
+    }
+    const unsigned bid = bin_logical_block(c.nblocks, PLACE ? EGS_XCDS : 0u);
+    if (bid >= c.nblocks) return;
+    uint32_t* hist = pc_dyn_lds;
+    const BinRound L = bin_round_carve(pc_dyn_lds + ((c.n_tiles + 3) & ~3), c.gpr, c.cull != 0);
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < c.n_tiles; t += EGS_BIN_THREADS) hist[t] = 0;            // (the first round's barrier orders this)
+    const int P = a.P;
+    const int live = a.active_count ? min(P, max(*a.active_count, 0)) : P;                  // capacity-sized models: rows beyond the live count are culled
+    const unsigned groups = ((unsigned)P + 63u) / 64u, per_block = bin_groups_per_block((unsigned)P, c.nblocks);
+    unsigned g0 = 0;
+    do {
+        if (!ONE_ROUND && g0) __syncthreads();                         // the previous round's readers (walk, block sums, hot ranks) are done
+        bool hot = false; uint64_t hot_wave = 0ull; int i = -1;
+        if ((int)w < c.gpr) {
+            const unsigned j = bin_group_of(bid, c.nblocks, g0 + w);
+            const bool have = g0 + w < per_block && j < groups;
+            i = have ? (int)(j * 64u + lane) : -1;
+            uint32_t my_tiles = 0; PreOut o;
+            if (i >= live && i < P) { a.radii[i] = 0; a.tiles_touched[i] = 0; a.visible[i] = 0; }
+            const float* V = a.V; const float* PM = a.PM; const float* campos = a.campos;
+            if (!ONE_ROUND) asm volatile("" : "+s"(V), "+s"(PM), "+s"(campos));     // (re-read every round instead of held in 35 scalar registers through the walk)
+            if (i >= 0 && i < live)
+                my_tiles = preprocess_one(i, a.D, a.M, a.means3D, a.shs, a.colors, a.opac, a.scales, a.mod, a.rots, a.cov3D_in, a.act, V, PM, campos,
+                                          a.W, a.H, a.tanfovx, a.tanfovy, a.radii, a.rec, a.rect_out, a.tiles_touched, a.clamped_out, a.visible, rot, hot, &o);
+            hot = hot && my_tiles != 0;
+            hot_wave = __ballot(hot);
+            if (my_tiles == 0) { o.rect = make_uint2(0u, 0u); o.r0 = o.r1 = o.r2 = make_float4(0.f, 0.f, 0.f, 0.f); }      // (culled: preprocess_one left `o` alone)
+            bin_park_group(L, w, lane, i >= 0 && i < P, my_tiles, o.rect, o.r0, o.r1, o.r2, false, c.cull != 0, c.use_map != 0);
+            uint32_t sum = my_tiles;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d, 64);
+            if (lane == 0) { wsum[w] = sum; whot[w] = (uint32_t)__popcll(hot_wave); }
+        }
+        __syncthreads();
+        if ((int)w < c.gpr && i >= 0) {
+            // the 256-Gaussian block of this wave: waves (w & ~3) .. (w & ~3) + 3 of the round (all present: gpr is a multiple of four)
+            const unsigned w0 = w & ~3u, blk = (unsigned)i >> 8;
+            if ((w & 3u) == 0 && lane == 0) {
+                a.block_sums[blk] = wsum[w0] + wsum[w0 + 1] + wsum[w0 + 2] + wsum[w0 + 3];
+                a.block_hot[blk] = min(whot[w0] + whot[w0 + 1] + whot[w0 + 2] + whot[w0 + 3], EGS_HOT_PER_BLOCK);
+            }
+            if (hot) {   // rank among the block's hot Gaussians -> the code that names this one's replica lines (egs_common.h); few per frame
+                uint32_t rank = (uint32_t)__popcll(hot_wave & (lane ? (~0ull >> (64 - lane)) : 0ull));
+                for (unsigned k = w0; k < w; k++) rank += whot[k];
+                if (rank < EGS_HOT_PER_BLOCK) {
+                    float4* r2 = a.rec + (size_t)i * EGS_SPLAT_REC_F4 + 2;
+                    uint32_t bbx = __float_as_uint(r2->z), bby = __float_as_uint(r2->w);
+                    egs_hot_code_set(bbx, bby, rank + 1u);
+                    r2->z = __uint_as_float(bbx); r2->w = __uint_as_float(bby);
+                    a.clamped_out[i] = (uint8_t)((a.clamped_out[i] & EGS_CLAMP_MASK) | ((rank + 1u) << 3));   // where the backward looks for it
+                }
+            }
+        }
+        bin_walk_round(L, bid, c.nblocks, g0, c.gpr, c.gx, false, c.cull != 0, c.use_map != 0, a.W, a.H,
+                       [&](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); });
+        g0 += (unsigned)c.gpr;
+    } while (!ONE_ROUND && g0 < per_block);
+    __syncthreads();
+    bin_flush_counts(hist, c.n_tiles, bid, c.stride, c.table, c.chunk_sum, blockIdx.x);
 }
 
 // stage offsets (floats) of the leaves a fused optimizer owns: rows of the workgroup's 256 Gaussians, leaf after leaf
@@ -1178,6 +1268,39 @@ hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, cons
         hipLaunchKernelGGL(k_preprocess<false>, dim3((P + 255) / 256), dim3(256), 0, s, PP_ARGS, pa, rot);
     }
 #undef PP_ARGS
+    return hipGetLastError();
+}
+
+bool egs_can_fuse_count(int P, int W, int H) {
+    if (P <= 0) return false;
+    const EgsBinGeometry q = egs_bin_geometry(P, W, H);
+    // one round only: the looped instantiation holds the projection's inputs through the walk and spills (1M @ 1080p, four rounds of eight
+    // groups: 116 + 151 us against 34 + 214 with the separate count pass) -- EGS_FUSE_MULTI_ROUND=1 lets it run all the same (measurements)
+    static const bool multi = getenv("EGS_FUSE_MULTI_ROUND") != nullptr;
+    if (!multi && bin_groups_per_block((unsigned)P, q.nblocks) > (unsigned)q.gpr) return false;
+    return q.gpr >= 4 && q.gpr % 4 == 0 && q.lds >= sizeof(EgsOrderLds);
+}
+hipError_t egs_launch_preprocess_count(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
+                                       const float* opac, const float* scales, float mod, const float* rots, int act,
+                                       const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, EgsBinPtrs b,
+                                       const int32_t* active_count, const EgsImgPtrs* place, EgsObjRot rot, hipStream_t s) {
+    const EgsBinGeometry q = egs_bin_geometry(P, cam.W, cam.H);
+    EgsPreArgs a = { P, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.tanfovx, cam.tanfovy,
+                     radii, g.rec, g.rect, g.offsets, g.clamped, g.visible, g.scan_scratch, g.block_hot, active_count };
+    EgsCountArgs c = { q.gpr, q.gx, q.n_tiles, q.nblocks, q.cull, q.use_map, b.table, q.stride, b.chunk_sum };
+    EgsPrologueArgs pa = {};
+    const unsigned grid = ((q.nblocks + 7) / 8) * 8;
+    const bool one = bin_groups_per_block((unsigned)P, q.nblocks) <= (unsigned)q.gpr;
+    if (place) { pa.n_tiles = q.n_tiles; pa.quad_work = place->fwd_cost; pa.tile_order = place->fwd_order; }
+#define PC_LAUNCH(PL, ONE) do {                                                                                                       \
+        if (q.lds > 64 * 1024) {                                                                                                      \
+            hipError_t e = hipFuncSetAttribute((const void*)k_preprocess_count<PL, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds); \
+            if (e != hipSuccess) return e;                                                                                            \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((k_preprocess_count<PL, ONE>), dim3(grid + (PL ? EGS_XCDS : 0)), dim3(EGS_BIN_THREADS), q.lds, s, a, c, pa, rot); } while (0)
+    if (place) { if (one) PC_LAUNCH(true, true); else PC_LAUNCH(true, false); }
+    else { if (one) PC_LAUNCH(false, true); else PC_LAUNCH(false, false); }
+#undef PC_LAUNCH
     return hipGetLastError();
 }
 

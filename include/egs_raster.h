@@ -53,7 +53,9 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 4          /* 4: grad_mask on the backwards, egs_l1_ssim_pair_*, out_depth / out_alpha may both be NULL on every forward (colour only) */
+#define EGS_ABI_VERSION 5          /* 5: the placement buffer grew a sums region (egs_placement_bytes) that must be ZERO when the buffer is first handed over:
+                                         egs_placement_init;  4: grad_mask on the backwards, egs_l1_ssim_pair_*, out_depth / out_alpha may both be NULL on every
+                                         forward (colour only) */
 #define EGS_TILE 16                 /* tile edge in pixels; part of the parity contract */
 #define EGS_MAX_SH_DEGREE 3
 
@@ -205,9 +207,15 @@ int egs_forward(
  * calls: every forward leaves there what its blend spent on each 8x8 quadrant, and the next forward given the same buffer deals its
  * tiles to CUs and its quadrants to SIMDs by those numbers (an ordering job carried by the preprocess launch).  It pays when
  * consecutive calls render similar frames -- a video or an orbit in order, the static buffers of a replayed hipGraph -- and is neutral
- * otherwise.  ANY contents are valid (zeros, another resolution's data): they decide when a quadrant is blended, never what is
- * computed.  One buffer per concurrently running forward (it is read and written by the call).  NULL: the static tile mapping. */
+ * otherwise.  One buffer per concurrently running forward (it is read and written by the call).  NULL: the static tile mapping.
+ * ABI 5: given a placement buffer, the forward also folds the count pass of its tile bucketing into the preprocess launch (one launch and
+ * one round of set-up loads less per frame); that pass accumulates per-chunk instance sums in the tail of the buffer, which the chain
+ * itself clears again before it ends.  Those words must therefore be ZERO when a buffer is handed over for the first time -- a zero-filled
+ * allocation, or egs_placement_init() -- and the memory must not be used for anything else between calls.  (The first forward that meets
+ * an address it has not seen clears the words with a launch of its own; the tile-order words in front of them may hold anything -- they
+ * decide when a quadrant is blended, never what is computed.)  Results are identical with and without a placement buffer. */
 size_t egs_placement_bytes(int width, int height);
+int egs_placement_init(void* placement, int width, int height, void* stream);
 
 /* ---- the same chain with NO host wait, for hipGraph capture of a whole training step: everything is only enqueued
  *      (capacity must be > 0).  A frame that needs more than `capacity` instances is invalid (its kernels were clipped to
@@ -497,6 +505,10 @@ int egs_debug_force_ballot_rank(int on);
  * reference's count.  on == 0 keeps every instance, which makes the internal lists comparable bit for bit with the
  * reference algorithm's (used by the parity tests).  Returns the previous setting; applies to subsequent forwards. */
 int egs_debug_set_tile_culling(int on);
+/* 1 (default): a forward given a placement buffer folds the count pass of its bucketing into the preprocess launch (see the placement
+ * buffer above); 0: the two launches of ABI <= 4.  Lists, images and gradients are the same either way (tests/test_gpu_parity.py).
+ * -> the previous setting.  EGS_NO_FUSED_COUNT=1 in the environment starts a process with it off. */
+int egs_debug_set_fused_count(int on);
 
 /* ---- optional per-stage timing with HIP events on the caller's stream (bench / profiling aid) ------
  * The only process-wide state in the library; off by default.  egs_profile_begin allocates an event pool and

@@ -72,6 +72,17 @@ def tile_culling(on):
         _C.set_tile_culling(old)
 
 
+@contextlib.contextmanager
+def fused_count(on):
+    """Run a block with the count pass of the bucketing inside the preprocess launch (on, the default with a placement buffer) or as its own launch."""
+    from egogaussian_amd import _C
+    old = _C.set_fused_count(on)
+    try:
+        yield
+    finally:
+        _C.set_fused_count(old)
+
+
 def check_culled_lists(st, ranges_hip, point_list_hip, H, W):
     """With tile culling on, every tile's list must be the oracle's list with some entries removed (same order), and every
     removed (tile, splat) instance must be one the reference skips at all 256 pixels: alpha < 1/255 or power > 0

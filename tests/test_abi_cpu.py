@@ -42,10 +42,10 @@ def test_sizes_and_layouts():
     assert b.key_bits == 32 + 11 and b.index_passes == 3 and b.bin_blocks == 489     # 60 x 34 = 2040 tiles -> 11 bits; 19 index bits
     assert b.point_list == 0 < b.pairs < b.scratch < b.table < b.spine       # the backward only needs point_list (offset 0)
     assert L.egs_get_binning_layout(1000000, 5000, 1920, 1080, C.byref(b)) == 0 and b.key_bits == 45 and b.index_passes == 3
-    assert L.egs_get_binning_layout(200, 5000, 64, 64, C.byref(b)) == 0 and b.key_bits == 37 and b.index_passes == 1 and b.bin_blocks == 4     # workgroups of whole 64-Gaussian groups, sized by P (binning.hip egs_bin_gpb)
+    assert L.egs_get_binning_layout(200, 5000, 64, 64, C.byref(b)) == 0 and b.key_bits == 37 and b.index_passes == 1 and b.bin_blocks == 1     # workgroups of whole 256-Gaussian blocks, sized by P (binning.hip egs_bin_gpb)
     i = lib.ImageLayout(); assert L.egs_get_image_layout(100, 70, C.byref(i)) == 0 and i.ranges < i.final_T < i.n_contrib
     assert i.n_contrib < i.quad_work < i.tile_order < i.quad_pairs and i.quad_pairs + 7 * 5 * 8 * 4 <= L.egs_image_bytes(100, 70)
-    assert L.egs_abi_version() == 4 and L.egs_knn3_grid_scratch_bytes(0) == 0 and L.egs_knn3_grid_scratch_bytes(100000) > 100000 * 20
+    assert L.egs_abi_version() == 5 and L.egs_knn3_grid_scratch_bytes(0) == 0 and L.egs_knn3_grid_scratch_bytes(100000) > 100000 * 20
     assert L.egs_knn3_grid(5, None, None, None, None) == -1 and L.egs_knn3_grid(0, None, None, None, None) == 0
 
 

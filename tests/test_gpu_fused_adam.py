@@ -361,8 +361,10 @@ def test_loss_backward_carrying_the_raster_prologue(H, W):
 
 @pytest.mark.parametrize("H,W", [(96, 160), (1080, 1920), (2160, 3840)])
 def test_forward_placement_buffer_never_changes_results(H, W):
-    """The persistent placement buffer (include/egs_raster.h): whatever it holds -- zeros, the previous frame's costs, random words --
-    every tile is blended exactly once and the outputs are bit-identical; after a forward it holds that forward's per-quadrant costs."""
+    """The persistent placement buffer (include/egs_raster.h): whatever its cost and tile-order words hold -- zeros, the previous frame's
+    costs, random words -- every tile is blended exactly once and the outputs are bit-identical; after a forward it holds that forward's
+    per-quadrant costs.  ABI 5: the sums region behind them (the fused count pass's chunk sums) is zero between frames -- the chain that
+    used it clears it -- and is the one part a caller must not scribble on."""
     from egogaussian_amd import _C
     from egogaussian_amd.scene_synth import SynthGaussians, Pipe
     from egogaussian_amd.renderer import render
@@ -371,7 +373,10 @@ def test_forward_placement_buffer_never_changes_results(H, W):
     pc = SynthGaussians(student, device=DEV, requires_grad=False)
     nt = ((W + 15) // 16) * ((H + 15) // 16)
     place = _C.placement_buffer(torch.device(DEV), W, H)
-    words = place.view(torch.int32)
+    n_free = ((nt * 4 + lib.load().egs_order_words(W, H)) * 4 + 255) // 256 * 256 // 4      # words in front of the sums region
+    words = place.view(torch.int32)[:n_free]
+    sums = place.view(torch.int32)[n_free:]
+    assert sums.numel() >= 8 * nt
     outs = []
     gen = torch.Generator().manual_seed(5)
     for fill in ("zeros", "previous", "random", "huge"):
@@ -391,6 +396,7 @@ def test_forward_placement_buffer_never_changes_results(H, W):
         cost = words[:nt * 4].cpu().numpy()
         visits = _C.image_views(_C.stats["image_buffer"], W, H)["quad_visits"].cpu().numpy().reshape(-1)
         assert (cost >= 10 * visits).all() and cost.sum() > 0
+        assert not bool(sums.any()), "the chain left chunk sums behind"
     for o in outs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
     assert lib.load().egs_placement_bytes(W, H) == place.numel()

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import (make_inputs, seeded_grads, rel_err, outlier_fraction, tile_culling, check_culled_lists, flip_pixels,
+from tests.common import (make_inputs, seeded_grads, rel_err, outlier_fraction, tile_culling, fused_count, check_culled_lists, flip_pixels,
                           check_grads_isolating_flips)
 
 pytestmark = pytest.mark.gpu
@@ -195,6 +195,66 @@ def test_tile_culling_changes_no_output_bit(N, H, W, seed, mode, smul):
     key_a = np.repeat(np.arange(len(a["rng"]), dtype=np.int64), a["rng"][:, 1] - a["rng"][:, 0]) * (1 << 32) + a["pl"]
     key_b = tile_of.astype(np.int64) * (1 << 32) + b["pl"]
     assert np.array_equal(key_a[np.isin(key_a, key_b)], key_b)      # an ordered sub-list of the full list
+
+
+@pytest.mark.parametrize("N,H,W,seed,mode,smul", [(20000, 270, 480, 5, "sh_cov", 2.0), (3001, 67, 131, 2, "rgb_sr", 1.0), (70000, 540, 960, 9, "sh_sr", 1.0),
+                                                  (1200, 33, 47, 1, "sh_cov", 6.0)])
+@pytest.mark.parametrize("cull", [False, True], ids=["reference-lists", "culled-lists"])
+def test_fused_count_pass_changes_nothing(N, H, W, seed, mode, smul, cull):
+    """ABI 5: with a placement buffer the count pass of the tile bucketing runs inside the preprocess launch (k_preprocess_count).  Every
+    array the chain leaves -- radii, records, rectangles, per-block counts, the scanned table's tile starts, ranges, the sorted lists, the
+    images -- must equal, bit for bit, what the separate k_preprocess + k_bin_count launches produce; twice in a row (the second frame
+    finds the chunk sums the first one's chain cleared), and after a frame of ANOTHER size on the same stream in between."""
+    from egogaussian_amd import _C
+    dev = _dev()
+    d = make_inputs(N, H, W, seed, 0, mode, scale_mul=smul)
+    other = make_inputs(900, 48, 80, seed + 1, 0, "rgb_sr")
+    res = {}
+    with tile_culling(cull):
+        hip_forward(d, dev)                                          # establishes the capacity: the fused path needs capacity > 0
+        for fused in (False, True, True):
+            with fused_count(fused):
+                if fused:
+                    hip_forward(other, dev)
+                g, out = hip_forward(d, dev)
+            iv = _C.image_views(out[7], W, H); bv = _C.binning_views(out[6], N, out[0], W, H, _C.stats["capacity"]); gv = _C.geom_views(out[5], N)
+            rng = iv["ranges"].cpu().numpy().view(np.uint32).astype(np.int64)
+            n_list = int((rng[:, 1] - rng[:, 0]).sum())
+            cur = dict(R=out[0], planes=[t.clone() for t in out[1:5]] + [iv["final_T"].clone(), iv["n_contrib"].clone()], rng=rng,
+                       pl=bv["point_list"].cpu().numpy().view(np.uint32)[:n_list].copy(),
+                       geom=[gv["offsets"].clone(), gv["visible"].clone()] + [gv[k][gv["visible"]].clone() for k in ("rec", "rect", "clamped")])   # (rows of culled Gaussians are not written)
+            if not fused:
+                res = cur
+                continue
+            assert cur["R"] == res["R"] and np.array_equal(cur["rng"], res["rng"]) and np.array_equal(cur["pl"], res["pl"]), "fused count pass changed the lists"
+            for x, y in zip(cur["planes"] + cur["geom"], res["planes"] + res["geom"]):
+                assert torch.equal(x, y), "fused count pass changed an output"
+
+
+def test_placement_buffer_first_seen_dirty():
+    """A placement buffer the library has never seen may hold anything in its tile-order words, but its sums region must be zero: the
+    first forward that meets the address clears it (include/egs_raster.h).  Hand over a buffer full of 0xAB through the C ABI path the
+    Python layer uses and compare with the regular one."""
+    from egogaussian_amd import _C
+    dev = _dev()
+    N, H, W = 6000, 135, 240
+    d = make_inputs(N, H, W, 4, 0, "sh_cov")
+    hip_forward(d, dev)
+    g, ref = hip_forward(d, dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = [k for k in _C._placement if k[0] == idx and k[1] == W and k[2] == H]
+    assert key, "no placement buffer for this size"
+    saved = _C._placement[key[0]]
+    try:
+        _C._placement[key[0]] = torch.full_like(saved, 0xAB)          # a different address, never registered, dirty
+        g, out = hip_forward(d, dev)
+        g, out2 = hip_forward(d, dev)
+    finally:
+        _C._placement[key[0]] = saved
+    for o in (out, out2):
+        assert o[0] == ref[0]
+        for x, y in zip(o[1:5], ref[1:5]):
+            assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("H,W", [(2160, 3840), (2304, 4096)], ids=["32400-tiles", "36864-tiles"])
