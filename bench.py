@@ -52,17 +52,24 @@ PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 SQ_FILE = os.path.join(ROOT, "profiles", "sq_counters.json")
 
 
-def algorithmic_bytes(stage, N, R, npix, sh_coeffs=1):
+def algorithmic_bytes(stage, N, R, npix, sh_coeffs=1, fused_count=False):
     """Bytes one launch of `stage` must move at minimum: per-unit figures x units.  R = instances the
-    launch actually processes (after tile culling)."""
+    launch actually processes (after tile culling).  fused_count (ABI 5): the count walk of the bucketing runs inside the preprocess
+    launch on what that launch holds in registers -- the `preprocess` events then cover it, `tile_bucket` is the scan and the scatter walk."""
     return {
         "preprocess": (44 + 12 * sh_coeffs) * N + 48 * N,   # xyz 12 + log-scale 12 + quaternion 16 + opacity logit 4 + sh 12/coefficient in; record 48 out
-        "tile_bucket": 2 * (16 + 32) * N + 8 * R,      # two walks over (tiles_touched, rect, depth | ellipse) per Gaussian; one pair out per instance
+        "tile_bucket": (1 if fused_count else 2) * (16 + 32) * N + 8 * R,      # walk(s) over (tiles_touched, rect, depth | ellipse) per Gaussian; one pair out per instance
         "tile_sort": 8 * R + 4 * R,                    # pair in, index out; the radix passes stay in registers/LDS
         "render_forward": 4 * R + 48 * R + 28 * npix,  # id + record per instance; 7 floats per pixel out
         "render_backward": 4 * R + 48 * R + 40 * R + 32 * npix,   # + one 40-byte accumulate per instance; 8 floats/pixel in
         "preprocess_backward": 48 * N + (44 + 12 * sh_coeffs) * N + 32 * N + (68 + 12 * sh_coeffs) * N,  # accumulator + inputs + record head in; grads out (xyz, mean2D, scale, quat, sh, colour, opacity)
     }[stage]
+
+
+def _fuses_count(N, hw):
+    """Does a forward of this size run the fused preprocess + count launch (include/egs_raster.h egs_forward_fuses_count)?"""
+    from egogaussian_amd import lib as egs_lib
+    return bool(egs_lib.load().egs_forward_fuses_count(int(N), int(hw[1]), int(hw[0])))
 
 
 def spawn_command(gpus, argv, port=None):
@@ -97,14 +104,14 @@ def tile_list_stats(_C, img, W, H):
             "pairs_Q": int(iv["quad_pairs"].long().sum().item()), "visits": int(iv["quad_visits"].long().sum().item())}
 
 
-def stage_table(stages, N, R_kept, npix, sh_coeffs=1):
+def stage_table(stages, N, R_kept, npix, sh_coeffs=1, hw=None):
     """{stage: (total ms, launches)} -> {stage: ms per launch, algorithmic MB, GB/s, fraction of the HBM roofline}"""
     rows = {}
     for name, (ms, n) in stages.items():
         if n == 0:
             continue
         per = ms / n
-        ab = algorithmic_bytes(name, N, R_kept, npix, sh_coeffs)
+        ab = algorithmic_bytes(name, N, R_kept, npix, sh_coeffs, fused_count=bool(hw) and _fuses_count(N, hw))
         rows[name] = {"ms_per_launch": round(per, 4), "launches": n, "alg_MB": round(ab / 1e6, 2),
                       "alg_GBps": round(ab / (per * 1e-3) / 1e9, 1), "frac_hbm": round(ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     return rows
@@ -153,7 +160,7 @@ def config_leg(dev, N, H, W, forward_only, iters=30, log_scale_shift=0.0, scene=
         torch.cuda.synchronize()
         R = int(_C.stats["num_rendered"]); R_kept = int(_C.stats["total_view"].item())
         lists = tile_list_stats(_C, _C.stats["image_buffer"], W, H)
-    rows = stage_table(stages, N, R_kept, H * W)
+    rows = stage_table(stages, N, R_kept, H * W, hw=(H, W))
     op_ms = sum(r["ms_per_launch"] for r in rows.values())
     alg = sum(r["alg_MB"] for r in rows.values())
     leg = {"workload": f"S({N},{H},{W},seed0){what}: rasterizer " + ("forward only, no gradient" if forward_only else
@@ -738,7 +745,7 @@ def main():
         if n == 0:
             continue
         per = ms / n
-        ab = algorithmic_bytes(name, N, R_kept, npix, (D + 1) ** 2)
+        ab = algorithmic_bytes(name, N, R_kept, npix, (D + 1) ** 2, fused_count=_fuses_count(N, (H, W)))
         stage_rows[name] = {"ms_per_launch": round(per, 4), "launches": n, "alg_MB": round(ab / 1e6, 2),
                             "alg_GBps": round(ab / (per * 1e-3) / 1e9, 1), "frac_hbm": round(ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if dominant is None or per * n > stages[dominant][0]:

@@ -171,6 +171,7 @@ static bool fused_count_on() {
     if (g_fused_count < 0) { const char* e = getenv("EGS_NO_FUSED_COUNT"); g_fused_count = (e && e[0] && e[0] != '0') ? 0 : 1; }
     return g_fused_count != 0;
 }
+int egs_forward_fuses_count(int P, int width, int height) { return (fused_count_on() && egs_can_fuse_count(P, width, height)) ? 1 : 0; }
 int egs_debug_set_fused_count(int on) { const int old = fused_count_on() ? 1 : 0; g_fused_count = on ? 1 : 0; return old; }
 int egs_debug_force_ballot_rank(int on) { const int old = egs_force_ballot_rank; egs_force_ballot_rank = on ? 1 : 0; return old; }
 

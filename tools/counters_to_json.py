@@ -17,7 +17,7 @@ import pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egogaussian_amd.lib import kernel_source_hash          # noqa: E402
 
-STAGES = {"preprocess": ["k_preprocess<", "k_preprocess("], "tile_bucket": ["k_bin_count", "k_table_scan", "k_bin_scatter"], "tile_sort": ["k_tile_sort"],
+STAGES = {"preprocess": ["k_preprocess<", "k_preprocess(", "k_preprocess_count"], "tile_bucket": ["k_bin_count", "k_table_scan", "k_bin_scatter"], "tile_sort": ["k_tile_sort"],
           "render_forward": ["k_render_forward"], "render_backward": ["k_render_backward", "k_backward_prologue"],
           "preprocess_backward": ["k_preprocess_backward"], "loss": ["k_l1_ssim_"], "adam": ["k_adam"]}
 N_SIMD, XCDS, CLOCK = 1024, 8, 2.4e9

@@ -7,7 +7,7 @@ doubled; calibration on a kernel with a known byte count in the same run is reco
 import json, os, sys
 import pandas as pd
 
-STAGES = {"preprocess": ["k_preprocess("], "tile_bucket": ["k_bin_count", "k_scan_", "k_bin_scatter"], "tile_sort": ["k_tile_sort"],
+STAGES = {"preprocess": ["k_preprocess(", "k_preprocess_count"], "tile_bucket": ["k_bin_count", "k_scan_", "k_bin_scatter"], "tile_sort": ["k_tile_sort"],
           "render_forward": ["k_render_forward"], "render_backward": ["k_render_backward", "k_backward_prologue"],
           "preprocess_backward": ["k_preprocess_backward"], "cov3d": ["k_cov3d_"], "loss": ["k_l1_ssim_"], "adam": ["k_adam"]}
 
@@ -32,7 +32,7 @@ def main():
         lead = [n for n in fk.index if pats[0] in n]
         launches = int(fk.loc[lead, "count"].max()) if lead else int(fk["count"].max())
         if stage == "tile_bucket":
-            launches = int(fk.loc[[n for n in fk.index if "k_bin_count" in n], "count"].max())
+            launches = int(fk.loc[[n for n in fk.index if "k_bin_scatter" in n], "count"].max())
         fetch_b = float(fk["sum"].sum()) * 1024 * 2 / launches
         write_b = float(wk["sum"].sum()) * 1024 / launches
         res[stage] = {"hbm_bytes_per_launch": int(fetch_b + write_b), "fetch_bytes_x2": int(fetch_b), "write_bytes": int(write_b),

@@ -8,6 +8,8 @@
 //   5  lanes 16 r (r < 4) + ...: four lanes, one per 16-lane quarter
 //   6  pattern 0 with plain stores instead of atomics
 //   7  lanes 4 v (v < 10) but slots reversed (9 - v)
+//   8  TWO lines per instruction: lanes 4 v carry line A, lanes 4 v + 1 line B (20 lanes) -- per LINE half the instructions of pattern 0
+//   9  FOUR lines per instruction: lanes 4 v + k carry line k (40 lanes)
 // with K VALU-only filler iterations between two atomics (K = 0: back to back).  Output: ns per wave-instruction chip-wide.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -25,9 +27,12 @@ __global__ __launch_bounds__(256) void k(float* acc, uint32_t lines, int iters, 
     else if (PAT == 4) { if (lane < 32) { if ((lane & 7) == 0) slot = lane >> 3; else if ((lane & 7) == 4) slot = lane == 28 ? 8 : 4 + (lane >> 3); else if (lane == 25) slot = 7; } }
     else if (PAT == 5) { if ((lane & 15) == 0) slot = lane >> 4; }
     else if (PAT == 7) { if ((lane & 3) == 0 && lane < 40) slot = 9 - (lane >> 2); }
+    else if (PAT == 8) { if ((lane & 2) == 0 && lane < 40) slot = lane >> 2; }
+    else if (PAT == 9) { if (lane < 40) slot = lane >> 2; }
     float f = (float)lane * 0.001f;
     for (int it = 0; it < iters; it++) {
-        const uint32_t line = hash(wave * 4096u + it) % lines;
+        uint32_t line = hash(wave * 4096u + it) % lines;
+        if (PAT == 8 || PAT == 9) line = hash(wave * 4096u + it + 77777u * (lane & 3)) % lines;
         for (int q = 0; q < filler; q++) f = fmaf(f, 1.0001f, 0.5f);
         if (slot >= 0) {
             if (PAT == 6) acc[(size_t)line * 12 + slot] = f;
@@ -51,15 +56,16 @@ int main() {
     const uint32_t lines = 500000;
     float *acc, *sink; hipMalloc(&acc, (size_t)lines * 48 + 4096); hipMalloc(&sink, 4); hipMemset(acc, 0, (size_t)lines * 48);
     printf("ns per atomic wave-instruction chip-wide (8192 waves); requests per ns = 1 / that\n%8s", "filler");
-    for (int p = 0; p < 8; p++) printf(" %8s%d", "pat", p);
+    for (int p = 0; p < 10; p++) printf(" %8s%d", "pat", p);
     printf("\n");
-    for (int filler : {0, 64, 128, 192}) {
+    for (int filler : {0}) {
         printf("%8d", filler);
         const int iters = 120;
         printf(" %9.4f", run<0>(acc, lines, iters, filler, sink)); printf(" %9.4f", run<1>(acc, lines, iters, filler, sink));
         printf(" %9.4f", run<2>(acc, lines, iters, filler, sink)); printf(" %9.4f", run<3>(acc, lines, iters, filler, sink));
         printf(" %9.4f", run<4>(acc, lines, iters, filler, sink)); printf(" %9.4f", run<5>(acc, lines, iters, filler, sink));
         printf(" %9.4f", run<6>(acc, lines, iters, filler, sink)); printf(" %9.4f", run<7>(acc, lines, iters, filler, sink));
+        printf(" %9.4f", run<8>(acc, lines, iters, filler, sink)); printf(" %9.4f", run<9>(acc, lines, iters, filler, sink));
         printf("\n");
     }
     return 0;
