@@ -130,13 +130,19 @@ __device__ __forceinline__ void fwd_step(FwdCtx& c, v2f (&w01)[11], v2f (&w23)[1
             c.dm_dmu1[p] = A; c.dm_dexx[p] = B; c.dm_dexy[p] = D + E; c.sm += A;
             return;
         }
+        // 1 / (D E) as v_rcp_f32 + one Newton step (<= 1 ulp) and the second quotient as a product: the two IEEE division sequences were
+        // ~20 dependent instructions of a wave whose instruction stream IS the launch (16.8 -> 15.8 us at 3x540x960); -DEGS_LOSS_IEEE_DIV: A/B
+#ifdef EGS_LOSS_IEEE_DIV
         const float invDE = 1.f / (D * E);
+#else
+        const float de_ = D * E; float invDE = __builtin_amdgcn_rcpf(de_); invDE = fmaf(fmaf(-de_, invDE, 1.f), invDE, invDE);
+#endif
         const float sm = A * B * invDE;
         // partial derivatives of the map holding the other windowed moments fixed
         if (EGS_LOSS_ABL & 1) { c.sm += (2.f * mu2 * (B - A)) * invDE - sm * (2.f * mu1 * (E - D)) * invDE + -sm / E + 2.f * A * invDE; }
         else {
             c.dm_dmu1[p] = (2.f * mu2 * (B - A)) * invDE - sm * (2.f * mu1 * (E - D)) * invDE;
-#ifdef EGS_LOSS_ONE_DIV
+#ifndef EGS_LOSS_IEEE_DIV
             c.dm_dexx[p] = -sm * (D * invDE);
 #else
             c.dm_dexx[p] = -sm / E;
