@@ -42,8 +42,9 @@ def main():
     h = kernel_source_hash()
     traffic, sq = {}, {}
     for stage, pats in STAGES.items():
-        lead = [pats[0]]
-        _, launches = pick(t[1], lead, "FETCH_SIZE")
+        # launches of the stage = those of its most frequent kernel (a stage's first frame may run other kernels than the rest: the fused
+        # k_preprocess_count needs a capacity, so frame 0 is k_preprocess + k_bin_count)
+        launches = max(pick(t[1], [pt], "FETCH_SIZE")[1] for pt in pats)
         if not launches:
             continue
         fetch, _ = pick(t[1], pats, "FETCH_SIZE")
