@@ -47,6 +47,21 @@ def test_sizes_and_layouts():
     assert i.n_contrib < i.quad_work < i.tile_order < i.quad_pairs and i.quad_pairs + 7 * 5 * 8 * 4 <= L.egs_image_bytes(100, 70)
     assert L.egs_abi_version() == 5 and L.egs_knn3_grid_scratch_bytes(0) == 0 and L.egs_knn3_grid_scratch_bytes(100000) > 100000 * 20
     assert L.egs_knn3_grid(5, None, None, None, None) == -1 and L.egs_knn3_grid(0, None, None, None, None) == 0
+    # ABI 5: the placement buffer = 4 cost words per tile + the tile-order words + (256-byte aligned) eight sums words per tile;
+    # which forwards fold the count pass of the bucketing into the preprocess launch (one round of <= 16 groups per workgroup)
+    nt = 60 * 34
+    assert L.egs_placement_bytes(960, 540) == ((nt * 4 + L.egs_order_words(960, 540)) * 4 + 255) // 256 * 256 + 8 * nt * 4
+    assert L.egs_placement_bytes(0, 540) == 0 and L.egs_placement_init(None, 960, 540, None) == -1
+    fuses = L.egs_forward_fuses_count
+    assert fuses(500000, 960, 540) == 1 and fuses(100000, 960, 540) == 1 and fuses(253202, 960, 540) == 1 and fuses(1, 64, 64) == 1
+    assert fuses(1000000, 1920, 1080) == 0        # four rounds of eight groups per workgroup: the separate count launch
+    assert fuses(0, 960, 540) == 0
+    old = L.egs_debug_set_fused_count(0)
+    try:
+        assert fuses(500000, 960, 540) == 0
+    finally:
+        L.egs_debug_set_fused_count(old)
+    assert fuses(500000, 960, 540) == 1
 
 
 def test_argument_errors_precede_device_work():
