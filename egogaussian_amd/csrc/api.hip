@@ -7,7 +7,7 @@
 #include <string.h>
 #include <vector>
 #include <mutex>
-#include <unordered_set>
+#include <unordered_map>
 #include <stdlib.h>
 
 namespace {
@@ -220,20 +220,27 @@ size_t egs_placement_bytes(int width, int height) {
 // Which placement buffers hold ZERO chunk sums (egs_placement_init, or a complete fused chain of this library): the first fused forward
 // that meets an unknown address clears the sums with a launch of its own.
 static std::mutex g_placement_mu;
-static std::unordered_set<const void*> g_placement_clean;
+static std::unordered_map<const void*, uint64_t> g_placement_clean;       // address -> (width << 32 | height) it was cleared for: the sums region's offset depends on the tile count
 int egs_placement_init(void* placement, int width, int height, void* stream) {
     if (!placement || check_dims(0, width, height)) return EGS_ERR_ARG;
     const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
     EGS_TRY(egs_launch_zero_u32((uint32_t*)((char*)placement + placement_sums_offset(nt)), placement_sums_words(nt), (hipStream_t)stream));
     std::lock_guard<std::mutex> lk(g_placement_mu);
-    g_placement_clean.insert(placement);
+    g_placement_clean[placement] = ((uint64_t)(uint32_t)width << 32) | (uint32_t)height;
     return 0;
 }
+// A chain that fails between the fused count pass and the sort launch that clears the sums leaves them dirty: the address is forgotten, and
+// the next forward that is handed this buffer clears it first.
+struct PlacementDirtyOnError {
+    const void* p = nullptr;
+    ~PlacementDirtyOnError() { if (p) { std::lock_guard<std::mutex> lk(g_placement_mu); g_placement_clean.erase(p); } }
+};
 // -> the sums region if the fused count pass may use it now (cleared first when the address is new)
 static int placement_sums(void* placement, int width, int height, hipStream_t s, uint32_t** sums, uint32_t* words) {
     const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
     bool known;
-    { std::lock_guard<std::mutex> lk(g_placement_mu); known = g_placement_clean.count(placement) != 0; }
+    { std::lock_guard<std::mutex> lk(g_placement_mu); auto it = g_placement_clean.find(placement);
+      known = it != g_placement_clean.end() && it->second == (((uint64_t)(uint32_t)width << 32) | (uint32_t)height); }
     if (!known) { const int rc = egs_placement_init(placement, width, height, (void*)s); if (rc) return rc; }
     *sums = (uint32_t*)((char*)placement + placement_sums_offset(nt)); *words = (uint32_t)placement_sums_words(nt);
     return 0;
@@ -350,7 +357,9 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     // With a persistent placement buffer the count pass of the bucketing rides in the preprocess launch (k_preprocess_count) and adds its
     // chunk sums into that buffer's sums region, which is zero between frames (egs_common.h EgsBinPtrs); egs_debug_set_fused_count: A/B switch
     const bool fuse = capacity > 0 && placement && fused_count_on() && egs_can_fuse_count(P, width, height);
+    PlacementDirtyOnError dirty_guard;
     if (fuse) {
+        dirty_guard.p = placement;                                   // (disarmed once the bucketing chain is enqueued)
         rc = placement_sums(placement, width, height, s, &b_spec.chunk_sum, &b_spec.zero_after_n); if (rc) return rc;
         b_spec.zero_after = b_spec.chunk_sum;
         EGS_TRY(egs_launch_preprocess_count(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
@@ -368,6 +377,7 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
         EgsBinPtrs b = b_spec;
         EgsImgPtrs im = im_spec;
         EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, overflow_flag, 1, fuse ? 1 : 0, s, 0));
+        dirty_guard.p = nullptr;
         egs_prof_start(EGS_K_RENDER_FWD, s);
         EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, placement ? 1 : 0, s));
         egs_prof_stop(EGS_K_RENDER_FWD, s);

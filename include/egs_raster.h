@@ -212,7 +212,8 @@ int egs_forward(
  * one round of set-up loads less per frame); that pass accumulates per-chunk instance sums in the tail of the buffer, which the chain
  * itself clears again before it ends.  Those words must therefore be ZERO when a buffer is handed over for the first time -- a zero-filled
  * allocation, or egs_placement_init() -- and the memory must not be used for anything else between calls.  (The first forward that meets
- * an address it has not seen clears the words with a launch of its own; the tile-order words in front of them may hold anything -- they
+ * an address it has not seen -- or has seen with another image size: the region's offset follows the tile count -- clears the words with a
+ * launch of its own, and so does the first one after a forward that failed half way; the tile-order words in front of them may hold anything -- they
  * decide when a quadrant is blended, never what is computed.)  Results are identical with and without a placement buffer. */
 size_t egs_placement_bytes(int width, int height);
 int egs_placement_init(void* placement, int width, int height, void* stream);

@@ -257,6 +257,33 @@ def test_placement_buffer_first_seen_dirty():
             assert torch.equal(x, y)
 
 
+def test_one_placement_buffer_two_image_sizes():
+    """A C caller may hand ONE placement allocation to forwards of different sizes: the sums region sits behind a size-dependent number of
+    cost words, so the library clears it again whenever the size it last saw for that address differs (api.hip placement registry)."""
+    from egogaussian_amd import _C
+    dev = _dev()
+    sizes = [(6000, 135, 240, 4), (9000, 270, 480, 7)]
+    ins = [make_inputs(N, H, W, seed, 0, "sh_cov") for N, H, W, seed in sizes]
+    refs = []
+    for d in ins:
+        hip_forward(d, dev)
+        refs.append(hip_forward(d, dev)[1])
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    keys = [[k for k in _C._placement if k[0] == idx and k[1] == W and k[2] == H][0] for _, H, W, _ in sizes]
+    saved = [_C._placement[k] for k in keys]
+    shared = torch.full((max(t.numel() for t in saved),), 0x5C, device=dev, dtype=torch.uint8)
+    try:
+        for k in keys:
+            _C._placement[k] = shared
+        for rnd in range(3):
+            for d, ref in zip(ins, refs):
+                out = hip_forward(d, dev)[1]
+                assert out[0] == ref[0] and all(torch.equal(x, y) for x, y in zip(out[1:5], ref[1:5])), f"round {rnd}"
+    finally:
+        for k, t in zip(keys, saved):
+            _C._placement[k] = t
+
+
 @pytest.mark.parametrize("H,W", [(2160, 3840), (2304, 4096)], ids=["32400-tiles", "36864-tiles"])
 def test_4k_image_tile_counters_fill_the_lds(H, W):
     """3840x2160 = 32400 tiles: the per-tile counters of the bucketing kernels take 127 KiB of the 160 KiB LDS (one
