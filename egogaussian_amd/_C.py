@@ -360,7 +360,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alpha,
                                  debug, activation_flags=0, sh_rest=None, densify_stats=None, guard=None, sink=None,
-                                 prologue_scratch=None, object_rotation=None, grad_mask=0):
+                                 prologue_scratch=None, object_rotation=None, grad_mask=0, loss_grad=None):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
            dL_dscales[P,3], dL_drotations[P,4]); with sh_rest, dL_dsh is [P,1,3] and a ninth element dL_dsh_rest[P,M-1,3] follows.
     densify_stats (extension): (xyz_gradient_accum[P,1], denom[P,1], max_radii2D[P] or None), float32, updated in place by the kernel
@@ -370,6 +370,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     egs_backward_adam); their gradients are not produced: those positions of the result are None.
     prologue_scratch (extension): the scratch buffer a preceding egs_l1_ssim_backward_ex prepared for THIS backward (tile order,
     cleared accumulator, optimizer bookkeeping: fused.l1_ssim_loss(raster_prologue=True)); the backward then starts at its blend kernel.
+    loss_grad (extension, ABI 5): a lib.LossGrad -- dL_dout_color is then NOT read (it only gives the image size): the blend computes the
+    image loss's gradient itself from what the loss forward left (include/egs_raster.h egs_backward_lossgrad; fused.l1_ssim_loss(raster_lossgrad=True)).
     grad_mask (extension, ABI 4): GRAD_* bits of the inputs whose gradient the caller reads (autograd's needs_input_grad), 0 = all.
     GRAD_COLORS alone with `colors` given -- the reference's label call, /root/reference/gaussian_renderer/render_helper.py:38-54 --
     takes the colours-only backward: only dL_dcolors is produced, every other position of the result is None."""
@@ -425,7 +427,22 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             dscales = None if fused(_lib.SINK_SCALES) else e(0, 3)
             drots = None if fused(_lib.SINK_ROTATIONS) else e(0, 4)
         rot_st, _rot_keep = _object_rotation_struct(object_rotation, dev, P)
-        if P != 0 and (owned or prologue_scratch is not None or rot_st is not None):
+        if P != 0 and loss_grad is not None:
+            if g_depth is not None or g_alpha is not None:
+                raise RuntimeError("loss_grad: the loss must depend on the colour output only")
+            scratch = prologue_scratch if prologue_scratch is not None else torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
+            _lib.check(L.egs_backward_lossgrad(
+                P, int(degree), M, int(R), _ptr(background), _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors), _ptr(scales),
+                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix),
+                _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
+                _ptr(imageBuffer), C.byref(loss_grad), _ptr(dmeans2D), _ptr(dcolors),
+                _ptr(dopacity), _ptr(dmeans3D_arg), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
+                _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
+                C.byref(sink.struct) if owned else None, 1 if prologue_scratch is not None else 0,
+                C.byref(rot_st) if rot_st is not None else None, 0, _ptr(scratch), _stream(dev), int(bool(debug))))
+            if owned:
+                sink.mark_stepped()
+        elif P != 0 and (owned or prologue_scratch is not None or rot_st is not None):
             scratch = prologue_scratch if prologue_scratch is not None else torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
             _lib.check(L.egs_backward_adam(
                 P, int(degree), M, int(R), _ptr(background), _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors), _ptr(scales),

@@ -165,6 +165,12 @@ int egs_abi_version(void) { return EGS_ABI_VERSION; }
 #endif
 const char* egs_source_hash(void) { return EGS_SOURCE_HASH; }
 
+// experiment hook: the next backward blends compute the image-loss gradient themselves (all NULL: off)
+int egs_debug_set_lossgrad(const float* img, const float* gt, const float* m0, const float* m1, const float* m2, const float* gate,
+                           const float* upstream, float lambda_dssim) {
+    egs_debug_lossgrad = EgsLossGradHost{ img, gt, m0, m1, m2, gate, upstream, nullptr, 1.f - lambda_dssim, lambda_dssim };
+    return 0;
+}
 int egs_debug_set_tile_culling(int on) { const int old = egs_tile_culling; egs_tile_culling = on ? 1 : 0; return old; }
 static int g_fused_count = -1;       // -1: not decided yet (EGS_NO_FUSED_COUNT=1 in the environment turns it off)
 static bool fused_count_on() {
@@ -477,10 +483,22 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
                  float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
                  float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
                  const uint32_t* skip_flag, const egs_adam_sink* sink, int prologue_done, const egs_object_rotation* rot, int grad_mask, void* scratch,
-                 void* stream, int debug) {
+                 void* stream, int debug, const egs_loss_grad* loss_grad = nullptr) {
     int rc = check_dims(P, width, height); if (rc) return rc;
     EgsObjRot orot; rc = obj_rot_args(rot, scales, orot); if (rc) return rc;
-    if (P == 0) return 0;
+    // the image loss's gradient computed by the blend itself (egs_backward_lossgrad): colour gradients only, three channels
+    EgsLossGradHost lgh = {}; const EgsLossGradHost* lgp = nullptr;
+    if (loss_grad) {
+        const egs_loss_grad& q = *loss_grad;
+        if (!q.image || !q.gt || !q.dm_dmu1 || !q.dm_dexx || !q.dm_dexy || !q.upstream_grad) return EGS_ERR_ARG;
+        if (dL_dout_depth || dL_dout_alpha || (grad_mask == EGS_GRAD_COLORS && colors_precomp && !sink && !stat_grad_accum)) return EGS_ERR_MODE;
+        lgh = EgsLossGradHost{ q.image, q.gt, q.dm_dmu1, q.dm_dexx, q.dm_dexy, q.gate, q.upstream_grad, nullptr, 1.f - q.lambda_dssim, q.lambda_dssim,
+                               q.deferred_partial_sums, q.deferred_partial_sums ? egs_l1_ssim_partial_count(3, height, width) / 2 : 0, q.lambda_dssim,
+                               q.deferred_loss, q.deferred_partial_sums ? q.loss_running_sum : nullptr };
+        lgp = &lgh;
+        if (!dL_dout_color) dL_dout_color = q.image;                 // (never read: the checks below want a pointer)
+    }
+    if (P == 0) { if (lgp) EGS_TRY(egs_launch_loss_finish(lgh, width, height, (hipStream_t)stream)); return 0; }
     if (R < 0 || R >= (1ll << 31)) return EGS_ERR_RANGE;
     if (grad_mask & ~EGS_GRAD_MASK_BITS) return EGS_ERR_ARG;
     // Only the precomputed colours' gradient is wanted (the reference's label call): a blend that sums w dL/dC alone, no preprocess backward
@@ -500,7 +518,7 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
         EgsImgPtrs im = img_ptrs(const_cast<void*>(image_buffer), width, height);
         if (!prologue_done) EGS_TRY(egs_launch_backward_prologue(P, width, height, im, grad_acc, g.block_hot, nullptr, s));
         egs_prof_start(EGS_K_RENDER_BWD, s);
-        EGS_TRY(egs_launch_render_backward(P, width, height, background, g, b.point_list, im, dL_dout_color, nullptr, nullptr, grad_acc, 1, s));
+        EGS_TRY(egs_launch_render_backward(P, width, height, background, g, b.point_list, im, dL_dout_color, nullptr, nullptr, grad_acc, 1, nullptr, s));
         egs_prof_stop(EGS_K_RENDER_BWD, s);
         EGS_SYNC_IF_DEBUG(s);
         egs_prof_start(EGS_K_PREPROCESS_BWD, s);
@@ -562,11 +580,12 @@ static int backward_impl(int P, int sh_degree, int sh_coeffs, int64_t R, const f
         EGS_TRY(egs_launch_zero_f4((float4*)grad_acc, egs_acc_floats((size_t)P) / 4, s));
         if (sink) EGS_TRY(egs_launch_adam_tick(tick, s));
     }
+    if (R == 0 && lgp) EGS_TRY(egs_launch_loss_finish(lgh, width, height, s));
     if (R > 0) {
         const uint32_t* point_list = b.point_list;
         if (!prologue_done) EGS_TRY(egs_launch_backward_prologue(P, width, height, im, grad_acc, g.block_hot, sink ? &tick : nullptr, s));
         egs_prof_start(EGS_K_RENDER_BWD, s);                         // (the stage is the blend kernel alone)
-        EGS_TRY(egs_launch_render_backward(P, width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth, dL_dout_alpha, grad_acc, 0, s));
+        EGS_TRY(egs_launch_render_backward(P, width, height, background, g, point_list, im, dL_dout_color, dL_dout_depth, dL_dout_alpha, grad_acc, 0, lgp, s));
         egs_prof_stop(EGS_K_RENDER_BWD, s);
         EGS_SYNC_IF_DEBUG(s);
     }
@@ -618,6 +637,23 @@ int egs_backward_adam(int P, int sh_degree, int sh_coeffs, int64_t R, const floa
                          skip_flag, sink, prologue_done, rot, grad_mask, scratch, stream, debug);
 }
 
+int egs_backward_lossgrad(int P, int sh_degree, int sh_coeffs, int64_t R, const float* background, const float* means3D,
+                          const float* shs, const float* shs_rest, const float* colors_precomp, const float* scales, float scale_modifier,
+                          const float* rotations, const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix,
+                          const float* campos, int width, int height, float tan_fovx, float tan_fovy, const int32_t* radii,
+                          const void* geom_buffer, const void* binning_buffer, const void* image_buffer, const egs_loss_grad* loss_grad,
+                          float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
+                          float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
+                          const uint32_t* skip_flag, const egs_adam_sink* sink, int prologue_done, const egs_object_rotation* rot, int grad_mask, void* scratch,
+                          void* stream, int debug) {
+    if (!loss_grad) return EGS_ERR_ARG;
+    return backward_impl(P, sh_degree, sh_coeffs, R, background, means3D, shs, shs_rest, colors_precomp, scales, scale_modifier, rotations,
+                         cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, width, height, tan_fovx, tan_fovy, radii, geom_buffer,
+                         binning_buffer, image_buffer, nullptr, nullptr, nullptr, dL_dmeans2D, dL_dcolors, dL_dopacity,
+                         dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscales, dL_drotations, stat_grad_accum, stat_denom, stat_max_radii,
+                         skip_flag, sink, prologue_done, rot, grad_mask, scratch, stream, debug, loss_grad);
+}
+
 // egs_backward_prologue (HOST struct) -> the side jobs a loss backward launch carries
 static int prologue_args(const egs_backward_prologue* side, EgsPrologueArgs& pa) {
     int rc = check_dims(side->P, side->width, side->height); if (rc) return rc;
@@ -648,6 +684,15 @@ int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* im
     int rc = prologue_args(side, pa); if (rc) return rc;
     return egs_launch_l1_ssim_backward(channels, height, width, img, gt, lambda_dssim, upstream_grad, gate, dm_dmu1, dm_dexx, dm_dexy, dL_dimg,
                                        deferred_partial_sums, deferred_loss, loss_running_sum, &pa, (hipStream_t)stream);
+}
+
+int egs_l1_ssim_forward_ex(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
+                           float* partial_sums, float* dm_dmu1, float* dm_dexx, float* dm_dexy, float* loss, float* loss_running_sum,
+                           const egs_backward_prologue* side, void* stream) {
+    EgsPrologueArgs pa = {};
+    if (side) { int rc = prologue_args(side, pa); if (rc) return rc; }
+    return egs_launch_l1_ssim_forward(channels, height, width, img, gt, lambda_dssim, partial_sums, dm_dmu1, dm_dexx, dm_dexy, loss, loss_running_sum,
+                                      side ? &pa : nullptr, (hipStream_t)stream);
 }
 
 int egs_l1_ssim_pair_backward(int channels, int height, int width, const float* img, const float* gt, const float* upstream_l1,

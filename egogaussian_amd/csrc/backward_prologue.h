@@ -209,3 +209,6 @@ int egs_launch_l1_ssim_backward(int channels, int height, int width, const float
                                 const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
                                 const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
                                 float* loss_running_sum, const EgsPrologueArgs* side, hipStream_t stream);
+int egs_launch_l1_ssim_forward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
+                               float* partial_sums, float* dm_dmu1, float* dm_dexx, float* dm_dexy, float* loss, float* loss_running_sum,
+                               const EgsPrologueArgs* side, hipStream_t stream);      // side != NULL: the launch carries the backward blend's preparation

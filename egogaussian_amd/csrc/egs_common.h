@@ -200,9 +200,18 @@ hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs 
 // of an optimizer fused into this backward) as a launch of its own -- or carried by egs_l1_ssim_backward_ex (backward_prologue.h).
 // block_hot (may be NULL: every replica line is cleared): the per-workgroup hot counts of the frame's preprocess -- only the replica lines in use are cleared
 hipError_t egs_launch_backward_prologue(int P, int W, int H, EgsImgPtrs im, float* grad_acc, const uint32_t* block_hot, const EgsAdamTick* tick, hipStream_t s);
+// The image loss's gradient computed inside the backward blend (render_bwd.hip k_render_backward<1, true>): what the loss forward left.
+// w_l1_n, w_ssim_n: the weights of mean|x - y| and of (1 - mean SSIM) before the division by the element count (loss.hip).
+// fin_*: the loss VALUE the forward deferred (egs_l1_ssim_forward with loss == NULL) is assembled by one wave of the blend launch.
+struct EgsLossGradHost { const float* img; const float* gt; const float* dm_dmu1; const float* dm_dexx; const float* dm_dexy; const float* gate;
+                         const float* upstream; const float* upstream_ssim; float w_l1_n, w_ssim_n;
+                         const float* fin_partial; size_t fin_n; float fin_lambda; float* fin_loss; float* fin_running; };
+extern EgsLossGradHost egs_debug_lossgrad;
+hipError_t egs_launch_loss_finish(const EgsLossGradHost& lg, int W, int H, hipStream_t s);     // the deferred value alone (a frame with no instance)
+// lg (may be NULL): the blend computes dL/dcolour itself (k_render_backward<1, true>); dL_dcolor, dL_ddepth, dL_dalpha are then not read
 hipError_t egs_launch_render_backward(int P, int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
-                                      const float* dL_dalpha, float* grad_acc, int colors_only, hipStream_t s);
+                                      const float* dL_dalpha, float* grad_acc, int colors_only, const EgsLossGradHost* lg, hipStream_t s);
 // colors_only: the blend left only the colour sums (k_render_backward<0>); this turns them into dL/dcolors_precomp [P,3]
 hipError_t egs_launch_colors_from_acc(int P, const float* grad_acc, const uint8_t* clamped, const int32_t* radii, float* dcolors, hipStream_t s);
 hipError_t egs_launch_adam_tick(const EgsAdamTick& tick, hipStream_t s);       // the same bookkeeping as a launch of its own (frames with no instance)

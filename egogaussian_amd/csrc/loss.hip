@@ -11,6 +11,7 @@
 // 20 B in + 4 B out backward (+ 10/SR halo rows and 10/54 halo columns re-read).
 #include "egs_common.h"
 #include "backward_prologue.h"
+#include "loss_window.h"
 
 // Mapping (wave64 streaming, no workgroup barriers): a wave owns a strip of SW = 54 output columns x SR output rows of
 // one channel.  Lane L is image column  strip_x0 - 5 + L  (5 halo columns each side) and walks DOWN the rows:
@@ -35,17 +36,6 @@
 #endif
 
 namespace {
-
-// gaussian(11, 1.5) normalised, as float32 (utils/loss_utils.py:66-68)
-#define KW0 1.028380124e-03f
-#define KW1 7.598758209e-03f
-#define KW2 3.600077331e-02f
-#define KW3 1.093606874e-01f
-#define KW4 2.130055279e-01f
-#define KW5 2.660117149e-01f
-__device__ __forceinline__ constexpr float kwin(int k) {
-    return k == 0 || k == 10 ? KW0 : k == 1 || k == 9 ? KW1 : k == 2 || k == 8 ? KW2 : k == 3 || k == 7 ? KW3 : k == 4 || k == 6 ? KW4 : KW5;
-}
 
 // Forward: the maps are blurred in PAIRS, (E[x], E[y]) and (E[x^2 + y^2], E[xy]).  A pair lives in a 64-bit register pair and every tap is one v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 -- the same IEEE
 // operations per component in the same order as the scalar formulation, at half the instruction count -- and one ds_write_b64 /
@@ -171,11 +161,19 @@ __device__ __forceinline__ unsigned loss_logical_block(unsigned b, unsigned main
 }
 
 // grid: 8 * ceil(C * ceil(strips_x * strips_y / WPB) / 8) (1-D, see loss_logical_block); a wave = one strip
+// SIDE: the last `side_jobs` workgroups carry the preparation of the rasterizer's backward blend of the same frame (as k_l1_ssim_backward<true>
+// does) -- for a training step whose blend computes the loss gradient itself (render_bwd.hip, LG) and therefore has no loss-backward launch.
+template <bool SIDE>
 __global__ __launch_bounds__(64 * WPB) void k_l1_ssim_forward(int H, int W, int strips_x, int strips_y, const float* __restrict__ img,
                                                                const float* __restrict__ gt, float* __restrict__ partial,
                                                                float* __restrict__ dm_dmu1, float* __restrict__ dm_dexx,
-                                                               float* __restrict__ dm_dexy, unsigned per_plane, unsigned main_wgs) {
+                                                               float* __restrict__ dm_dexy, unsigned per_plane, unsigned main_wgs,
+                                                               unsigned side_jobs, EgsPrologueArgs side) {
     __shared__ v2f lds[WPB][2 * 80];
+    if (SIDE) {
+        __shared__ EgsOrderLds order_lds;
+        if (blockIdx.x >= gridDim.x - side_jobs) { egs_prologue_job<64 * WPB>(side, blockIdx.x - (gridDim.x - side_jobs), side_jobs, order_lds); return; }
+    }
     const unsigned lane = threadIdx.x & 63, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
     const unsigned rel = loss_logical_block(blockIdx.x, main_wgs);
     if (rel >= main_wgs) return;
@@ -297,28 +295,6 @@ __device__ __forceinline__ void bwd_step(BwdCtx& c, Window<3>& w, int y_in, floa
     }
 }
 
-// The scalar loss from the per-strip partial sums, by ONE wave (fixed order, so the value is deterministic): used by the backward kernel when the caller deferred
-// the loss value to it (egs_l1_ssim_forward with loss == NULL) -- a training step replayed from a graph reads the value only after
-// the backward anyway, and every launch it does not make is ~4.5 us of GPU time.
-__device__ __forceinline__ void wave_finish_loss(size_t nblocks, const float* __restrict__ partial, float w_l1, float w_ssim, float lambda,
-                                                 float* __restrict__ loss, float* __restrict__ running_sum, unsigned lane) {
-    float a = 0.f, b = 0.f;
-    for (size_t i0 = 0; i0 < nblocks; i0 += 64 * 8) {                  // eight loads in flight per lane
-        float2 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { const size_t i = i0 + (size_t)k * 64 + lane; v[k] = i < nblocks ? reinterpret_cast<const float2*>(partial)[i] : make_float2(0.f, 0.f); }
-#pragma unroll
-        for (int k = 0; k < 8; k++) { a += v[k].x; b += v[k].y; }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
-    if (lane == 0) {
-        const float v = w_l1 * a + lambda - w_ssim * b;
-        if (loss) loss[0] = v;
-        if (running_sum) running_sum[0] += v;
-    }
-}
-
 // SIDE: the launch also carries the jobs that prepare the rasterizer's backward blend of the same frame (backward_prologue.h) in
 // its LAST `side_jobs` workgroups -- tile ordering on one CU per XCD, the fused optimizer's bookkeeping, clearing the gradient
 // accumulator with a few dozen workgroups that stride over it.  (Round 2 put ~1 500 short zeroing workgroups FIRST: they took every
@@ -435,6 +411,9 @@ int egs_launch_l1_ssim_backward_w(int channels, int height, int width, const flo
                                 const float* upstream_grad, const float* upstream_ssim, const float* gate, const float* dm_dmu1, const float* dm_dexx,
                                 const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
                                 float* loss_running_sum, const EgsPrologueArgs* side, hipStream_t stream);
+int egs_launch_l1_ssim_forward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
+                               float* partial_sums, float* dm_dmu1, float* dm_dexx, float* dm_dexy, float* loss, float* loss_running_sum,
+                               const EgsPrologueArgs* side, hipStream_t stream);
 int egs_launch_l1_ssim_backward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
                                 const float* upstream_grad, const float* gate, const float* dm_dmu1, const float* dm_dexx,
                                 const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
@@ -482,18 +461,38 @@ size_t egs_l1_ssim_partial_count(int channels, int height, int width) {
 int egs_l1_ssim_forward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
                         float* partial_sums, float* dm_dmu1, float* dm_dexx, float* dm_dexy, float* loss, float* loss_running_sum,
                         void* stream) {
+    return egs_launch_l1_ssim_forward(channels, height, width, img, gt, lambda_dssim, partial_sums, dm_dmu1, dm_dexx, dm_dexy, loss, loss_running_sum,
+                                      nullptr, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+int egs_launch_l1_ssim_forward(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
+                               float* partial_sums, float* dm_dmu1, float* dm_dexx, float* dm_dexy, float* loss, float* loss_running_sum,
+                               const EgsPrologueArgs* side, hipStream_t stream) {
     if (channels <= 0 || height <= 0 || width <= 0 || !img || !gt || !partial_sums || !dm_dmu1 || !dm_dexx || !dm_dexy)
         return EGS_ERR_ARG;
     const int strips_x = (width + SW - 1) / SW, strips_y = (height + SR - 1) / SR;
     const unsigned per_plane = (unsigned)((strips_x * strips_y + WPB - 1) / WPB), main_wgs = per_plane * (unsigned)channels;
-    hipLaunchKernelGGL(k_l1_ssim_forward, dim3(((main_wgs + 7u) / 8u) * 8u), dim3(64 * WPB), 0, (hipStream_t)stream, height, width, strips_x, strips_y, img, gt,
-                       partial_sums, dm_dmu1, dm_dexx, dm_dexy, per_plane, main_wgs);
+    const unsigned main_pad = ((main_wgs + 7u) / 8u) * 8u;
+    EgsPrologueArgs none = {};
+    if (side) {
+        // 124 VGPRs: eight 2-wave workgroups per CU, 2 048 resident slots; the zeroing workgroups take what the strips leave, 32 at least
+        const unsigned spare = main_pad + EGS_XCDS + 1 + 32 <= 2048 ? 2048 - main_pad - EGS_XCDS - 1 : 32;
+        const unsigned side_jobs = egs_prologue_jobs(side->n4, side->has_tick, 64 * WPB, spare);
+        hipLaunchKernelGGL(k_l1_ssim_forward<true>, dim3(main_pad + side_jobs), dim3(64 * WPB), 0, stream, height, width, strips_x, strips_y, img, gt,
+                           partial_sums, dm_dmu1, dm_dexx, dm_dexy, per_plane, main_wgs, side_jobs, *side);
+    } else
+    hipLaunchKernelGGL(k_l1_ssim_forward<false>, dim3(main_pad), dim3(64 * WPB), 0, stream, height, width, strips_x, strips_y, img, gt,
+                       partial_sums, dm_dmu1, dm_dexx, dm_dexy, per_plane, main_wgs, 0u, none);
     const float n = (float)channels * (float)height * (float)width;
     if (loss)                                       // loss == NULL: the value is assembled by egs_l1_ssim_backward (deferred)
-        hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, (size_t)strips_x * strips_y * channels, partial_sums,
+        hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, stream, (size_t)strips_x * strips_y * channels, partial_sums,
                            (1.f - lambda_dssim) / n, lambda_dssim / n, lambda_dssim, loss, loss_running_sum);
     return (int)hipGetLastError();
 }
+
+extern "C" {
 
 int egs_l1_ssim_pair_forward(int channels, int height, int width, const float* img, const float* gt, float* partial_sums, float* dm_dmu1,
                              float* dm_dexx, float* dm_dexy, float* l1_out, float* ssim_out, void* stream) {

@@ -23,6 +23,7 @@
 #include "blend_common.h"
 #include "backward_prologue.h"
 #include "blend_instrument.h"      // measurement / ablation hooks: all empty in the product build
+#include "loss_window.h"
 #include <algorithm>
 
 namespace {
@@ -63,18 +64,33 @@ __global__ __launch_bounds__(1024) void k_backward_prologue(EgsPrologueArgs a) {
 // MODE 0 (ABI 4, egs_backward grad_mask == EGS_GRAD_COLORS): only dL/dcolors_precomp is wanted -- the reference's label call
 // (/root/reference/gaussian_renderer/render_helper.py:38-54 detaches every geometric input).  dL/dcolour_c = sum over pixels of
 // w dL/dC_c with w = alpha T: no dL/dalpha recurrence, no background term, no moments -- three sums per (wave, splat) instead of ten.
-template <int MODE>
+// LG (loss gradient inside the blend): dL/dC of the tile's 256 pixels is not loaded but computed here from what the image loss's FORWARD
+// left -- its three derivative maps, the image and the ground truth -- with k_l1_ssim_backward's arithmetic, operation for operation
+// (loss.hip bwd_step / vblur_s / hblur_s: vertical 11-tap blur of the maps first, then the horizontal one, zero padding outside the image),
+// so that the training step needs no loss-backward launch at all.  Threads 0..233 = (channel, map, window column): each loads its column of
+// the tile's 26-row window and leaves 16 vertically blurred values in LDS ([channel][map][16][27] floats, 15.2 KiB, in the space the loop
+// below uses for the staged records and the reduction); after ONE barrier every lane blurs horizontally at its own pixel.
+#ifdef EGS_LG_CHECK
+__device__ unsigned egs_lg_mismatch;
+#endif
+struct EgsLossGrad { const float* img; const float* gt; const float* m0; const float* m1; const float* m2; const float* gate;
+                     const float* up; const float* up_ssim; float w_l1, w_ssim;
+                     const float* fin_partial; size_t fin_n; float fin_lambda; float* fin_loss; float* fin_running; };
+#define LG_COLS 27
+template <int MODE, bool LG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_render_backward(
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ tile_order, float* __restrict__ grad_acc,
     const uint32_t* __restrict__ quad_visits, const uint32_t hot_base /* first float of the hot replica lines inside grad_acc */,
-    const uint32_t hot_slots /* lines per replica = ceil(P / 256) * EGS_HOT_PER_BLOCK */) {
+    const uint32_t hot_slots /* lines per replica = ceil(P / 256) * EGS_HOT_PER_BLOCK */, const EgsLossGrad lg) {
     constexpr bool HAS_DA = MODE == 2;
     constexpr int NV = MODE == 0 ? 3 : 10;                            // sums per (wave, splat)
-    __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
-    __shared__ __attribute__((aligned(16))) float red[4][5 * 64];
+    __shared__ float4 smem[4 * 64 * EGS_SPLAT_REC_F4 + 4 * 5 * 16];      // the staged records of four waves, then their reduction slices
+    float4 (*lds)[64 * EGS_SPLAT_REC_F4] = reinterpret_cast<float4 (*)[64 * EGS_SPLAT_REC_F4]>(smem);
+    float (*red)[5 * 64] = reinterpret_cast<float (*)[5 * 64]>(smem + 4 * 64 * EGS_SPLAT_REC_F4);
+    static_assert(sizeof(smem) >= 9 * 16 * LG_COLS * sizeof(float), "the loss-gradient prologue's blurred maps fit the loop's LDS");
     __shared__ uint32_t quad_claimed;
     const uint32_t order_word = tile_order[blockIdx.x];              // 0xffffffff = padding workgroup
     if (order_word == 0xffffffffu) return;
@@ -103,9 +119,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     float* myred = red[wv];
     EGS_BWD_MEASURE(const uint64_t t_start = wall_clock64(); uint32_t meas = 0;)
     const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
-    if (qx0 >= W || qy0 >= H) return;
     const int px = qx0 + (int)(lane & 7), py = qy0 + (int)(lane >> 3);
     const bool inside = px < W && py < H;
+    float lg_r = 0.f, lg_g = 0.f, lg_b = 0.f;
+    if (LG) {
+        // the loss value the forward deferred: one wave of the launch adds up the per-strip partial sums (loss_window.h), as k_l1_ssim_backward did
+        if (lg.fin_partial && blockIdx.x == 0 && wv == 0) wave_finish_loss(lg.fin_n, lg.fin_partial, lg.w_l1, lg.w_ssim, lg.fin_lambda, lg.fin_loss, lg.fin_running, lane);
+        const int tx0 = (tile % gx) * EGS_TILE, ty0 = (tile / gx) * EGS_TILE;
+        float* vb = reinterpret_cast<float*>(smem);                  // [9][16][LG_COLS]
+        const size_t HWp = (size_t)H * W;
+        if (!(order_word & EGS_ORDER_HAS_PERM)) __syncthreads();      // (nothing else has touched the LDS yet; keeps the barrier count uniform)
+        if (threadIdx.x < 234) {
+            const unsigned cm = threadIdx.x / 26u, col = threadIdx.x - cm * 26u, ch = cm / 3u, mp_i = cm - ch * 3u;
+            const float* __restrict__ mp = (mp_i == 0 ? lg.m0 : mp_i == 1 ? lg.m1 : lg.m2) + ch * HWp;
+            const int gxc = tx0 - 5 + (int)col;
+            const bool colok = gxc >= 0 && gxc < W;
+            float wv_[26];
+#pragma unroll
+            for (int r = 0; r < 26; r++) {
+                const int gy_ = ty0 - 5 + r;
+                const bool ok = colok && gy_ >= 0 && gy_ < H;
+                wv_[r] = ok ? mp[(size_t)gy_ * W + gxc] : 0.f;
+            }
+            float* dst = vb + (size_t)cm * 16 * LG_COLS + col;
+#pragma unroll
+            for (int o = 0; o < 16; o++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) acc = fmaf(kwin(k), wv_[o + k], acc);
+                dst[o * LG_COLS] = acc;
+            }
+        }
+        __syncthreads();
+        // horizontal blur at the lane's own pixel, then the gradient of 0.8 L1 + 0.2 (1 - SSIM) (bwd_step of loss.hip, operation for operation)
+        if (inside) {
+            const int lx = px - tx0, ly = py - ty0;
+            const float up0 = lg.up[0];
+            float w_l1 = lg.w_l1, w_ssim = lg.w_ssim, up = up0;
+            if (lg.up_ssim) { w_l1 *= up0; w_ssim *= lg.up_ssim[0]; up = 1.f; }
+            const float gate = lg.gate ? lg.gate[(size_t)py * W + px] : 1.f;
+            float gch[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                float bl[3];
+#pragma unroll
+                for (int m = 0; m < 3; m++) {
+                    const float* r = vb + (size_t)(ch * 3 + m) * 16 * LG_COLS + ly * LG_COLS + lx;      // r[k] = column lx - 5 + k of the window
+                    float acc = kwin(0) * (r[0] + r[10]);
+                    acc = fmaf(kwin(1), r[1] + r[9], acc); acc = fmaf(kwin(2), r[2] + r[8], acc);
+                    acc = fmaf(kwin(3), r[3] + r[7], acc); acc = fmaf(kwin(4), r[4] + r[6], acc);
+                    bl[m] = fmaf(kwin(5), r[5], acc);
+                }
+                const size_t q = ch * HWp + (size_t)py * W + px;
+                const float x = lg.img[q], y = lg.gt[q];
+                const float diff = x - y;
+                const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                float g = w_l1 * sgn - w_ssim * (bl[0] + 2.f * x * bl[1] + y * bl[2]);
+                g *= up;
+                if (lg.gate) g *= gate;
+                gch[ch] = g;
+            }
+            lg_r = gch[0]; lg_g = gch[1]; lg_b = gch[2];
+        }
+        __syncthreads();                                              // the loop below reuses this LDS for its staged records
+    }
+    if (qx0 >= W || qy0 >= H) return;
+
     const float pxf = (float)px, pyf = (float)py;
     const uint32_t qx1 = (uint32_t)min(qx0 + 7, W - 1), qy1 = (uint32_t)min(qy0 + 7, H - 1);
 
@@ -117,7 +196,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         T_final = final_T[pix]; last = n_contrib[pix];
-        g_r = dL_dcolor[pix]; g_g = dL_dcolor[HW + pix]; g_b = dL_dcolor[2 * HW + pix];
+        if (LG) { g_r = lg_r; g_g = lg_g; g_b = lg_b; }
+        else { g_r = dL_dcolor[pix]; g_g = dL_dcolor[HW + pix]; g_b = dL_dcolor[2 * HW + pix]; }
+#ifdef EGS_LG_CHECK                     // debug build: the computed gradient against the one k_l1_ssim_backward wrote (bit for bit)
+        if (LG && (__float_as_uint(lg_r) != __float_as_uint(dL_dcolor[pix]) || __float_as_uint(lg_g) != __float_as_uint(dL_dcolor[HW + pix]) ||
+                   __float_as_uint(lg_b) != __float_as_uint(dL_dcolor[2 * HW + pix]))) atomicAdd(&egs_lg_mismatch, 1u);
+#endif
         if (HAS_DA && dL_ddepth) g_d = dL_ddepth[pix];
         if (HAS_DA && dL_dalpha) g_a = dL_dalpha[pix];
     }
@@ -255,6 +339,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 }  // namespace
 
+EgsLossGradHost egs_debug_lossgrad = {};
+namespace {
+__global__ __launch_bounds__(64) void k_loss_finish(size_t n, const float* __restrict__ partial, float w_l1, float w_ssim, float lambda, float* loss, float* running) {
+    wave_finish_loss(n, partial, w_l1, w_ssim, lambda, loss, running, threadIdx.x);
+}
+}  // namespace
+hipError_t egs_launch_loss_finish(const EgsLossGradHost& lg, int W, int H, hipStream_t s) {
+    if (!lg.fin_partial) return hipSuccess;
+    const float n = (float)W * (float)H * 3.f;
+    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, s, lg.fin_n, lg.fin_partial, lg.w_l1_n / n, lg.w_ssim_n / n, lg.fin_lambda, lg.fin_loss, lg.fin_running);
+    return hipGetLastError();
+}
+#ifdef EGS_LG_CHECK
+extern "C" unsigned egs_debug_lg_mismatches() { unsigned v = 0; (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(egs_lg_mismatch), sizeof(v)); return v; }
+#endif
 // What the blend below needs in place: tile order, cleared accumulator, (fused optimizer) bookkeeping -- as a launch of its own
 // (egs_l1_ssim_backward_ex can carry the same jobs instead).
 hipError_t egs_launch_backward_prologue(int P, int W, int H, EgsImgPtrs im, float* grad_acc, const uint32_t* block_hot, const EgsAdamTick* tick, hipStream_t s) {
@@ -273,16 +372,22 @@ hipError_t egs_launch_backward_prologue(int P, int W, int H, EgsImgPtrs im, floa
 
 hipError_t egs_launch_render_backward(int P, int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
-                                      const float* dL_dalpha, float* grad_acc, int colors_only, hipStream_t s) {
+                                      const float* dL_dalpha, float* grad_acc, int colors_only, const EgsLossGradHost* lg, hipStream_t s) {
+    if (!lg && egs_debug_lossgrad.img) lg = &egs_debug_lossgrad;      // (experiment hook: egs_debug_set_lossgrad)
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
     if (n_tiles == 0) return hipSuccess;
-#define EGS_BWD_LAUNCH(MODE) hipLaunchKernelGGL(k_render_backward<MODE>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles, \
+    EgsLossGrad lgk = {};
+    if (lg) { lgk.img = lg->img; lgk.gt = lg->gt; lgk.m0 = lg->dm_dmu1; lgk.m1 = lg->dm_dexx; lgk.m2 = lg->dm_dexy; lgk.gate = lg->gate;
+              lgk.up = lg->upstream; lgk.up_ssim = lg->upstream_ssim; lgk.w_l1 = lg->w_l1_n / ((float)W * (float)H * 3.f); lgk.w_ssim = lg->w_ssim_n / ((float)W * (float)H * 3.f);
+              lgk.fin_partial = lg->fin_partial; lgk.fin_n = lg->fin_n; lgk.fin_lambda = lg->fin_lambda; lgk.fin_loss = lg->fin_loss; lgk.fin_running = lg->fin_running; }
+#define EGS_BWD_LAUNCH(MODE, LGF) hipLaunchKernelGGL((k_render_backward<MODE, LGF>), dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles, \
                            im.ranges, point_list, g.rec, bg, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, \
-                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles, (uint32_t)((size_t)P * EGS_GRAD_STRIDE), (uint32_t)egs_hot_slots((size_t)P))
-    if (colors_only) EGS_BWD_LAUNCH(0);
-    else if (dL_ddepth || dL_dalpha) EGS_BWD_LAUNCH(2);
-    else EGS_BWD_LAUNCH(1);
+                           im.tile_order, grad_acc, im.quad_pairs + (size_t)4 * n_tiles, (uint32_t)((size_t)P * EGS_GRAD_STRIDE), (uint32_t)egs_hot_slots((size_t)P), lgk)
+    if (colors_only) EGS_BWD_LAUNCH(0, false);
+    else if (dL_ddepth || dL_dalpha) EGS_BWD_LAUNCH(2, false);
+    else if (lg) EGS_BWD_LAUNCH(1, true);
+    else EGS_BWD_LAUNCH(1, false);
 #undef EGS_BWD_LAUNCH
     return hipGetLastError();
 }

@@ -140,7 +140,7 @@ def rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation
 
 class _L1SSIM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, gt, lambda_dssim, gate, running_sum=None, defer_value=False, raster_node=None):
+    def forward(ctx, img, gt, lambda_dssim, gate, running_sum=None, defer_value=False, raster_node=None, lossgrad=False):
         L = _lib.load()
         img, gt = _need_hip(img, "image"), _need_hip(gt, "gt")
         assert img.dim() == 3 and img.shape == gt.shape
@@ -149,9 +149,21 @@ class _L1SSIM(torch.autograd.Function):
         partial = torch.empty(L.egs_l1_ssim_partial_count(Cc, H, W), device=dev)
         maps = torch.empty((3, Cc, H, W), device=dev)
         loss = torch.empty((), device=dev)
+        side = None
+        if lossgrad and raster_node is not None and Cc == 3:
+            # raster_lossgrad: the rasterizer's backward blend will compute this loss's image gradient itself; what the loss BACKWARD launch
+            # used to carry for it (tile order, cleared accumulator, optimizer bookkeeping) rides in this forward launch instead
+            from .rasterizer import backward_prologue_of
+            side = backward_prologue_of(raster_node)
         with _hip.device_ctx(dev):
-            _lib.check(L.egs_l1_ssim_forward(Cc, H, W, _p(img), _p(gt), float(lambda_dssim), _p(partial), _p(maps[0]), _p(maps[1]),
-                                             _p(maps[2]), None if defer_value else _p(loss), None if defer_value else _p(running_sum), _stream(dev)))
+            if side is not None:
+                _lib.check(L.egs_l1_ssim_forward_ex(Cc, H, W, _p(img), _p(gt), float(lambda_dssim), _p(partial), _p(maps[0]), _p(maps[1]),
+                                                    _p(maps[2]), None if defer_value else _p(loss), None if defer_value else _p(running_sum),
+                                                    C.byref(side), _stream(dev)))
+            else:
+                _lib.check(L.egs_l1_ssim_forward(Cc, H, W, _p(img), _p(gt), float(lambda_dssim), _p(partial), _p(maps[0]), _p(maps[1]),
+                                                 _p(maps[2]), None if defer_value else _p(loss), None if defer_value else _p(running_sum), _stream(dev)))
+        ctx.lossgrad = side is not None
         ctx.save_for_backward(img, gt, maps, gate if gate is not None else torch.empty(0))
         ctx.lam, ctx.has_gate = float(lambda_dssim), gate is not None
         ctx.deferred = (partial, loss, running_sum) if defer_value else None
@@ -168,6 +180,19 @@ class _L1SSIM(torch.autograd.Function):
         if g.dtype != torch.float32 or not g.is_contiguous():
             g = g.float().contiguous()
         dimg = torch.empty_like(img)
+        if ctx.lossgrad:
+            # no launch here: the rasterizer backward that follows computes dL/dimage inside its blend kernel (include/egs_raster.h
+            # egs_backward_lossgrad) -- bit-identical to what this launch would have written.  `dimg` goes back uninitialised and unread.
+            lg = _lib.LossGrad()
+            lg.image, lg.gt, lg.dm_dmu1, lg.dm_dexx, lg.dm_dexy = img.data_ptr(), gt.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr()
+            lg.gate = gate.data_ptr() if gate is not None else None
+            lg.upstream_grad, lg.lambda_dssim = g.data_ptr(), ctx.lam
+            d = ctx.deferred
+            if d:
+                lg.deferred_partial_sums, lg.deferred_loss = d[0].data_ptr(), d[1].data_ptr()
+                lg.loss_running_sum = d[2].data_ptr() if d[2] is not None else None
+            ctx.raster_node.loss_grad = (lg, (img, gt, maps, gate, g, d))
+            return dimg, None, None, None, None, None, None, None
         side = None
         if ctx.raster_node is not None:
             from .rasterizer import backward_prologue_of
@@ -177,7 +202,7 @@ class _L1SSIM(torch.autograd.Function):
             _lib.check(L.egs_l1_ssim_backward_ex(Cc, H, W, _p(img), _p(gt), ctx.lam, _p(g), _p(gate), _p(maps[0]), _p(maps[1]),
                                                  _p(maps[2]), _p(dimg), _p(d[0]) if d else None, _p(d[1]) if d else None,
                                                  _p(d[2]) if d else None, C.byref(side) if side is not None else None, _stream(img.device)))
-        return dimg, None, None, None, None, None, None
+        return dimg, None, None, None, None, None, None, None
 
 
 class _L1SSIMPair(torch.autograd.Function):
@@ -234,13 +259,17 @@ def l1_and_ssim(image, gt, raster_prologue=True):
     return _L1SSIMPair.apply(image, gt, node)
 
 
-def l1_ssim_loss(image, gt, lambda_dssim=0.2, grad_gate=None, running_sum=None, defer_value=False, raster_prologue=False):
+def l1_ssim_loss(image, gt, lambda_dssim=0.2, grad_gate=None, running_sum=None, defer_value=False, raster_prologue=False, raster_lossgrad=False):
     """(1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)).  `grad_gate` [H,W] multiplies d loss / d image
     per pixel (the reference's `render_image.register_hook(lambda grad: grad * (1 - hand_mask))`).
     running_sum: optional device scalar the loss value is also added to (logging without a launch or a host read per iteration).
     defer_value=True: the returned tensor receives its value during backward() instead of right away -- one launch less per
     iteration, for steps whose loss is only read after the backward (graph.GraphedTrainStep).
-    raster_prologue=True: see below -- one launch less per iteration when `image` is the rasterizer's output itself."""
+    raster_prologue=True: see below -- one launch less per iteration when `image` is the rasterizer's output itself.
+    raster_lossgrad=True (with raster_prologue, three channels, and a loss.backward() that is SURE to follow -- the optimizer bookkeeping of a
+    fused Adam rides in the FORWARD launch then): this loss has no backward launch at all; the rasterizer's backward blend computes the image
+    gradient from the maps this forward leaves, bit-identical to the launch it replaces (include/egs_raster.h egs_backward_lossgrad).  The
+    gradient tensor autograd hands from this loss to the rasterizer is uninitialised memory: hooks on `image` must not read it (use grad_gate)."""
     if running_sum is not None:
         running_sum = _need_hip(running_sum, "running_sum")
     node = None
@@ -251,4 +280,4 @@ def l1_ssim_loss(image, gt, lambda_dssim=0.2, grad_gate=None, running_sum=None, 
         fn = image.grad_fn
         if fn is not None and getattr(fn, "egs_raster_node", False):
             node = fn
-    return _L1SSIM.apply(image, gt, lambda_dssim, grad_gate, running_sum, defer_value, node)
+    return _L1SSIM.apply(image, gt, lambda_dssim, grad_gate, running_sum, defer_value, node, bool(raster_lossgrad and node is not None))

@@ -93,7 +93,7 @@ class _StaticCamera:
 
 class GraphedTrainStep:
     def __init__(self, pc, optimizer, bg, lambda_dssim=0.2, pipe=Pipe, render_kwargs=None, densify_stats=False, dynamic=False,
-                 which_object=1, gated=False, check_every=0, steps_per_replay=1, fuse_optimizer=True, double_buffer=False):
+                 which_object=1, gated=False, check_every=0, steps_per_replay=1, fuse_optimizer=True, double_buffer=False, loss_grad_in_blend=True):
         """densify_stats: the captured step also keeps the per-iteration densification statistics (trainers/train_static.py:125-127:
                        max_radii2D, xyz_gradient_accum, denom) -- updated by the rasterizer's backward itself, no launch of their own.
         dynamic:       the `fine_all` call shape (/root/reference/trainers/fine_all.py:88-93): render(..., rot_cov=True,
@@ -111,11 +111,16 @@ class GraphedTrainStep:
                        960x540 frames: 2.7 us per step).  Results are those of the single-buffered step.  MEASURED at config C: 1.6 % slower than
                        the single graph (3 175 vs 3 225 it/s) -- the event waits between the streams cost more than the hidden copy --,
                        so it is off by default and bench.py does not use it.
+        loss_grad_in_blend: the captured step has NO loss-backward launch: the rasterizer's backward blend computes the image loss's gradient
+                       for its tile itself, from the maps the loss forward leaves, bit-identical to the launch it replaces
+                       (fused.l1_ssim_loss(raster_lossgrad=True), include/egs_raster.h egs_backward_lossgrad): nine launches per step -> eight.
         fuse_optimizer: the parameters render() hands to the rasterizer as stored take their Adam step inside its backward
                        (renderer.render, optimizer=): no gradient arrays, no optimizer launch for them; the step's loss must then
                        depend on the model through that one render only -- which is the step this class captures.  Results are
                        bit-identical either way."""
         self.fuse_optimizer = bool(fuse_optimizer)
+        import os
+        self.loss_grad_in_blend = bool(loss_grad_in_blend) and not os.environ.get("EGS_NO_LOSS_GRAD_IN_BLEND")      # (A/B switch for bench.py)
         self.double_buffer = bool(double_buffer)
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True)")
@@ -143,7 +148,7 @@ class GraphedTrainStep:
                      optimizer=self.opt if self.fuse_optimizer else None, color_only=True, **kw)      # (the loss reads the colour image only)
         # the loss value and the running sum are produced by the loss BACKWARD kernel (nothing reads them before): two launches less
         loss = l1_ssim_loss(out["render"], f["gt"], self.lam, grad_gate=f["gate"] if self.gated else None, running_sum=self.loss_sum,
-                            defer_value=True, raster_prologue=True)
+                            defer_value=True, raster_prologue=True, raster_lossgrad=self.loss_grad_in_blend)
         loss.backward(gradient=self._one)                            # a resident 1.0: no fill kernel per iteration
         self.opt.step()                                              # whatever the backward did not step itself (fuse_optimizer)
         return loss.detach(), out

@@ -45,6 +45,12 @@ class BackwardPrologue(C.Structure):             # egs_backward_prologue
                 ("sink", C.POINTER(AdamSink)), ("skip_flag", C.c_void_p), ("geom_buffer", C.c_void_p)]
 
 
+class LossGrad(C.Structure):                     # egs_loss_grad
+    _fields_ = [("image", C.c_void_p), ("gt", C.c_void_p), ("dm_dmu1", C.c_void_p), ("dm_dexx", C.c_void_p), ("dm_dexy", C.c_void_p),
+                ("gate", C.c_void_p), ("upstream_grad", C.c_void_p), ("lambda_dssim", C.c_float), ("deferred_partial_sums", C.c_void_p),
+                ("deferred_loss", C.c_void_p), ("loss_running_sum", C.c_void_p)]
+
+
 SINK_MEANS3D, SINK_OPACITY, SINK_SCALES, SINK_ROTATIONS, SINK_SH, SINK_SH_REST = range(6)      # EGS_SINK_*
 
 # name -> (restype, argtypes); every symbol include/egs_raster.h declares
@@ -86,6 +92,10 @@ SIGNATURES = {
 
     "egs_l1_ssim_pair_backward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(BackwardPrologue), vp]),
     "egs_l1_ssim_backward_ex": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(BackwardPrologue), vp]),
+    "egs_l1_ssim_forward_ex": (C.c_int, [i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, C.POINTER(BackwardPrologue), vp]),
+    "egs_backward_lossgrad": (C.c_int, [i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32,
+                                        vp, vp, vp, vp, C.POINTER(LossGrad), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                        C.POINTER(AdamSink), i32, C.POINTER(ObjectRotation), i32, vp, vp, i32]),
     "egs_adam_step": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
     "egs_adam_workgroups": (C.c_int64, [i64]),
     "egs_adam_step_capturable": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp]),

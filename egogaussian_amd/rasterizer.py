@@ -67,6 +67,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.guard = guard
         ctx.egs_raster_node = True                  # fused.l1_ssim_loss(raster_prologue=True) recognises its input's grad_fn by this
         ctx.prologue_scratch = None
+        ctx.loss_grad = None                        # fused.l1_ssim_loss(raster_lossgrad=True): (lib.LossGrad, tensors it points to) -- this backward's blend then computes dL/dcolour itself
         ctx.raster_settings = rs
         ctx.activation_flags = int(activation_flags)
         ctx.densify_stats = densify_stats           # (tensors updated in place by the backward; not autograd inputs)
@@ -102,8 +103,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos, geom,
             ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags, sh_rest if split else None, ctx.densify_stats, ctx.guard,
-            ctx.sink, ctx.prologue_scratch, ctx.object_rotation, grad_mask)
+            ctx.sink, ctx.prologue_scratch, ctx.object_rotation, grad_mask, None if ctx.loss_grad is None else ctx.loss_grad[0])
         ctx.prologue_scratch = None
+        ctx.loss_grad = None
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = grads[:8]
         none_if_absent = lambda g, x: g if (g is not None and x.numel() != 0) else None
         return (g_means3D, g_means2D, none_if_absent(g_sh, sh), none_if_absent(g_colors, colors_precomp),

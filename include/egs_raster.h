@@ -423,6 +423,39 @@ int egs_l1_ssim_backward_ex(int channels, int height, int width, const float* im
                             const float* dm_dexy, float* dL_dimg, const float* deferred_partial_sums, float* deferred_loss,
                             float* loss_running_sum, const egs_backward_prologue* side /*HOST or NULL*/, void* stream);
 
+/* ---- ABI 5: a training step WITHOUT a loss-backward launch.  The rasterizer's backward blend runs one workgroup per 16x16 tile and starts
+ * by loading dL/dC of its 256 pixels; that gradient is a function of what the loss FORWARD left (its three derivative maps, the image, the
+ * ground truth) in an 11x11 neighbourhood of the pixel, so the workgroup can compute it itself -- with k_l1_ssim_backward's arithmetic
+ * operation for operation: the values are bit-identical to the ones that kernel would have written (tests/test_gpu_fused.py) -- and the
+ * step loses a launch whose own work was ~15 us (config C: 3 350 -> ~3 450 it/s).  What that launch also carried moves:
+ *   egs_l1_ssim_forward_ex     the forward, carrying the backward blend's preparation (egs_backward_prologue) as egs_l1_ssim_backward_ex did
+ *   egs_backward_lossgrad      egs_backward_adam with an egs_loss_grad in place of the three dL_dout_* arrays (colour loss only: the depth
+ *                              and alpha outputs carry no gradient); sink may be NULL (no optimizer inside); with deferred_partial_sums the
+ *                              loss VALUE the forward deferred is assembled by one wave of the blend launch. */
+typedef struct egs_loss_grad {       /* HOST struct */
+    const float* image;              /* [3,H,W] the rendered image the loss was taken on */
+    const float* gt;                 /* [3,H,W] */
+    const float* dm_dmu1; const float* dm_dexx; const float* dm_dexy;   /* [3,H,W] each, as written by egs_l1_ssim_forward */
+    const float* gate;               /* [H,W] or NULL: per-pixel factor on the image gradient (the trainers' 1 - hand_mask hook) */
+    const float* upstream_grad;      /* device float[1]: dL/d(loss) */
+    float lambda_dssim;
+    const float* deferred_partial_sums;   /* NULL unless the forward deferred the value (loss == NULL there) */
+    float* deferred_loss;            /* device float[1] out, or NULL */
+    float* loss_running_sum;         /* device float[1] in/out, or NULL */
+} egs_loss_grad;
+int egs_l1_ssim_forward_ex(int channels, int height, int width, const float* img, const float* gt, float lambda_dssim,
+                           float* partial_sums, float* dm_dmu1, float* dm_dexx, float* dm_dexy, float* loss /*or NULL: deferred*/,
+                           float* loss_running_sum, const egs_backward_prologue* side /*HOST or NULL*/, void* stream);
+int egs_backward_lossgrad(int P, int sh_degree, int sh_coeffs, int64_t R, const float* background, const float* means3D,
+                          const float* shs, const float* shs_rest, const float* colors_precomp, const float* scales, float scale_modifier,
+                          const float* rotations, const float* cov3D_precomp, int activation_flags, const float* viewmatrix, const float* projmatrix,
+                          const float* campos, int width, int height, float tan_fovx, float tan_fovy, const int32_t* radii,
+                          const void* geom_buffer, const void* binning_buffer, const void* image_buffer, const egs_loss_grad* loss_grad /*HOST*/,
+                          float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
+                          float* dL_dscales, float* dL_drotations, float* stat_grad_accum, float* stat_denom, float* stat_max_radii,
+                          const uint32_t* skip_flag, const egs_adam_sink* sink /*HOST or NULL*/, int prologue_done, const egs_object_rotation* rot /*HOST or NULL*/,
+                          int grad_mask, void* scratch, void* stream, int debug);
+
 /* ---- f-4 (optimizer part): multi-tensor Adam step in one launch.  Same update as torch.optim.Adam(weight_decay=0,
  *      amsgrad=False), which the reference builds at /root/reference/scene/gaussian_model.py:198 and steps at
  *      /root/reference/trainers/train_static.py:137.  All array arguments are HOST arrays of length n_tensors holding

@@ -282,6 +282,78 @@ def test_graphed_train_step_matches_eager():
             assert float(diff.max()) < 0.02, "graph-replayed parameters drifted from the eager ones"
 
 
+@pytest.mark.parametrize("gated", [False, True], ids=["plain", "hand-mask gate"])
+def test_loss_gradient_inside_the_blend_matches_the_loss_backward_launch(gated):
+    """ABI 5 (egs_backward_lossgrad): with raster_lossgrad=True the image loss has NO backward launch -- the rasterizer's backward blend
+    computes dL/dimage for its tile from the maps the loss forward left (bit-identical per pixel: checked with the -DEGS_LG_CHECK build,
+    profiles/), the loss forward carries the blend's preparation, and the deferred loss value is assembled by one wave of the blend.  Every
+    parameter gradient, the loss value and the running sum must be what the separate launch gives (gradients up to the order of the
+    accumulator atomics)."""
+    import math
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.fused import l1_ssim_loss
+    N, H, W = 20000, 135, 250                                           # (a ragged image: partial tiles on both edges)
+    teacher = make_scene(N, H, W, 0); teacher["log_scale"] += math.log(2.0)
+    cam = make_camera(7, H, W, device=DEV)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=DEV)
+    with torch.no_grad():
+        gt = render(cam, SynthGaussians(teacher, device=DEV, requires_grad=False), Pipe, bg)["render"].clone()
+    gate = (torch.rand((H, W), generator=torch.Generator().manual_seed(3)) < 0.8).float().to(DEV) if gated else None
+    res = []
+    for mode in (False, True, True):
+        pc = SynthGaussians(perturb_student(teacher), device=DEV)
+        run = torch.full((1,), 0.25, device=DEV)
+        out = render(cam, pc, Pipe, bg)
+        loss = l1_ssim_loss(out["render"], gt, 0.2, grad_gate=gate, running_sum=run, defer_value=True, raster_prologue=True, raster_lossgrad=mode)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append(([p.grad.clone() for p in pc.parameters() if p.grad is not None], float(loss), float(run)))
+    ref = res[0]
+    assert len(ref[0]) >= 5 and math.isfinite(ref[1]) and ref[1] > 0
+    for got in res[1:]:
+        assert got[1] == ref[1] and got[2] == ref[2] and abs(ref[2] - 0.25 - ref[1]) < 1e-6, "deferred loss value / running sum"
+        assert len(got[0]) == len(ref[0])
+        for a, b in zip(got[0], ref[0]):
+            scale = float(b.abs().max()) + 1e-30
+            assert float((a - b).abs().max()) <= 2e-5 * scale, "gradient with the loss gradient computed inside the blend"
+
+
+def test_graphed_step_with_and_without_loss_gradient_in_the_blend():
+    """GraphedTrainStep(loss_grad_in_blend=False) keeps the loss-backward launch; both captured steps train alike."""
+    import math
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.optim import FusedAdam
+    from egogaussian_amd.graph import GraphedTrainStep
+    N, H, W, K = 20000, 96, 160, 8
+    teacher = make_scene(N, H, W, 0); teacher["log_scale"] += math.log(2.0)
+    student = perturb_student(teacher)
+    cams = [make_camera(k, H, W, device=DEV) for k in (0, 30, 60, 90)]
+    bg = torch.zeros(3, device=DEV)
+    with torch.no_grad():
+        tpc = SynthGaussians(teacher, device=DEV, requires_grad=False)
+        gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
+    groups = lambda pc: [{"params": [pc._xyz], "lr": 1.6e-4}, {"params": [pc._features_dc], "lr": 2.5e-3}, {"params": [pc._opacity], "lr": 0.05},
+                         {"params": [pc._scaling], "lr": 5e-3}, {"params": [pc._rotation], "lr": 1e-3}]
+    runs = []
+    for in_blend in (False, True):
+        pc = SynthGaussians(student, device=DEV)
+        opt = FusedAdam(groups(pc), lr=0.0, eps=1e-15, capturable=True)
+        step = GraphedTrainStep(pc, opt, bg, loss_grad_in_blend=in_blend).capture(cams[0], gts[0], warmup=2)
+        losses = [float(step(cams[k % 4], gts[k % 4]).clone()) for k in range(1, K + 1)]
+        torch.cuda.synchronize()
+        assert step.ok()
+        runs.append((losses, [p.detach().clone() for p in pc.parameters()], float(opt.state[pc._xyz]["step"])))
+    (la, pa, sa), (lb, pb, sb) = runs
+    assert sa == sb == 2 + K
+    assert all(abs(x - y) <= 2e-4 * abs(x) + 1e-7 for x, y in zip(la, lb)), (la, lb)
+    for a, b in zip(pa, pb):
+        if a.numel():
+            diff = (a - b).abs(); scale = float(a.abs().max())
+            assert float((diff > 2e-5 * scale + 1e-6).float().mean()) < 2e-3 and float(diff.max()) < 0.02
+
+
 def test_graphed_fine_all_step_matches_eager():
     """The `fine_all` call shape captured into a graph -- render(rot_cov=True, accum_R=<static, refreshed per call>, which_object=1),
     hand-mask gate as a static input -- replayed on changing (camera, image, accum_R, gate) leaves the parameters where the same steps
