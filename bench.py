@@ -573,7 +573,8 @@ def main():
                     img.register_hook(lambda grad: grad * gk)
                 loss = training_loss(img, gts[k])
             else:
-                loss = l1_ssim_loss(out["render"], gts[k], 0.2, grad_gate=gates[k] if dynamic else None, raster_prologue=eager_fast)
+                loss = l1_ssim_loss(out["render"], gts[k], 0.2, grad_gate=gates[k] if dynamic else None, raster_prologue=eager_fast,
+                                    raster_lossgrad=eager_fast)       # (no loss-backward launch: the blend computes the image gradient itself)
             th2 = time.perf_counter()
             loss.backward()
             th3 = time.perf_counter()

@@ -308,7 +308,7 @@ def test_loss_gradient_inside_the_blend_matches_the_loss_backward_launch(gated):
         loss = l1_ssim_loss(out["render"], gt, 0.2, grad_gate=gate, running_sum=run, defer_value=True, raster_prologue=True, raster_lossgrad=mode)
         loss.backward()
         torch.cuda.synchronize()
-        res.append(([p.grad.clone() for p in pc.parameters() if p.grad is not None], float(loss), float(run)))
+        res.append(([p.grad.clone() for p in pc.parameters() if p.grad is not None], float(loss.detach()), float(run)))
     ref = res[0]
     assert len(ref[0]) >= 5 and math.isfinite(ref[1]) and ref[1] > 0
     for got in res[1:]:
@@ -317,6 +317,33 @@ def test_loss_gradient_inside_the_blend_matches_the_loss_backward_launch(gated):
         for a, b in zip(got[0], ref[0]):
             scale = float(b.abs().max()) + 1e-30
             assert float((a - b).abs().max()) <= 2e-5 * scale, "gradient with the loss gradient computed inside the blend"
+
+
+def test_loss_gradient_in_the_blend_on_a_frame_with_no_instance():
+    """A camera that sees nothing: R == 0, no blend launch -- the deferred loss value must still be assembled (egs_launch_loss_finish) and
+    every gradient is zero, as with the separate loss-backward launch."""
+    from egogaussian_amd.scene_synth import make_scene, make_camera, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.fused import l1_ssim_loss
+    N, H, W = 2000, 64, 96
+    scene = make_scene(N, H, W, 0)
+    cam = make_camera(0, H, W, device=DEV)
+    bg = torch.tensor([0.3, 0.1, 0.2], device=DEV)
+    gt = torch.rand((3, H, W), generator=torch.Generator().manual_seed(1)).to(DEV)
+    vals = []
+    for mode in (False, True):
+        pc = SynthGaussians(scene, device=DEV)
+        with torch.no_grad():
+            pc._xyz += 1.0e4                                             # far outside every frustum
+        out = render(cam, pc, Pipe, bg)
+        assert int(out["radii"].max()) == 0
+        run = torch.zeros(1, device=DEV)
+        loss = l1_ssim_loss(out["render"], gt, 0.2, running_sum=run, defer_value=True, raster_prologue=True, raster_lossgrad=mode)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert all(float(p.grad.abs().max()) == 0.0 for p in pc.parameters() if p.grad is not None)
+        vals.append((float(loss.detach()), float(run)))
+    assert vals[0] == vals[1] and vals[0][0] > 0 and vals[0][0] == vals[0][1]
 
 
 def test_graphed_step_with_and_without_loss_gradient_in_the_blend():
