@@ -103,7 +103,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos, geom,
             ctx.num_rendered, binning, img, alpha, rs.debug, ctx.activation_flags, sh_rest if split else None, ctx.densify_stats, ctx.guard,
-            ctx.sink, ctx.prologue_scratch, ctx.object_rotation, grad_mask, None if ctx.loss_grad is None else ctx.loss_grad[0])
+            ctx.sink, ctx.prologue_scratch, ctx.object_rotation, grad_mask, loss_grad=None if ctx.loss_grad is None else ctx.loss_grad[0])
         ctx.prologue_scratch = None
         ctx.loss_grad = None
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = grads[:8]
