@@ -696,7 +696,8 @@ def main():
                 pairs += ls["pairs_Q"]; visits += ls["visits"]
                 list_mean.append(ls["tile_list_len_mean"]); list_max.append(ls["tile_list_len_max"])
         n_s = len(range(0, n_used, max(1, n_used // 4)))
-        return dict(elapsed=elapsed, stages=stages, stage_timing=stage_timing, loss=loss_acc.item(), psnr_end=psnr_end, psnr_start=psnr_start,
+        return dict(lg_in_blend=bool(graphed is not None and getattr(graphed, "loss_grad_in_blend", False)),
+                    elapsed=elapsed, stages=stages, stage_timing=stage_timing, loss=loss_acc.item(), psnr_end=psnr_end, psnr_start=psnr_start,
                     R_mean=float(r_sum[0]) / max(r_sum[1], 1), kept_ratio=kept / max(rect, 1), pairs=pairs / n_s, visits=visits / n_s,
                     list_mean=float(np.mean(list_mean)), list_max=int(max(list_max)),
                     use_graph=use_graph, checksum=checksum, overflow=overflow, pc=pc, cams=cams, spr=spr, host_us=host_us, t_timed_start=t_timed_start, reps=reps,
@@ -774,8 +775,15 @@ def main():
     replay_us = None
     if budget and replay_kernel and head["use_graph"] and key == "500000@960x540":
         replay_us = next((v for k_, v in budget["kernels_us"].items() if replay_kernel in k_), None)     # (the trace may hold mangled names)
+    lg_bytes = 0
     if replay_us:
         d = dict(d); d["ms_per_launch_eager_events"] = d["ms_per_launch"]; d["ms_per_launch"] = round(replay_us * 1e-3, 5)
+        if dominant == "render_backward" and head.get("lg_in_blend"):
+            # the replayed step's blend also does the image loss's backward (no launch of its own, ABI 5): what that kernel had to read -- three
+            # derivative maps, image, ground truth: 20 B per pixel-channel -- is this launch's work now (the eager pass behind `stages` keeps the
+            # loss-backward launch, so its render_backward row is the blend alone)
+            lg_bytes = 20 * 3 * npix
+            d["alg_MB"] = round(d["alg_MB"] + lg_bytes / 1e6, 2)
         d["alg_GBps"] = round(d["alg_MB"] * 1e6 / (replay_us * 1e-6) / 1e9, 1)
     t_dom = d["ms_per_launch"] * 1e-3
     issue_frac = None
@@ -796,8 +804,10 @@ def main():
                 "pairs_Q": int(head["pairs"]), "visits": int(head["visits"]), "lanes_kept_per_visit": round(head["pairs"] / max(head["visits"], 1), 2),
                 "pairs_per_s_G": pair_rows,
                 "ms_per_launch": d["ms_per_launch"], "alg_bytes_per_launch": int(d["alg_MB"] * 1e6),
-                **({"alg_bytes_per_launch_survey_8d": int(84 * R_kept + 32 * npix),
-                    "frac_survey_8d": round((84 * R_kept + 32 * npix) / t_dom / 1e9 / HBM_PEAK_GBS, 5),
+                **({"alg_bytes_loss_gradient": lg_bytes, "alg_bytes_loss_gradient_note": "included in alg_bytes_per_launch: the replayed blend computes dL/dimage itself "
+                    "(20 B per pixel-channel of maps, image and ground truth); without it the figure is the blend's own 92 B per instance + 32 B per pixel"} if lg_bytes else {}),
+                **({"alg_bytes_per_launch_survey_8d": int(84 * R_kept + 32 * npix + lg_bytes),
+                    "frac_survey_8d": round((84 * R_kept + 32 * npix + lg_bytes) / t_dom / 1e9 / HBM_PEAK_GBS, 5),
                     "alg_bytes_note": "alg_bytes_per_launch prices an instance at 92 B (4 id + 48 record as this library packs it + 40 accumulate), "
                                       "SURVEY.md 8d at 84 B (44 list re-read + 40 accumulate); both + 32 B per pixel"} if dominant == "render_backward" else {}),
                 "timing": (f"rocprofv3 --kernel-trace of the graph-replayed step, same kernel sources (profiles/graph_step_budget.json: {budget['steps']} steps); "
