@@ -93,6 +93,12 @@ def set_tile_culling(on):
     return bool(_lib.load().egs_debug_set_tile_culling(int(bool(on))))
 
 
+def set_sort_in_blend(on):
+    """The per-tile sort inside the forward blend's launch (include/egs_raster.h, egs_debug_set_sort_in_blend): on by default; off = the
+    separate k_tile_sort launch.  Returns the previous setting."""
+    return bool(_lib.load().egs_debug_set_sort_in_blend(int(bool(on))))
+
+
 def set_fused_count(on):
     """The count pass of the tile bucketing inside the preprocess launch (include/egs_raster.h, egs_debug_set_fused_count): on by default
     whenever a forward has a placement buffer; off = the separate k_bin_count launch.  Returns the previous setting."""

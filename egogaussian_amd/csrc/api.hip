@@ -177,6 +177,12 @@ static bool fused_count_on() {
     if (g_fused_count < 0) { const char* e = getenv("EGS_NO_FUSED_COUNT"); g_fused_count = (e && e[0] && e[0] != '0') ? 0 : 1; }
     return g_fused_count != 0;
 }
+static int g_sort_in_blend = -1;     // -1: not decided yet (EGS_NO_SORT_IN_BLEND=1 in the environment turns it off)
+static bool sort_in_blend_on() {
+    if (g_sort_in_blend < 0) { const char* e = getenv("EGS_NO_SORT_IN_BLEND"); g_sort_in_blend = (e && e[0] && e[0] != '0') ? 0 : 1; }
+    return g_sort_in_blend != 0;
+}
+int egs_debug_set_sort_in_blend(int on) { const int old = sort_in_blend_on() ? 1 : 0; g_sort_in_blend = on ? 1 : 0; return old; }
 int egs_forward_fuses_count(int P, int width, int height) { return (fused_count_on() && egs_can_fuse_count(P, width, height)) ? 1 : 0; }
 int egs_debug_set_fused_count(int on) { const int old = fused_count_on() ? 1 : 0; g_fused_count = on ? 1 : 0; return old; }
 int egs_debug_force_ballot_rank(int on) { const int old = egs_force_ballot_rank; egs_force_ballot_rank = on ? 1 : 0; return old; }
@@ -382,10 +388,13 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     if (capacity > 0) {                                              // speculative: sized by the caller's guess
         EgsBinPtrs b = b_spec;
         EgsImgPtrs im = im_spec;
-        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, overflow_flag, 1, fuse ? 1 : 0, s, 0));
-        dirty_guard.p = nullptr;
+        // the per-tile sort inside the forward blend's launch (render_fwd.hip SORT): egs_launch_binning then makes no sort launch and says what the
+        // blend needs; with the sums of a fused count pass to clear, a failure before the blend is enqueued leaves them dirty (dirty_guard)
+        EgsSortArgs sort_args = {};
+        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, overflow_flag, 1, fuse ? 1 : 0, sort_in_blend_on() ? &sort_args : nullptr, s, 0));
         egs_prof_start(EGS_K_RENDER_FWD, s);
-        EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, placement ? 1 : 0, s));
+        EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, placement ? 1 : 0, &sort_args, s));
+        dirty_guard.p = nullptr;
         egs_prof_stop(EGS_K_RENDER_FWD, s);
         // a caller that checks LATER (egs_forward_enqueue outside a graph: the eager loop without a host wait per forward) also gets the
         // overflow word -- [0] clipped, [1] instances bucketed -- behind the counts, once the chain that writes it has run
@@ -454,10 +463,11 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
     EgsGeomPtrs g = geom_ptrs(const_cast<void*>(geom_buffer), P);
     EgsBinPtrs b = bin_ptrs(binning_buffer, P, R, width, height);
     EgsImgPtrs im = img_ptrs(image_buffer, width, height);
-    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, nullptr, nullptr, 0, 0, s, debug));
+    EgsSortArgs sort_args = {};
+    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, nullptr, nullptr, 0, 0, (sort_in_blend_on() && !debug) ? &sort_args : nullptr, s, debug));
     const uint32_t* point_list = b.point_list;
     egs_prof_start(EGS_K_RENDER_FWD, s);
-    EGS_TRY(egs_launch_render_forward(width, height, background, g, point_list, im, out_color, out_depth, out_alpha, 0, s));
+    EGS_TRY(egs_launch_render_forward(width, height, background, g, point_list, im, out_color, out_depth, out_alpha, 0, &sort_args, s));
     egs_prof_stop(EGS_K_RENDER_FWD, s);
     EGS_SYNC_IF_DEBUG(s);
     return 0;

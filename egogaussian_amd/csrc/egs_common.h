@@ -182,9 +182,16 @@ hipError_t egs_launch_mark_visible(int P, const float* means3D, const float* vie
 hipError_t egs_launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, int inclusive, uint32_t* scratch,
                                uint64_t* total, hipStream_t s);
 // sums_zeroed: b.chunk_sum was cleared by this frame's preprocess launch (else a zero-fill launch comes first)
+// What the per-tile sort needs (tile_sort.h): kernel argument of k_tile_sort, and of the forward blend when it sorts its tiles itself
+struct EgsSortArgs {
+    int n_tiles; uint32_t stride; const uint32_t* table_scanned; const uint64_t* total; uint64_t* running_max; uint32_t* overflow_flag; int solo;
+    uint32_t R /* capacity */; int index_passes; uint64_t* pairs; uint64_t* scratch; uint32_t* point_list; uint2* ranges;
+    uint32_t* zero_after; uint32_t zero_after_n; int rank_atomic /* launcher -> launcher: the LDS lane-order property holds (wave_digit_rank) */;
+};
 // counted: b.table and b.chunk_sum were filled by egs_launch_preprocess_count (the count pass is not launched)
+// sort_in_blend (may be NULL): see binning.hip
 hipError_t egs_launch_binning(int P, int64_t R, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
-                              uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, int counted, hipStream_t s, int debug);
+                              uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, int counted, EgsSortArgs* sort_in_blend, hipStream_t s, int debug);
 // k_preprocess + the count pass of the tile bucketing in ONE launch (preprocess.hip); b.chunk_sum must be ZERO (see EgsBinPtrs).
 // -> false when the launch geometry does not allow it (fewer than four groups per round: very large images)
 bool egs_can_fuse_count(int P, int W, int H);
@@ -193,9 +200,10 @@ hipError_t egs_launch_preprocess_count(int P, int D, int M, const float* means3D
                                        const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, EgsBinPtrs b,
                                        const int32_t* active_count, const EgsImgPtrs* place, EgsObjRot rot, hipStream_t s);
 // placed: im.fwd_order holds this frame's placement (the preprocess launch carried the ordering job); else the static mapping
+// sort (may be NULL, or table_scanned == NULL in it): the blend sorts every tile's bucket itself first (egs_launch_binning made no sort launch)
 hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                      EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha, int placed,
-                                     hipStream_t s);
+                                     const EgsSortArgs* sort, hipStream_t s);
 // The backward blend, and what it needs in place first (tile order, cleared accumulator; `tick`, may be NULL: the per-step bookkeeping
 // of an optimizer fused into this backward) as a launch of its own -- or carried by egs_l1_ssim_backward_ex (backward_prologue.h).
 // block_hot (may be NULL: every replica line is cleared): the per-workgroup hot counts of the frame's preprocess -- only the replica lines in use are cleared

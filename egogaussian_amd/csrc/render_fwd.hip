@@ -27,6 +27,7 @@
 // keep/skip decisions.
 #include "egs_common.h"
 #include "blend_common.h"
+#include "tile_sort.h"            // SORT instantiations: the workgroup sorts its tile's bucket before it blends it
 #include "backward_prologue.h"
 #include "blend_instrument.h"      // measurement / ablation hooks: all empty in the product build
 
@@ -43,15 +44,24 @@ namespace {
 
 // DA = false (ABI 4: out_depth == out_alpha == NULL): the caller reads the colour image only -- the training step's loss -- so the depth and
 // alpha sums (two of the ~26 vector instructions per visit) and their two planes are left out.
-template <bool DA>
-__global__ __launch_bounds__(256) void k_render_forward(
+// SORT (RA: the fast LDS ranking, tile_sort.h): the per-tile depth sort runs HERE, in the workgroup that is about to blend the tile -- a tile's
+// bucket is private to it, so the sort needs no launch of its own (k_tile_sort, ~4.5 us of ramp and drain per frame); the sorted ids go to
+// point_list as before (the backward reads them) and are read back through the CU's L1.  The sort's exchange buffer and bucket counters
+// (18.5 KB) and the blend's staged records (12 KB) share the LDS.
+template <bool DA, bool SORT, bool RA>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_render_forward(
     int W, int H, int gx, int n_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ quad_work, uint32_t* __restrict__ quad_pairs,
-    const uint32_t* __restrict__ order, uint32_t* __restrict__ cost_hint) {
-    __shared__ float4 lds[4][64 * EGS_SPLAT_REC_F4];
+    const uint32_t* __restrict__ order, uint32_t* __restrict__ cost_hint, const EgsSortArgs sortA) {
+    constexpr int SM_BYTES = SORT ? (TS_SMALL_CAP * 8 + 2 * 512 * 4 + 64) : 4 * 64 * EGS_SPLAT_REC_F4 * 16;
+    static_assert(SM_BYTES >= 4 * 64 * EGS_SPLAT_REC_F4 * 16, "the staged records fit");
+    __shared__ __attribute__((aligned(16))) uint64_t smem64[SM_BYTES / 8];
+    float4 (*lds)[64 * EGS_SPLAT_REC_F4] = reinterpret_cast<float4 (*)[64 * EGS_SPLAT_REC_F4]>(smem64);
     __shared__ uint32_t quad_claimed;
+    if (SORT && sortA.zero_after)         // (what k_tile_sort's first launch also did: the fused count pass's chunk sums are consumed; every workgroup of the grid)
+        for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < sortA.zero_after_n; k += gridDim.x * 256u) sortA.zero_after[k] = 0u;
     const unsigned lane = threadIdx.x & 63, wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave id, kept scalar
     // Placement.  Without a cost hint: workgroup b takes tile egs_tile_of_block(b) and wave w quadrant w.  With one (`order`: the
     // words the ordering job made of the hint, backward_prologue.h): the tile and the quadrant -> SIMD assignment come from there, so
@@ -81,6 +91,12 @@ __global__ __launch_bounds__(256) void k_render_forward(
         tile = egs_tile_of_block(blockIdx.x, n_tiles);
         if (tile < 0) return;
     }
+    uint2 sorted_range = make_uint2(0u, 0u);
+    if (SORT) {
+        tile_sort_body<RA, 4, TS_SMALL_CAP, 0u>(sortA, tile, smem64, reinterpret_cast<uint32_t*>(smem64 + TS_SMALL_CAP),
+                                                reinterpret_cast<uint32_t*>(smem64 + TS_SMALL_CAP) + 2 * 512, &sorted_range);
+        __syncthreads();                                              // the ids are in point_list; the LDS is the blend's from here on
+    }
     float4* my = lds[wv];
     const unsigned my_addr = (unsigned)(uintptr_t)my;             // LDS byte offset of the wave's slice (low half of the generic address)
     const int qx0 = (tile % gx) * EGS_TILE + (int)(q & 1) * 8, qy0 = (tile / gx) * EGS_TILE + (int)(q >> 1) * 8;
@@ -93,9 +109,9 @@ __global__ __launch_bounds__(256) void k_render_forward(
     const float pxf = (float)px, pyf = (float)py;
     const uint32_t qx1 = (uint32_t)min(qx0 + 7, W - 1), qy1 = (uint32_t)min(qy0 + 7, H - 1);
 
-    const uint2 range = ranges[tile];
+    const uint2 range = SORT ? sorted_range : ranges[tile];
     const uint32_t n = range.y - range.x;
-    const uint32_t* list = point_list + range.x;
+    const uint32_t* list = (SORT ? (const uint32_t*)sortA.point_list : point_list) + range.x;      // (SORT: not through the read-only argument -- this workgroup has just written them)
 
     // Tl: live transmittance, forced to 0 once the pixel has stopped (so later splats add nothing);
     // Tf: the value final_T reports.  Invariant while live: Tl == Tf >= 1e-4.
@@ -214,14 +230,20 @@ __global__ __launch_bounds__(256) void k_render_forward(
 
 hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                      EgsImgPtrs im, float* out_color, float* out_depth, float* out_alpha, int placed,
-                                     hipStream_t s) {
+                                     const EgsSortArgs* sort, hipStream_t s) {
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
     if (n_tiles == 0) return hipSuccess;
-#define EGS_FWD_LAUNCH(DA) hipLaunchKernelGGL(k_render_forward<DA>, dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles, \
+    EgsSortArgs sa = {};
+    const bool do_sort = sort && sort->table_scanned;
+    if (do_sort) sa = *sort;
+#define EGS_FWD_LAUNCH(DA, SO, RA) hipLaunchKernelGGL((k_render_forward<DA, SO, RA>), dim3(egs_blocks_for_tiles(n_tiles)), dim3(256), 0, s, W, H, gx, n_tiles, \
                        im.ranges, point_list, g.rec, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib, im.quad_work, im.quad_pairs, \
-                       placed ? im.fwd_order : (const uint32_t*)nullptr, im.fwd_cost)
-    if (out_depth && out_alpha) EGS_FWD_LAUNCH(true); else EGS_FWD_LAUNCH(false);
+                       placed ? im.fwd_order : (const uint32_t*)nullptr, im.fwd_cost, sa)
+    const bool da = out_depth && out_alpha;
+    if (!do_sort) { if (da) EGS_FWD_LAUNCH(true, false, false); else EGS_FWD_LAUNCH(false, false, false); }
+    else if (sa.rank_atomic) { if (da) EGS_FWD_LAUNCH(true, true, true); else EGS_FWD_LAUNCH(false, true, true); }
+    else { if (da) EGS_FWD_LAUNCH(true, true, false); else EGS_FWD_LAUNCH(false, true, false); }
 #undef EGS_FWD_LAUNCH
     return hipGetLastError();
 }

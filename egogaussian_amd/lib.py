@@ -114,6 +114,7 @@ SIGNATURES = {
     "egs_debug_set_tile_culling": (C.c_int, [i32]),
     "egs_debug_set_fused_count": (C.c_int, [i32]),
     "egs_forward_fuses_count": (C.c_int, [i32, i32, i32]),
+    "egs_debug_set_sort_in_blend": (C.c_int, [i32]),
     "egs_profile_begin": (C.c_int, [i32]),
     "egs_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "egs_profile_stage_name": (C.c_char_p, [i32]),

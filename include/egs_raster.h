@@ -543,7 +543,11 @@ int egs_debug_set_tile_culling(int on);
  * buffer above); 0: the two launches of ABI <= 4.  Lists, images and gradients are the same either way (tests/test_gpu_parity.py).
  * -> the previous setting.  EGS_NO_FUSED_COUNT=1 in the environment starts a process with it off. */
 int egs_debug_set_fused_count(int on);
-int egs_forward_fuses_count(int P, int width, int height);      /* 1: a forward of this size given a placement buffer runs the fused pass */
+int egs_forward_fuses_count(int P, int width, int height);
+/* 1 (default): the forward blend's workgroups sort their own tile's bucket (no per-tile sort launch; whenever one sort instantiation
+ * suffices: capacity <= 2048 x tiles); 0: the separate k_tile_sort launch(es).  Lists and outputs are the same either way.
+ * -> the previous setting.  EGS_NO_SORT_IN_BLEND=1 in the environment starts a process with it off. */
+int egs_debug_set_sort_in_blend(int on);      /* 1: a forward of this size given a placement buffer runs the fused pass */
 
 /* ---- optional per-stage timing with HIP events on the caller's stream (bench / profiling aid) ------
  * The only process-wide state in the library; off by default.  egs_profile_begin allocates an event pool and

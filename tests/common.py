@@ -73,6 +73,17 @@ def tile_culling(on):
 
 
 @contextlib.contextmanager
+def sort_in_blend(on):
+    """Run a block with the per-tile sort inside the forward blend's launch (on, the default) or as launches of its own."""
+    from egogaussian_amd import _C
+    old = _C.set_sort_in_blend(on)
+    try:
+        yield
+    finally:
+        _C.set_sort_in_blend(old)
+
+
+@contextlib.contextmanager
 def fused_count(on):
     """Run a block with the count pass of the bucketing inside the preprocess launch (on, the default with a placement buffer) or as its own launch."""
     from egogaussian_amd import _C

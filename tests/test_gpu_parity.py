@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import (make_inputs, seeded_grads, rel_err, outlier_fraction, tile_culling, fused_count, check_culled_lists, flip_pixels,
+from tests.common import (make_inputs, seeded_grads, rel_err, outlier_fraction, tile_culling, fused_count, sort_in_blend, check_culled_lists, flip_pixels,
                           check_grads_isolating_flips)
 
 pytestmark = pytest.mark.gpu
@@ -229,6 +229,37 @@ def test_fused_count_pass_changes_nothing(N, H, W, seed, mode, smul, cull):
             assert cur["R"] == res["R"] and np.array_equal(cur["rng"], res["rng"]) and np.array_equal(cur["pl"], res["pl"]), "fused count pass changed the lists"
             for x, y in zip(cur["planes"] + cur["geom"], res["planes"] + res["geom"]):
                 assert torch.equal(x, y), "fused count pass changed an output"
+
+
+@pytest.mark.parametrize("N,H,W,seed,mode,smul", [(20000, 270, 480, 5, "sh_cov", 2.0), (3001, 67, 131, 2, "rgb_sr", 1.0), (70000, 540, 960, 9, "sh_sr", 1.0),
+                                                  (1200, 33, 47, 1, "sh_cov", 6.0), (9000, 64, 64, 3, "rgb_sr", 8.0)])
+@pytest.mark.parametrize("cull", [False, True], ids=["reference-lists", "culled-lists"])
+def test_sort_inside_the_forward_blend_changes_nothing(N, H, W, seed, mode, smul, cull):
+    """The forward blend's workgroups sort their tile's bucket themselves (render_fwd.hip SORT; no k_tile_sort launch): ranges, lists and every
+    output plane must equal, bit for bit, what the separate sort launch produces -- including tiles beyond the register path's 1 792 entries
+    (the last case: 9 000 splats x 8 on 16 tiles) and the chain that clears the fused count pass's chunk sums."""
+    from egogaussian_amd import _C
+    dev = _dev()
+    d = make_inputs(N, H, W, seed, 0, mode, scale_mul=smul)
+    res = {}
+    with tile_culling(cull):
+        hip_forward(d, dev)
+        for inside in (False, True, True):
+            with sort_in_blend(inside):
+                g, out = hip_forward(d, dev)
+            iv = _C.image_views(out[7], W, H); bv = _C.binning_views(out[6], N, out[0], W, H, _C.stats["capacity"])
+            rng = iv["ranges"].cpu().numpy().view(np.uint32).astype(np.int64)
+            n_list = int((rng[:, 1] - rng[:, 0]).sum())
+            cur = dict(R=out[0], planes=[t.clone() for t in out[1:5]] + [iv["final_T"].clone(), iv["n_contrib"].clone()], rng=rng,
+                       pl=bv["point_list"].cpu().numpy().view(np.uint32)[:n_list].copy(), longest=int((rng[:, 1] - rng[:, 0]).max()))
+            if not inside:
+                res = cur
+                continue
+            assert cur["R"] == res["R"] and np.array_equal(cur["rng"], res["rng"]) and np.array_equal(cur["pl"], res["pl"]), "sort inside the blend changed the lists"
+            for x, y in zip(cur["planes"], res["planes"]):
+                assert torch.equal(x, y), "sort inside the blend changed an output"
+    if smul == 8.0:
+        assert res["longest"] > 1792, "this case is meant to take the slab path"
 
 
 def test_placement_buffer_first_seen_dirty():
