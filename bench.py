@@ -52,7 +52,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 SQ_FILE = os.path.join(ROOT, "profiles", "sq_counters.json")
 
 
-def algorithmic_bytes(stage, N, R, npix, sh_coeffs=1, fused_count=False):
+def algorithmic_bytes(stage, N, R, npix, sh_coeffs=1, fused_count=False, sort_in_blend=False):
     """Bytes one launch of `stage` must move at minimum: per-unit figures x units.  R = instances the
     launch actually processes (after tile culling).  fused_count (ABI 5): the count walk of the bucketing runs inside the preprocess
     launch on what that launch holds in registers -- the `preprocess` events then cover it, `tile_bucket` is the scan and the scatter walk."""
@@ -60,7 +60,7 @@ def algorithmic_bytes(stage, N, R, npix, sh_coeffs=1, fused_count=False):
         "preprocess": (44 + 12 * sh_coeffs) * N + 48 * N,   # xyz 12 + log-scale 12 + quaternion 16 + opacity logit 4 + sh 12/coefficient in; record 48 out
         "tile_bucket": (1 if fused_count else 2) * (16 + 32) * N + 8 * R,      # walk(s) over (tiles_touched, rect, depth | ellipse) per Gaussian; one pair out per instance
         "tile_sort": 8 * R + 4 * R,                    # pair in, index out; the radix passes stay in registers/LDS
-        "render_forward": 4 * R + 48 * R + 28 * npix,  # id + record per instance; 7 floats per pixel out
+        "render_forward": 4 * R + 48 * R + 28 * npix + (12 * R if sort_in_blend else 0),  # id + record per instance; 7 floats per pixel out (+ the per-tile sort's pair in / index out when it runs inside this launch)
         "render_backward": 4 * R + 48 * R + 40 * R + 32 * npix,   # + one 40-byte accumulate per instance; 8 floats/pixel in
         "preprocess_backward": 48 * N + (44 + 12 * sh_coeffs) * N + 32 * N + (68 + 12 * sh_coeffs) * N,  # accumulator + inputs + record head in; grads out (xyz, mean2D, scale, quat, sh, colour, opacity)
     }[stage]
@@ -111,7 +111,7 @@ def stage_table(stages, N, R_kept, npix, sh_coeffs=1, hw=None):
         if n == 0:
             continue
         per = ms / n
-        ab = algorithmic_bytes(name, N, R_kept, npix, sh_coeffs, fused_count=bool(hw) and _fuses_count(N, hw))
+        ab = algorithmic_bytes(name, N, R_kept, npix, sh_coeffs, fused_count=bool(hw) and _fuses_count(N, hw), sort_in_blend="tile_sort" not in stages or not stages["tile_sort"][1])
         rows[name] = {"ms_per_launch": round(per, 4), "launches": n, "alg_MB": round(ab / 1e6, 2),
                       "alg_GBps": round(ab / (per * 1e-3) / 1e9, 1), "frac_hbm": round(ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     return rows
@@ -747,7 +747,7 @@ def main():
         if n == 0:
             continue
         per = ms / n
-        ab = algorithmic_bytes(name, N, R_kept, npix, (D + 1) ** 2, fused_count=_fuses_count(N, (H, W)))
+        ab = algorithmic_bytes(name, N, R_kept, npix, (D + 1) ** 2, fused_count=_fuses_count(N, (H, W)), sort_in_blend="tile_sort" not in stages or not stages["tile_sort"][1])
         stage_rows[name] = {"ms_per_launch": round(per, 4), "launches": n, "alg_MB": round(ab / 1e6, 2),
                             "alg_GBps": round(ab / (per * 1e-3) / 1e9, 1), "frac_hbm": round(ab / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if dominant is None or per * n > stages[dominant][0]:

@@ -411,7 +411,6 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
         lds_rank_ok.store(fast);
     }
     if (egs_force_ballot_rank) fast = 0;
-    egs_prof_start(EGS_K_SORT, s);
     const int ip = (index_bits + TS_DBITS - 1) / TS_DBITS;
     // A launch costs ~4.5 us of GPU time even when every workgroup returns at once.  When the buffer holds on average at most 2048
     // instances per tile (R is the capacity: >= 1.25 x the rectangle count, itself ~1.5 x what survives culling) no tile is expected
@@ -425,9 +424,9 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
         // sort -- the overflow word, the running maximum, clearing the chunk sums -- travels in `sort_out` to that launch.
         sa.rank_atomic = fast;
         *sort_in_blend = sa;
-        egs_prof_stop(EGS_K_SORT, s);
-        return hipGetLastError();
+        return hipGetLastError();                                     // (no EGS_K_SORT stage: the sort's time is part of the forward blend's)
     }
+    egs_prof_start(EGS_K_SORT, s);
     if (sort_in_blend) sort_in_blend->table_scanned = nullptr;        // (not taken: the forward reads the lists these launches leave)
     EgsSortArgs sa2 = sa; sa2.solo = 0;
     if (fast) {
