@@ -16,7 +16,7 @@ from tests.test_gpu_parity import hip_forward, hip_backward, oracle_forward, TOL
 from egogaussian_amd import _C                                                                                       # noqa: E402
 
 
-def run_draws(seed=0, budget_s=None, n_draws=None, dev=None, verbose=False):
+def run_draws(seed=0, budget_s=None, n_draws=None, dev=None, verbose=False, keep_going=False):
     """Random draws until `n_draws` are done or `budget_s` seconds have passed.  -> (cases run, worst max-relative gradient errors)."""
     rng = np.random.default_rng(int(seed))
     dev = torch.device("cuda:0") if dev is None else dev
@@ -122,11 +122,19 @@ def run_draws(seed=0, budget_s=None, n_draws=None, dev=None, verbose=False):
                     e64 = np.abs(hh - a64).reshape(a32.shape[0], -1).max(1) / sc
                     e32[near[near < a32.shape[0]]] = 0.0                 # (rows near a flipped pixel have their own bound, checked above)
                     rows = np.nonzero(e32 >= TOL)[0]
-                    bar = np.where(np.asarray(st["radii"])[rows] >= 36, 3.0 * TOL, TOL)
+                    # frame-filling splats: 3 x the bar, or -- when the float32 ORACLE itself is further than that from the float64 one (seed 777123,
+                    # draw 129: radius 300 px on 412x270, 111 k pixel terms: oracle32 18145.8, HIP 18149.1, oracle64 18155.9) -- no worse than
+                    # 1.5 x the float32 oracle's own distance from the float64 result
+                    o_err = np.abs(a32 - a64).reshape(a32.shape[0], -1).max(1) / sc
+                    bar = np.where(np.asarray(st["radii"])[rows] >= 36, np.maximum(3.0 * TOL, 1.5 * o_err[rows]), TOL)
                     if (e64[rows] >= bar).any():
-                        raise first
+                        if not keep_going:
+                            raise first
+                        worst.setdefault("_failed_draws", []).append(f"draw {n_cases}: {str(first)[:420]}")     # (a long run reports them all; pytest's slice stops here)
+                        break
                     far = max(far, float(np.where(e32 >= TOL, 0.0, e32).max()))
-                worst["_arbitrated_by_f64_oracle"] = worst.get("_arbitrated_by_f64_oracle", 0) + 1
+                else:
+                    worst["_arbitrated_by_f64_oracle"] = worst.get("_arbitrated_by_f64_oracle", 0) + 1
             worst["_far_from_flips"] = max(worst.get("_far_from_flips", 0.0), far)
         n_cases += 1
         worst["_strict_draws"] = worst.get("_strict_draws", 0) + (1 if strict else 0)
@@ -135,9 +143,12 @@ def run_draws(seed=0, budget_s=None, n_draws=None, dev=None, verbose=False):
 
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    n_cases, worst = run_draws(int(sys.argv[2]) if len(sys.argv) > 2 else 0, budget_s=budget)
+    n_cases, worst = run_draws(int(sys.argv[2]) if len(sys.argv) > 2 else 0, budget_s=budget, keep_going=True)
+    failed = worst.pop("_failed_draws", [])
     strict = worst.pop("_strict_draws", 0)
     arb = worst.pop("_arbitrated_by_f64_oracle", 0)
-    print(f"{n_cases} random cases passed in {budget:.0f} s, {strict} of them with every image and gradient within {TOL:g} outright (no threshold flip), "
+    for f in failed:
+        print("MISSED THE BAR (also against the float64 oracle):", f)
+    print(f"{n_cases} random cases run in {budget:.0f} s, {len(failed)} of them missed the gradient bar (listed above), {strict} of them with every image and gradient within {TOL:g} outright (no threshold flip), "
           f"{arb} after the float64 oracle arbitrated a row the float32 oracle's own accumulation noise had put over the bar; "
           "worst max-relative gradient errors: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
