@@ -395,7 +395,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     g_alpha = _opt(_f32c(dL_dout_alpha, "dL_dout_alpha"))
     sh_rest = _opt(_f32c(sh_rest, "sh_rest"))
     M = 0 if sh is None else sh.shape[1] + (0 if sh_rest is None else sh_rest.shape[1])
-    if COLORS_ONLY_BACKWARD and P != 0 and grad_mask == GRAD_COLORS and colors is not None and sink is None and densify_stats is None and object_rotation is None:
+    if COLORS_ONLY_BACKWARD and P != 0 and grad_mask == GRAD_COLORS and colors is not None and sink is None and densify_stats is None and object_rotation is None \
+            and loss_grad is None:          # (a loss gradient computed in the blend needs the full path: dL_dout_color is uninitialised then)
         with _hip.device_ctx(dev):
             dcolors = torch.empty((P, 3), device=dev, dtype=torch.float32)
             scratch = prologue_scratch if prologue_scratch is not None else torch.empty((L.egs_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)

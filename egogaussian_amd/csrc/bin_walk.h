@@ -121,7 +121,7 @@ __device__ __forceinline__ void bin_park_group(const BinRound& L, unsigned w, un
         // faint -- the box is a fraction of the rectangle, or empty (opacity < 1/255: nothing to walk): 4.06 M rectangle slots
         // -> 1.24 M there.  `tiles_touched` and R stay the reference's; with culling off the full rectangle is walked.
         const uint32_t bx = __float_as_uint(r2.z), by = __float_as_uint(r2.w);
-        const uint32_t px0 = bx & EGS_BOX_MASK, px1 = (bx >> 16) & EGS_BOX_MASK, py0 = by & EGS_BOX_MASK, py1 = by >> 16;
+        const uint32_t px0 = bx & EGS_BOX_MASK, px1 = (bx >> 16) & EGS_BOX_MASK, py0 = by & EGS_BOX_MASK, py1 = (by >> 16) & EGS_BOX_MASK;
         const uint32_t x0 = max(rc_l.x & 0xffffu, px0 / EGS_TILE), x1 = min(rc_l.x >> 16, px1 / EGS_TILE + 1u);
         const uint32_t y0 = max(rc_l.y & 0xffffu, py0 / EGS_TILE), y1 = min(rc_l.y >> 16, py1 / EGS_TILE + 1u);
         const bool some = px0 <= px1 && py0 <= py1 && x0 < x1 && y0 < y1;

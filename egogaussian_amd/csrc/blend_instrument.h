@@ -106,7 +106,7 @@
 #endif
 #if EGS_ABL == 7                       // no accumulation at all for splats whose alpha >= 1/255 box covers EGS_ABL7_AREA pixels or more
 #define EGS_BWD_ABL7(C2) { const uint32_t bx_ = __float_as_uint((C2).z), by_ = __float_as_uint((C2).w);                          \
-                           if ((((bx_ >> 16) & 0x7fffu) - (bx_ & 0x7fffu) + 1u) * ((by_ >> 16) - (by_ & 0x7fffu) + 1u) >= (uint32_t)(EGS_ABL7_AREA)) continue; }
+                           if ((((bx_ >> 16) & 0x7fffu) - (bx_ & 0x7fffu) + 1u) * (((by_ >> 16) & 0x7fffu) - (by_ & 0x7fffu) + 1u) >= (uint32_t)(EGS_ABL7_AREA)) continue; }
 #else
 #define EGS_BWD_ABL7(C2)
 #endif

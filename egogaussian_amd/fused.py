@@ -191,7 +191,10 @@ class _L1SSIM(torch.autograd.Function):
             if d:
                 lg.deferred_partial_sums, lg.deferred_loss = d[0].data_ptr(), d[1].data_ptr()
                 lg.loss_running_sum = d[2].data_ptr() if d[2] is not None else None
-            ctx.raster_node.loss_grad = (lg, (img, gt, maps, gate, g, d))
+            # (the third element is how the rasterizer's backward recognises THIS tensor: anything autograd put between the two nodes -- a second
+            # consumer of the image whose gradient was added, a hook that returned another tensor -- arrives as a different one and is refused
+            # there instead of being silently dropped)
+            ctx.raster_node.loss_grad = (lg, (img, gt, maps, gate, g, d), (dimg.data_ptr(), dimg._version))
             return dimg, None, None, None, None, None, None, None
         side = None
         if ctx.raster_node is not None:

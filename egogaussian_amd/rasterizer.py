@@ -93,6 +93,17 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_depth = torch.empty(0, device=dev)
         if grad_alpha is None:
             grad_alpha = torch.empty(0, device=dev)
+        if ctx.loss_grad is not None:
+            # the loss in front handed over NO gradient tensor (fused.l1_ssim_loss(raster_lossgrad=True): the blend computes dL/dcolour itself and
+            # `grad_color` is uninitialised memory nobody may read).  That is only the whole gradient of the image when nothing else contributed
+            # to it: a second loss term on the image, a hook that rewrote the gradient, or accumulation would arrive here as ANOTHER tensor (or
+            # a modified one) -- and would be dropped.  Refuse instead.
+            ptr, version = ctx.loss_grad[2]
+            if grad_color.data_ptr() != ptr or grad_color._version != version:
+                ctx.loss_grad = None
+                raise RuntimeError("l1_ssim_loss(raster_lossgrad=True): the rendered image has another gradient contribution (a second consumer, or a "
+                                   "hook that changed the gradient) -- the in-blend loss gradient would drop it.  Use raster_lossgrad=False "
+                                   "(GraphedTrainStep(loss_grad_in_blend=False)), or express a per-pixel mask as grad_gate=")
         split = sh_rest.numel() != 0
         # autograd's view of who reads which gradient, for the library (include/egs_raster.h EGS_GRAD_*): inputs order of forward()
         need = ctx.needs_input_grad

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tests.common import flip_pixels, check_grads_isolating_flips, make_inputs, seeded_grads, rel_err, outlier_fraction, tile_culling, check_culled_lists   # noqa: E402
+from tests.common import flip_pixels, check_grads_isolating_flips, check_images_isolating_flips, make_inputs, seeded_grads, rel_err, outlier_fraction, tile_culling, check_culled_lists   # noqa: E402
 from tests.test_gpu_parity import hip_forward, hip_backward, oracle_forward, TOL                                     # noqa: E402
 from egogaussian_amd import _C                                                                                       # noqa: E402
 
@@ -36,6 +36,21 @@ def run_draws(seed=0, budget_s=None, n_draws=None, dev=None, verbose=False, keep
             print(tag, flush=True)
         d = make_inputs(N, H, W, int(rng.integers(0, 1000)), deg, mode, frame=frame, scale_mul=smul, opacity_shift=float(rng.choice([0.0, 2.0, -2.0])))
         d["sh_degree"] = active
+        try:
+            strict = _one_draw(d, N, H, W, cull, split, active, tag, dev, worst, keep_going, n_cases)
+        except AssertionError as err:
+            if not keep_going:
+                raise
+            worst.setdefault("_failed_draws", []).append(f"draw {n_cases}: {tag}: {str(err)[:420]}")     # (a long run reports them all; pytest's slice stops at the first)
+            strict = False
+        n_cases += 1
+        worst["_strict_draws"] = worst.get("_strict_draws", 0) + (1 if strict else 0)
+    return n_cases, worst
+
+
+def _one_draw(d, N, H, W, cull, split, active, tag, dev, worst, keep_going, n_cases):
+    """One draw of run_draws against the oracle; -> whether it met 1e-4 everywhere outright (no threshold flip)."""
+    if True:
         o, st = oracle_forward(d)
         with tile_culling(cull):
             if split:
@@ -58,17 +73,16 @@ def run_draws(seed=0, budget_s=None, n_draws=None, dev=None, verbose=False, keep
                     check_culled_lists(st, rngs, pl, H, W)
                 else:
                     assert np.array_equal(pl, st["point_list"]) and np.array_equal(rngs, st["ranges"]), tag
-            strict = True                                        # this draw meets the 1e-4 bar outright: no outlier anywhere (no threshold flip)
-            for name, hip, ora in (("colour", color, st["color"]), ("depth", depth, st["depth"]), ("alpha", alpha, st["alpha"])):
-                f = outlier_fraction(hip.cpu().numpy(), ora, TOL)
-                strict = strict and f == 0.0
-                assert f <= max(1e-3, 8.0 / hip.numel()), f"{tag}: {name} outliers {f}"
             # pixels on the other side of an alpha / transmittance threshold than the oracle's (v_exp_f32 vs glibc expf in the last place),
-            # found with a threshold far below the parity bar (tests/common.py)
+            # found with a threshold far below the parity bar AND proven: the float64 re-walk of such a pixel's chain must hold a threshold-adjacent
+            # pair, else flip_pixels fails the draw (tests/common.py flip_cause); every other pixel of every plane is held to 1e-4
             flip_px = np.zeros((H, W), dtype=bool)
             if R:
                 flip_px = flip_pixels(color.cpu().numpy(), iv["final_T"].cpu().numpy(), st, None if cull else iv["n_contrib"].cpu().numpy().view(np.uint32))
+            check_images_isolating_flips((("colour", color.cpu().numpy(), st["color"]), ("depth", depth.cpu().numpy(), st["depth"]), ("alpha", alpha.cpu().numpy(), st["alpha"])),
+                                         st, flip_px, TOL, what=tag)
             flips = int(flip_px.sum())
+            strict = flips == 0                                  # this draw meets the 1e-4 bar outright: no outlier anywhere (no threshold flip)
             grads = seeded_grads(H, W, 7)
             if split:
                 gc, gd, ga = [x.to(dev) for x in grads]
@@ -136,9 +150,7 @@ def run_draws(seed=0, budget_s=None, n_draws=None, dev=None, verbose=False, keep
                 else:
                     worst["_arbitrated_by_f64_oracle"] = worst.get("_arbitrated_by_f64_oracle", 0) + 1
             worst["_far_from_flips"] = max(worst.get("_far_from_flips", 0.0), far)
-        n_cases += 1
-        worst["_strict_draws"] = worst.get("_strict_draws", 0) + (1 if strict else 0)
-    return n_cases, worst
+        return strict
 
 
 if __name__ == "__main__":
@@ -152,3 +164,4 @@ if __name__ == "__main__":
     print(f"{n_cases} random cases run in {budget:.0f} s, {len(failed)} of them missed the gradient bar (listed above), {strict} of them with every image and gradient within {TOL:g} outright (no threshold flip), "
           f"{arb} after the float64 oracle arbitrated a row the float32 oracle's own accumulation noise had put over the bar; "
           "worst max-relative gradient errors: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+    sys.exit(1 if failed else 0)                   # (a run with missed draws must not exit 0)

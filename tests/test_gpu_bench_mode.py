@@ -84,16 +84,60 @@ def test_config_C_bench_mode_vs_oracle():
     grads_or = dict(xyz=gb["dL_dmeans3D"], f_dc=gb["dL_dsh"].reshape(N, 1, 3), opacity=leaf["opacity"].grad.numpy(),
                     scaling=leaf["scaling"].grad.numpy(), rotation=leaf["rotation"].grad.numpy())
     e_img, f_img = rel_err(img_hip, st["color"]), outlier_fraction(img_hip, st["color"], TOL)
-    from tests.common import flip_pixels, check_grads_isolating_flips
+    from tests.common import flip_pixels, check_grads_isolating_flips, check_images_isolating_flips
     # (the transmittance plane of the REPLAYED frame: the captured forward's image buffer, which every replay rewrites)
     final_T_hip = _C.image_views(_C.stats["image_buffer"], W, H)["final_T"].cpu().numpy()
     flip_px = flip_pixels(img_hip, final_T_hip, st)
     print(f"\n  config C, benched mode: R = {st['R']}, image max rel err {e_img:.2e}, pixels off by more than float noise: {int(flip_px.sum())}")
-    assert f_img <= 1e-4 and e_img < 2e-2
+    check_images_isolating_flips((("color", img_hip, st["color"]), ("final_T", final_T_hip, st["final_T"])), st, flip_px, TOL, what="config C benched mode")
     keys = list(grads_or)
+    over = {}
     rep, _, _ = check_grads_isolating_flips(keys, [grads_hip[k] for k in keys], {k: np.asarray(grads_or[k]) for k in keys}, st, flip_px, TOL,
-                                            what="config C benched mode", halo=10, far_frac=1e-4, far_cap=10.0)     # (each side's upstream gradient comes from ITS image through the 11x11 SSIM window, forward and backward: 10 pixels)
+                                            what="config C benched mode", halo=10, far_frac=1e-4, far_cap=10.0, over_rows=over)     # (each side's upstream gradient comes from ITS image through the 11x11 SSIM window, forward and backward: 10 pixels)
     print("    " + rep)
+    # The rows the call above let through between 1 and 10 x the bar are ACCOUNTED FOR, not excused by a comment.  The
+    # claim is "fp32 accumulation order": a splat that covers thousands of pixels sums that many signed terms, and two orders of the same
+    # float32 terms differ by that much.  Measured here: (i) the same replay is run three more times on the same parameters -- the atomics
+    # land in another order each time -- and (ii) the float64 oracle runs the same chain.  A row is accounted for when the HIP value is no
+    # further from the float64 result than the bar, than twice the float32 oracle's own distance from it, or than four times its own
+    # run-to-run spread; anything else fails.
+    if over:
+        runs = [grads_hip]
+        for _ in range(3):
+            with torch.no_grad():
+                for k, v in params.items():
+                    v.copy_(before[k].to(dev))
+            step(pack_frame(cams[1], gts[1]))
+            torch.cuda.synchronize()
+            runs.append({k: v.grad.detach().cpu().numpy() for k, v in params.items()})
+        leaf64 = {k: v.double().clone().requires_grad_(True) for k, v in before.items()}
+        cov64 = covariance_from_scaling_rotation(torch.exp(leaf64["scaling"]), 1.0, leaf64["rotation"])
+        opac64 = torch.sigmoid(leaf64["opacity"])
+        o64 = Oracle(np.float64, nthreads=min(64, os.cpu_count() or 8))
+        st64 = o64.forward(means3D=leaf64["xyz"], opacities=opac64, shs=leaf64["f_dc"], cov3D_precomp=cov64, viewmatrix=cam.world_view_transform.cpu().double(),
+                           projmatrix=cam.full_proj_transform.cpu().double(), campos=cam.camera_center.cpu().double(), bg=bg.cpu().double(), image_height=H,
+                           image_width=W, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2))
+        gb64 = o64.backward(st64, img_or.grad.double())            # the SAME upstream gradient as the float32 oracle's: only the rasterizer backward differs
+        t64 = lambda a, like: torch.tensor(np.asarray(a, dtype=np.float64)).reshape(like.shape)
+        torch.autograd.backward([cov64, opac64], [t64(gb64["dL_dcov3D"], cov64), t64(gb64["dL_dopacity"], opac64)])
+        g64 = dict(xyz=gb64["dL_dmeans3D"], f_dc=gb64["dL_dsh"].reshape(N, 1, 3), opacity=leaf64["opacity"].grad.numpy(),
+                   scaling=leaf64["scaling"].grad.numpy(), rotation=leaf64["rotation"].grad.numpy())
+        unexplained = []
+        for k, rows in over.items():
+            o32 = np.asarray(grads_or[k], dtype=np.float64).reshape(N, -1); a64 = np.asarray(g64[k], dtype=np.float64).reshape(N, -1)
+            scale = float(np.abs(o32).max()) + 1e-30
+            stack = np.stack([np.asarray(r[k], dtype=np.float64).reshape(N, -1)[rows] for r in runs])          # [run, row, component]
+            spread = (stack.max(0) - stack.min(0)).max(1) / scale
+            e_h32 = np.abs(stack[0] - o32[rows]).max(1) / scale
+            e_h64 = np.abs(stack[0] - a64[rows]).max(1) / scale
+            e_o = np.abs(o32[rows] - a64[rows]).max(1) / scale
+            for i, r in enumerate(rows):
+                ok = e_h64[i] <= max(TOL, 2.0 * e_o[i], 4.0 * spread[i])
+                print(f"    {k} row {int(r)} (radius {int(st['radii'][r])} px): hip vs oracle32 {e_h32[i]:.2e}, hip vs oracle64 {e_h64[i]:.2e}, oracle32 vs oracle64 {e_o[i]:.2e}, "
+                      f"spread over 4 runs of the same replay {spread[i]:.2e}{'' if ok else '   <-- NOT ACCOUNTED FOR'}")
+                if not ok:
+                    unexplained.append((k, int(r)))
+        assert not unexplained, f"rows over the 1e-4 bar that neither the float64 oracle nor the run-to-run spread accounts for: {unexplained}"
 
 
 def test_training_psnr_parity_300_steps_float_and_8bit():

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.common import make_inputs
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 DEV = "cuda:0"
@@ -317,6 +319,66 @@ def test_loss_gradient_inside_the_blend_matches_the_loss_backward_launch(gated):
         for a, b in zip(got[0], ref[0]):
             scale = float(b.abs().max()) + 1e-30
             assert float((a - b).abs().max()) <= 2e-5 * scale, "gradient with the loss gradient computed inside the blend"
+
+
+def test_loss_gradient_in_the_blend_refuses_a_second_gradient_into_the_image():
+    """with raster_lossgrad=True the tensor autograd passes from the loss to the rasterizer is uninitialised and unread.  A second
+    loss term on the image, or a hook that rewrites the gradient (the reference's hand-mask hook), would be dropped silently -- the
+    rasterizer's backward must refuse instead; the plain single-consumer case still runs."""
+    import math
+    from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    from egogaussian_amd.fused import l1_ssim_loss
+    N, H, W = 3000, 48, 80
+    teacher = make_scene(N, H, W, 0); teacher["log_scale"] += math.log(2.0)
+    cam = make_camera(7, H, W, device=DEV)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=DEV)
+    gt = torch.rand((3, H, W), device=DEV)
+
+    def step(extra):
+        pc = SynthGaussians(perturb_student(teacher), device=DEV)
+        out = render(cam, pc, Pipe, bg)
+        img = out["render"]
+        loss = l1_ssim_loss(img, gt, 0.2, defer_value=True, raster_prologue=True, raster_lossgrad=True)
+        if extra == "second term":
+            loss = loss + 0.1 * img.mean()
+        elif extra == "hook":
+            img.register_hook(lambda g: g * 0.5)
+        loss.backward()
+        torch.cuda.synchronize()
+        return pc
+
+    pc = step(None)
+    assert all(torch.isfinite(p.grad).all() for p in pc.parameters() if p.grad is not None)
+    for extra in ("second term", "hook"):
+        with pytest.raises(RuntimeError, match="another gradient contribution"):
+            step(extra)
+
+
+def test_loss_gradient_in_the_blend_with_a_colours_only_backward_takes_the_full_path():
+    """the label-call shape (colors_precomp the only differentiable input) under raster_lossgrad=True must not reach the colours-only
+    fast path, which would read the uninitialised gradient tensor: the gradient has to equal the separate loss-backward launch's."""
+    import math
+    from egogaussian_amd.scene_synth import make_scene, make_camera
+    from egogaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from egogaussian_amd.fused import l1_ssim_loss
+    N, H, W = 3000, 48, 80
+    d = make_inputs(N, H, W, 0, 0, "col_sr", scale_mul=2.0)
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=d["tanfovx"], tanfovy=d["tanfovy"], bg=d["bg"].to(DEV), scale_modifier=1.0,
+                                       viewmatrix=d["viewmatrix"].to(DEV), projmatrix=d["projmatrix"].to(DEV), sh_degree=0, campos=d["campos"].to(DEV),
+                                       prefiltered=False, debug=False)
+    gt = torch.rand((3, H, W), generator=torch.Generator().manual_seed(2)).to(DEV)
+    res = []
+    for mode in (False, True):
+        cols = d["colors_precomp"].to(DEV).requires_grad_(True)
+        img, _, _, _ = GaussianRasterizer(rs)(means3D=d["means3D"].to(DEV), means2D=torch.zeros((N, 3), device=DEV), opacities=d["opacities"].to(DEV),
+                                              colors_precomp=cols, scales=d["scales"].to(DEV), rotations=d["rotations"].to(DEV))
+        l1_ssim_loss(img, gt, 0.2, defer_value=True, raster_prologue=True, raster_lossgrad=mode).backward()
+        torch.cuda.synchronize()
+        res.append(cols.grad.clone())
+    scale = float(res[0].abs().max())
+    assert scale > 0 and torch.isfinite(res[1]).all()
+    assert float((res[1] - res[0]).abs().max()) <= 2e-5 * scale
 
 
 def test_loss_gradient_in_the_blend_on_a_frame_with_no_instance():

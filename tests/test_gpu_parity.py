@@ -4,8 +4,11 @@ Bars (BASELINE.json north_star): tile / sort indices bit-exact; RGB / depth / al
 1e-4 relative fp32.  Two fp32 effects are handled explicitly rather than by loosening the bar:
   * exp() on the GPU (v_exp_f32) and in glibc differ in the last ulp, so a (pixel, splat) pair whose alpha sits
     within ~1e-6 relative of the 1/255 or 1e-4 thresholds can be kept on one side and skipped on the other.
-    Such pixels are rare and are counted: the strict bound applies to all but a 1e-4 fraction of pixels, and the
-    exceptions are bounded by the size of one threshold-level contribution.
+    Such pixels are DETECTED (off by more than 2e-6 of the image maximum) and must be PROVEN flips: the float64
+    re-walk of the pixel's chain has to show a threshold-adjacent pair (tests/common.py flip_cause), otherwise the
+    test fails; every other pixel of every image is held to 1e-4 (max-norm relative: of the plane's maximum), the
+    proven flips to one threshold-level contribution, and only the Gaussians in a flipped pixel's tile list are
+    excused from the gradient bar.
   * gradient sums are accumulated in a different order (wave reductions + atomics).
 """
 import math
@@ -15,7 +18,7 @@ import pytest
 import torch
 
 from tests.common import (make_inputs, seeded_grads, rel_err, outlier_fraction, tile_culling, fused_count, sort_in_blend, check_culled_lists, flip_pixels,
-                          check_grads_isolating_flips)
+                          check_grads_isolating_flips, check_images_isolating_flips)
 
 pytestmark = pytest.mark.gpu
 
@@ -143,10 +146,12 @@ def test_forward_and_backward_parity(N, H, W, seed, deg, mode, smul, cull):
     print(f"\n[{N}@{W}x{H} {mode} deg{deg}] R={R} n_contrib equal {nc_eq:.6f}; max rel err colour {e_c:.2e} depth {e_d:.2e} "
           f"alpha {e_a:.2e}; colour outliers>{TOL:g}: {f_c:.2e}")
     assert nc_eq > 0.9995
-    for name, hip, ora in (("color", color, st["color"]), ("depth", depth, st["depth"]), ("alpha", alpha, st["alpha"])):
-        assert outlier_fraction(hip.cpu().numpy(), ora, TOL) <= 1e-4, name
-        assert rel_err(hip.cpu().numpy(), ora) < 2e-2, name          # a threshold flip moves one pixel by <= ~alpha_min * c
-    assert rel_err(iv["final_T"].cpu().numpy(), st["final_T"]) < 2e-2
+    # threshold flips (tests/common.py): found with a threshold far below the bar and PROVEN (a threshold-adjacent pair in the float64 chain
+    # of the pixel, else flip_pixels fails); every other pixel of every plane within 1e-4 of the plane's maximum
+    flip_px = flip_pixels(color.cpu().numpy(), iv["final_T"].cpu().numpy(), st, None if cull else nc_hip)
+    print("   images: " + check_images_isolating_flips((("color", color.cpu().numpy(), st["color"]), ("depth", depth.cpu().numpy(), st["depth"]),
+                                                         ("alpha", alpha.cpu().numpy(), st["alpha"]), ("final_T", iv["final_T"].cpu().numpy(), st["final_T"])),
+                                                        st, flip_px, TOL, what=f"[{N}@{W}x{H} {mode}]") + f"; flipped pixels {int(flip_px.sum())}")
 
     # ---- gradients -------------------------------------------------------------------------------------
     grads = seeded_grads(H, W, seed + 10)
@@ -154,8 +159,7 @@ def test_forward_and_backward_parity(N, H, W, seed, deg, mode, smul, cull):
     torch.cuda.synchronize()
     gb = o.backward(st, *grads)
     names = ["dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot"]
-    # threshold flips (tests/common.py): found with a threshold far below the bar; every Gaussian away from them is held to 1e-4
-    flip_px = flip_pixels(color.cpu().numpy(), iv["final_T"].cpu().numpy(), st, None if cull else nc_hip)
+    # every Gaussian away from the (proven) flipped pixels is held to 1e-4
     rep, _, _ = check_grads_isolating_flips(names, hb, gb, st, flip_px, TOL, what=f"[{N}@{W}x{H} {mode}]")
     print("   grads: " + rep)
 
@@ -679,9 +683,9 @@ def test_config_D_1M_gaussians_1080p_depth_alpha_gradcheck():
     assert np.array_equal(bv["point_list"].cpu().numpy().view(np.uint32), st["point_list"])
     iv = _C.image_views(img, W, H)
     assert np.array_equal(iv["ranges"].cpu().numpy().view(np.uint32), st["ranges"])
-    for name, hip, ora in (("color", color, st["color"]), ("depth", depth, st["depth"]), ("alpha", alpha, st["alpha"])):
-        assert outlier_fraction(hip.cpu().numpy(), ora, TOL) <= 1e-4, name
     flip_px = flip_pixels(color.cpu().numpy(), iv["final_T"].cpu().numpy(), st, iv["n_contrib"].cpu().numpy().view(np.uint32))
+    print("  D images: " + check_images_isolating_flips((("color", color.cpu().numpy(), st["color"]), ("depth", depth.cpu().numpy(), st["depth"]),
+                                                         ("alpha", alpha.cpu().numpy(), st["alpha"])), st, flip_px, TOL, what="config D"))
     grads = seeded_grads(H, W, 99)
     hb = hip_backward(g, out, grads, dev)
     gb = o.backward(st, *grads)

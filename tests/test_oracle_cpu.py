@@ -144,3 +144,40 @@ def test_empty_inputs():
     assert np.allclose(st["color"], d["bg"].numpy()[:, None, None])
     g = Oracle(np.float32).backward(st, *seeded_grads(32, 32))
     assert all(np.all(v == 0) for v in g.values() if v is not None)
+
+
+def test_flip_rule_accepts_only_pixels_with_a_threshold_adjacent_pair():
+    """tests/common.py flip_pixels / flip_cause (the parity suite's threshold-flip rule) on the CPU: an output equal to the
+    oracle's has no flips; a pixel that is off with NO threshold-adjacent pair in the float64 re-walk of its chain fails the call; the same
+    difference on a pixel whose chain holds a pair with alpha within 1e-5 (relative) of 1/255 is accepted as a flip."""
+    from tests.common import flip_pixels, flip_cause
+    N, H, W = 400, 32, 48
+    d = make_inputs(N, H, W, 7, 0, "col_sr", scale_mul=3.0)
+    o = Oracle(np.float32)
+    st = o.forward(**d)
+    assert not flip_pixels(st["color"], st["final_T"], st, st["n_contrib"]).any()
+    # a pixel whose chain has no pair anywhere near a threshold (most have none): off by 1e-3 -> refused
+    cand = [(y, x) for y in range(H) for x in range(W) if st["n_contrib"][y, x] > 0 and flip_cause(st, y, x) is None]
+    assert len(cand) > H * W // 2
+    y, x = cand[len(cand) // 2]
+    bad = st["color"].copy(); bad[:, y, x] += 1e-3
+    with pytest.raises(AssertionError, match="NO threshold-adjacent pair"):
+        flip_pixels(bad, st["final_T"], st, st["n_contrib"])
+    # put the first list entry of that pixel's tile that reaches the pixel at all exactly on the alpha threshold (alpha = (1 + 3e-6) / 255) by
+    # editing its opacity
+    t = (y // 16) * ((W + 15) // 16) + x // 16
+    for g in st["point_list"][int(st["ranges"][t, 0]):int(st["ranges"][t, 1])].astype(int):
+        co = st["conic_opacity"][g].astype(np.float64)
+        dx, dy = float(st["xy"][g, 0]) - x, float(st["xy"][g, 1]) - y
+        G = math.exp(min(0.0, -0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy))
+        if G > 0.1:
+            break
+    assert G > 0.1
+    g = int(g)
+    d2 = dict(d); d2["opacities"] = d["opacities"].clone(); d2["opacities"][g] = (1.0 + 3e-6) / 255.0 / G
+    st2 = o.forward(**d2)
+    cause = flip_cause(st2, y, x)
+    assert cause is not None and cause.startswith("alpha threshold") and f"Gaussian {g})" in cause
+    off = st2["color"].copy(); off[:, y, x] += 1e-3
+    px = flip_pixels(off, st2["final_T"], st2, st2["n_contrib"])
+    assert px[y, x] and px.sum() == 1
