@@ -721,6 +721,7 @@ def main():
     head_name = "dynamic" if args.dynamic else "static"
     head, red = legs[head_name], legs[head_name]["red"]
 
+    world_seen = egs_dist.world_seen(dev)                       # an all-reduce of ones on device tensors: the ranks the COLLECTIVE saw
     ranks_info = None
     if args.verify_ranks:
         import torch.distributed as tdist
@@ -775,17 +776,26 @@ def main():
     replay_us = None
     if budget and replay_kernel and head["use_graph"] and key == "500000@960x540":
         replay_us = next((v for k_, v in budget["kernels_us"].items() if replay_kernel in k_), None)     # (the trace may hold mangled names)
-    lg_bytes = 0
+    # Byte conventions.  `achieved` / `frac` follow SURVEY.md 8d for the dominant kernel -- the backward blend: 84 B per
+    # instance (44 list re-read + 40 accumulate) + 32 B per pixel -- over the duration MEASURED IN THIS RUN (HIP events on the launch stream).
+    # Named beside it, never folded in: the record as this library packs it (92 B per instance: 4 id + 48 record + 40 accumulate), and the
+    # bytes of the image loss's backward that the replayed blend also does (ABI 5: 20 B per pixel-channel of maps, image, ground truth).
+    t_dom = d["ms_per_launch"] * 1e-3                                 # live: this run's events
+    alg_bytes = d["alg_MB"] * 1e6                                     # the stage table's convention (as packed)
+    if dominant == "render_backward":
+        alg_8d = 84 * R_kept + 32 * npix
+    elif dominant == "render_forward":
+        alg_8d = 44 * R_kept + 28 * npix
+    else:
+        alg_8d = alg_bytes
+    lg_bytes = 20 * 3 * npix if (dominant == "render_backward" and head.get("lg_in_blend")) else 0
+    replayed = None
     if replay_us:
-        d = dict(d); d["ms_per_launch_eager_events"] = d["ms_per_launch"]; d["ms_per_launch"] = round(replay_us * 1e-3, 5)
-        if dominant == "render_backward" and head.get("lg_in_blend"):
-            # the replayed step's blend also does the image loss's backward (no launch of its own, ABI 5): what that kernel had to read -- three
-            # derivative maps, image, ground truth: 20 B per pixel-channel -- is this launch's work now (the eager pass behind `stages` keeps the
-            # loss-backward launch, so its render_backward row is the blend alone)
-            lg_bytes = 20 * 3 * npix
-            d["alg_MB"] = round(d["alg_MB"] + lg_bytes / 1e6, 2)
-        d["alg_GBps"] = round(d["alg_MB"] * 1e6 / (replay_us * 1e-6) / 1e9, 1)
-    t_dom = d["ms_per_launch"] * 1e-3
+        t_rep = replay_us * 1e-6
+        replayed = {"ms_per_launch": round(replay_us * 1e-3, 5), "source": f"profiles/graph_step_budget.json: rocprofv3 --kernel-trace of the graph-replayed step on the same "
+                    f"kernel sources ({budget['steps']} steps), NOT measured in this run",
+                    "frac": round(alg_8d / t_rep / 1e9 / HBM_PEAK_GBS, 5),
+                    **({"frac_incl_loss_gradient_bytes": round((alg_8d + lg_bytes) / t_rep / 1e9 / HBM_PEAK_GBS, 5)} if lg_bytes else {})}
     issue_frac = None
     if sq_dom and sq_dom.get("valu_wave_instructions"):
         # share of the chip's VALU issue capacity the kernel's vector instructions account for: wave-instructions x measured
@@ -795,23 +805,23 @@ def main():
     for st_name in ("render_forward", "render_backward"):
         if st_name in stage_rows:
             pair_rows[st_name] = round(head["pairs"] / (stage_rows[st_name]["ms_per_launch"] * 1e-3) / 1e9, 2)
-    roofline = {"kernel": dominant, "bound": "hbm", "achieved": d["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(d["alg_GBps"] / HBM_PEAK_GBS, 5), "traffic": traffic,
+    achieved = alg_8d / t_dom / 1e9
+    roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_note": why_pmc or "profiles/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes, same kernel sources",
                 "valu_busy": (sq_dom or {}).get("valu_busy"), "issue_frac": issue_frac,
                 "counters_note": why_sq or "profiles/sq_counters.json: SQ counters of the same kernel sources",
                 "kernel_source_hash": src_hash,
                 "pairs_Q": int(head["pairs"]), "visits": int(head["visits"]), "lanes_kept_per_visit": round(head["pairs"] / max(head["visits"], 1), 2),
                 "pairs_per_s_G": pair_rows,
-                "ms_per_launch": d["ms_per_launch"], "alg_bytes_per_launch": int(d["alg_MB"] * 1e6),
-                **({"alg_bytes_loss_gradient": lg_bytes, "alg_bytes_loss_gradient_note": "included in alg_bytes_per_launch: the replayed blend computes dL/dimage itself "
-                    "(20 B per pixel-channel of maps, image and ground truth); without it the figure is the blend's own 92 B per instance + 32 B per pixel"} if lg_bytes else {}),
-                **({"alg_bytes_per_launch_survey_8d": int(84 * R_kept + 32 * npix + lg_bytes),
-                    "frac_survey_8d": round((84 * R_kept + 32 * npix + lg_bytes) / t_dom / 1e9 / HBM_PEAK_GBS, 5),
-                    "alg_bytes_note": "alg_bytes_per_launch prices an instance at 92 B (4 id + 48 record as this library packs it + 40 accumulate), "
-                                      "SURVEY.md 8d at 84 B (44 list re-read + 40 accumulate); both + 32 B per pixel"} if dominant == "render_backward" else {}),
-                "timing": (f"rocprofv3 --kernel-trace of the graph-replayed step, same kernel sources (profiles/graph_step_budget.json: {budget['steps']} steps); "
-                           f"the eager HIP-event pass of this run gave {d.get('ms_per_launch_eager_events')} ms" if replay_us else head["stage_timing"] + f" ({why_budget})"),
+                "ms_per_launch": d["ms_per_launch"], "alg_bytes_per_launch": int(alg_8d),
+                "alg_bytes_convention": "SURVEY.md 8d: 84 B per instance after tile culling + 32 B per pixel (backward blend); 44 B + 28 B (forward blend)",
+                "timing": head["stage_timing"],
+                "as_packed": {"alg_bytes_per_launch": int(alg_bytes), "frac": round(alg_bytes / t_dom / 1e9 / HBM_PEAK_GBS, 5),
+                              "note": "an instance priced as this library packs it: 4 B id + 48 B record + 40 B accumulate = 92 B"},
+                **({"loss_gradient_bytes": lg_bytes, "loss_gradient_note": "the graph-replayed blend also computes dL/dimage for its tile (no loss-backward launch, ABI 5): "
+                    "20 B per pixel-channel of maps, image and ground truth; NOT in `achieved` / `frac` (the live events time the eager blend, which loads dL/dimage)"} if lg_bytes else {}),
+                **({"replayed": replayed} if replayed else {"replayed_note": why_budget}),
                 "note": "blend stages are VALU-issue-bound (per pixel-splat pair work), not HBM-bound: pairs_Q = (pixel, splat) pairs one frame "
                         "blends, visits = (8x8-pixel wave, splat) iterations of the forward; see `stages` for the streaming kernels"}
     op_ms = sum(ms / n for ms, n in stages.values() if n)
@@ -860,6 +870,7 @@ def main():
                       "four times while training continues: value_median / value_spread = median and [min, max] of the five",
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "collective": egs_dist.collective_name(), **({"collective_error": collective_error} if collective_error else {}),
+        "rccl_world_seen": world_seen if egs_dist.collective_name() == "rccl" else None, "collective_world_seen": world_seen,
         "config": {"workload": f"S({N},{H},{W},seed{args.teacher_seed}) teacher/student, 300-frame orbit, 1 frame per GPU per step; step = " + step_text[head_name],
                    "gaussians": N, "image": [H, W], "sh_degree": D, "instances_R": int(R_mean), "instances_after_tile_culling": int(R_kept),
                    "teacher_seed": args.teacher_seed,
@@ -881,6 +892,8 @@ def main():
                             "GPU not waited for"} if head.get("host_us") else {}),
         "roofline": roofline, "stages": stage_rows, "cpu_baseline": cpu,
         **({"eager_frames_voided": head["eager_overflows"]} if head.get("eager_overflows") is not None else {}),
+        **({"valid": False, "invalid_reason": f"{head['eager_overflows']} frame(s) of the timed loop exceeded the instance capacity and were voided on the device: "
+                                              "`value` counts steps that did no update"} if head.get("eager_overflows") else {}),
     }
     if head_name == "static" and "dynamic" in legs:
         dl, dr = legs["dynamic"], legs["dynamic"]["red"]

@@ -479,14 +479,22 @@ __device__ __forceinline__ void pp_bwd_one(
     Ewa e; ewa_project(p, c6, V, W, H, tanfovx, tanfovy, e);
 
     // conic (xx, xy/2, yy) -> cov2D (a,b,c); the published backward regularises 1/det^2 by 1e-7.
-    const float gA = acc[2], gB = acc[3], gC = acc[4];
-    const float denom = e.a * e.c - e.b * e.b;
-    const float d2inv = 1.f / (denom * denom + 0.0000001f);
+    // These three lines are dL/dcov2D = -cov2D^-1 (dL/dconic) cov2D^-1 written out, and the lines after them multiply the result by the
+    // covariance again (gm0 = 2 S0 dL_da + S1 dL_db ...): the product only cancels back to "cov2D^-1 x gradient" if the three numbers keep
+    // that structure.  In float32 they do not for an elongated splat (a c within 2 % of b^2: every term below is ~60 x the sum, the rounding
+    // of each lands in the next lines' cancellation once more) -- dL/dmeans3D of the one recorded parity miss was 7e-4 of the array's
+    // maximum off with EXACT blend sums, float32 oracle included (tools/dev/chain_precision.py).  Evaluated in float64 from the same float32
+    // (a, b, c) they are the exact formula of a covariance 1e-7 away, and the row lands 2e-6 from the float64 oracle.  ~25 double
+    // operations per Gaussian in a kernel that streams 300 B per Gaussian.
+    const double gA = (double)acc[2], gB = (double)acc[3], gC = (double)acc[4];
+    const double ea = (double)e.a, eb = (double)e.b, ec = (double)e.c;
+    const double denom = ea * ec - eb * eb;
+    const double d2inv = 1.0 / (denom * denom + 0.0000001);
     float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
-    if (d2inv != 0.f) {
-        dL_da = d2inv * (-e.c * e.c * gA + 2.f * e.b * e.c * gB + (denom - e.a * e.c) * gC);
-        dL_dc = d2inv * (-e.a * e.a * gC + 2.f * e.a * e.b * gB + (denom - e.a * e.c) * gA);
-        dL_db = d2inv * 2.f * (e.b * e.c * gA - (denom + 2.f * e.b * e.b) * gB + e.a * e.b * gC);
+    if (d2inv != 0.0) {
+        dL_da = (float)(d2inv * (-ec * ec * gA + 2.0 * eb * ec * gB + (denom - ea * ec) * gC));
+        dL_dc = (float)(d2inv * (-ea * ea * gC + 2.0 * ea * eb * gB + (denom - ea * ec) * gA));
+        dL_db = (float)(d2inv * 2.0 * (eb * ec * gA - (denom + 2.0 * eb * eb) * gB + ea * eb * gC));
         const float* m0 = e.m0; const float* m1 = e.m1;
         g6[0] = m0[0] * m0[0] * dL_da + m0[0] * m1[0] * dL_db + m1[0] * m1[0] * dL_dc;
         g6[3] = m0[1] * m0[1] * dL_da + m0[1] * m1[1] * dL_db + m1[1] * m1[1] * dL_dc;

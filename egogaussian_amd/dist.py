@@ -126,6 +126,17 @@ def reduce_scalars(values, device="cpu", op="sum"):
     return [float(x) for x in t.tolist()]
 
 
+def world_seen(device="cpu"):
+    """How many ranks the collective itself saw: an all-reduce (sum) of a one on every rank, on a DEVICE tensor for RCCL -- the proof in a
+    result line that N ranks really exchanged data over the group, not only that N processes ran.  0 when there is no process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    dev = "cpu" if dist.get_backend() == "gloo" else (_pg_device if _pg_device is not None else device)
+    t = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(t)
+    return int(round(float(t.item())))
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         if _pg_device is not None:

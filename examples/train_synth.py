@@ -137,6 +137,9 @@ def main(argv=None):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0 - t_eval
     step.check()
+    # (what the run was, for callers that assert on it: tests/test_gpu_densify.py runs the reference's full schedule through this function)
+    pc.train_report = dict(gaussians_start=a.gaussians, gaussians_end=live(), psnr_end=quality(), its_per_s=a.iters / dt, recaptures=manual_recaptures + step.recaptures,
+                           recaptures_after_overflow=step.recaptures, overflow_events=step.skipped_frames_seen, iterations=it, instance_capacity=step.capacity)
     report(f"end: {live()} Gaussians, held-out PSNR {quality():.2f} dB, {a.iters / dt:.0f} it/s including densification, opacity resets and "
            f"{manual_recaptures + step.recaptures} re-capture(s) ({step.recaptures} after an instance-capacity overflow, {step.skipped_frames_seen} overflow events)")
     if a.out:

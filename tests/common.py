@@ -160,70 +160,121 @@ def quantize_8bit(img):
 
 
 # ---- threshold flips: isolate the damage instead of loosening the bar --------------------------------------------------------------
-# v_exp_f32 and glibc expf differ in the last place, so a (pixel, splat) pair whose alpha sits within ~1e-6 relative of 1/255 (or whose
-# transmittance sits at 1e-4) is kept on one side and skipped on the other.  Such a pair changes ITS pixel, hence the gradients of the
-# splats in that pixel's list -- and nothing else.  The parity tests therefore (1) find the flipped pixels with a threshold far below the
-# parity bar (a kept / skipped pair moves the colour by alpha T c >= ~4e-7 c, float noise is ~1e-7), (2) collect the Gaussians of the
-# oracle's tile lists of those pixels' tiles (a superset of the splats the pixel's chain touches), and (3) hold EVERY OTHER Gaussian's
-# gradients and every other pixel to the north star's 1e-4; the few affected rows are bounded by a flipped pair's share.
+# v_exp_f32 and glibc expf differ in the last place, so a (pixel, splat) pair whose alpha sits within float32 arithmetic's reach of 1/255
+# (or whose transmittance sits at 1e-4) is kept on one side and skipped on the other.  Such a pair changes ITS pixel, hence the gradients of
+# the splats in that pixel's list -- and nothing else.  The parity tests therefore (1) find the pixels that differ by more than a detection
+# level far below the parity bar, (2) make every one of them PROVE why (pixel_account below: the float64 re-walk of the pixel's chain
+# either bounds what two float32 evaluations of that chain can differ by -- the pixel is then ordinary float noise and stays under the
+# 1e-4 bar like every other pixel -- or holds a threshold-adjacent pair -- a flip; anything else fails the test), (3) collect the
+# Gaussians of the oracle's tile lists of the FLIPPED pixels' tiles (a superset of the splats the pixel's chain touches), and (4) hold
+# every other Gaussian's gradients and every other pixel to the north star's 1e-4; the few affected rows are bounded by a flipped pair's share.
 FLIP_DETECT = 2e-6
 
+ALPHA_WINDOW = 1e-5          # least relative half-width around 1/255 in which a pair's alpha may be kept on one side and skipped on the other
+T_WINDOW = 1e-9              # least absolute half-width around the 1e-4 transmittance stop (relative 1e-5)
+POWER_WINDOW = 1e-6          # least |power| below which the `power > 0` skip may go either way
+EPS32 = 2.0 ** -24           # float32 unit roundoff
+K_ARITH = 8.0                # roundings that separate two float32 evaluations of one exponent: ~4 per side (dx, dy, three products, two sums;
+                             # this library also rounds the conic once more when it pre-scales it by log2 e), each relative to the LARGEST
+                             # term of -(A dx^2 + C dy^2) / 2 - B dx dy, not to the sum: for a splat centred hundreds of pixels away the
+                             # terms are in the hundreds and the exponent they cancel to is ~ -5
 
-ALPHA_WINDOW = 1e-5          # relative half-width around 1/255 in which a pair's alpha may be kept on one side and skipped on the other
-T_WINDOW = 1e-9              # absolute half-width around the 1e-4 transmittance stop (relative 1e-5)
-POWER_WINDOW = 1e-6          # |power| below which the `power > 0` skip may go either way
 
-
-def flip_cause(st, y, x):
-    """Why pixel (y, x) may legitimately differ between two fp32 implementations: its chain re-walked in FLOAT64 from the oracle's
-    per-Gaussian state (pixel centres, conics, opacities: the values both sides share bit for bit) holds, at or before the point where
-    it stops, a pair whose alpha lies within ALPHA_WINDOW (relative) of 1/255, whose exponent lies within POWER_WINDOW of 0, or whose
-    T' = T (1 - alpha) lies within T_WINDOW of 1e-4 -- the three tests of the compositing loop (oracle/raster_oracle.c
-    egso_render_forward) whose outcome a last-place difference in exp() can change.  -> a description of the first such pair, or None:
-    a pixel that differs WITHOUT one is a wrong result, not a threshold flip."""
+def pixel_account(st, y, x):
+    """The chain of pixel (y, x) re-walked in FLOAT64 from the oracle's per-Gaussian state (pixel centres, conics, opacities, colours: the
+    values both sides share bit for bit; oracle/raster_oracle.c egso_render_forward is the loop).  ->
+      cause   : a description of the first pair, at or before the point where both sides must have stopped, at which two float32
+                evaluations may take different branches -- alpha within the pair's own arithmetic error (at least ALPHA_WINDOW, relative)
+                of 1/255, exponent within it of 0, T' = T (1 - alpha) within the accumulated error (at least T_WINDOW) of 1e-4 -- or None;
+      noise_c : what two float32 evaluations that take the SAME branches can differ by in the pixel's colour (absolute, any channel),
+      noise_T : ... and in its final transmittance.
+    The error model: an exponent is off by at most K_ARITH * EPS32 * (|A dx^2| / 2 + |C dy^2| / 2 + |B dx dy| + 1) =: r_j (absolute, hence
+    relative in alpha); T_j by the sum of alpha_k r_k / (1 - alpha_k) over the kept pairs in front; a contribution c alpha T by its
+    relative errors added.  Worst case, first order: a pixel that is off by MORE than this with no adjacent pair is a wrong result."""
     W = st["W"]
     gx = (W + 15) // 16
     t = (y // 16) * gx + x // 16
     ids = st["point_list"][int(st["ranges"][t, 0]):int(st["ranges"][t, 1])].astype(np.int64)
     if ids.size == 0:
-        return None
+        return None, 0.0, 0.0
     co = st["conic_opacity"][ids].astype(np.float64)
     dx = st["xy"][ids, 0].astype(np.float64) - float(x)
     dy = st["xy"][ids, 1].astype(np.float64) - float(y)
-    power = -0.5 * (co[:, 0] * dx * dx + co[:, 2] * dy * dy) - co[:, 1] * dx * dy
+    ta, tb, tc = 0.5 * co[:, 0] * dx * dx, co[:, 1] * dx * dy, 0.5 * co[:, 2] * dy * dy
+    power = -(ta + tc) - tb
+    r = K_ARITH * EPS32 * (np.abs(ta) + np.abs(tb) + np.abs(tc) + 1.0)              # per pair: |d power| = |d alpha| / alpha
     alpha = np.minimum(0.99, co[:, 3] * np.exp(np.minimum(power, 50.0)))
-    near_p = np.abs(power) <= POWER_WINDOW
-    near_a = (power <= POWER_WINDOW) & (np.abs(alpha - 1.0 / 255.0) <= ALPHA_WINDOW / 255.0)
+    near_p = np.abs(power) <= np.maximum(POWER_WINDOW, r)
+    near_a = (power <= np.maximum(POWER_WINDOW, r)) & (np.abs(alpha * 255.0 - 1.0) <= np.maximum(ALPHA_WINDOW, r))
     keep = (power <= 0.0) & (alpha >= 1.0 / 255.0)
     Tp = np.cumprod(np.where(keep, 1.0 - alpha, 1.0))                 # T' after entry j if it is kept
-    near_T = keep & (np.abs(Tp - 1e-4) <= T_WINDOW)
-    stop = np.nonzero(keep & (Tp < 1e-4 - T_WINDOW))[0]                # the first entry at which BOTH sides must have stopped
+    relT = np.cumsum(np.where(keep, (alpha * r + EPS32) / (1.0 - alpha), 0.0))      # relative error of T' after entry j
+    win_T = np.maximum(T_WINDOW, 1e-4 * relT)
+    near_T = keep & (np.abs(Tp - 1e-4) <= win_T)
+    stop = np.nonzero(keep & (Tp < 1e-4 - win_T))[0]                   # the first entry at which BOTH sides must have stopped
     end = int(stop[0]) + 1 if stop.size else ids.size
+    cause = None
     for name, m in (("alpha", near_a), ("T'", near_T), ("power", near_p)):
         j = np.nonzero(m[:end])[0]
         if j.size:
             j = int(j[0])
-            return f"{name} threshold: list entry {j} (Gaussian {int(ids[j])}) alpha*255 = {alpha[j] * 255.0:.9f}, power = {power[j]:.3e}, T' = {Tp[j]:.6e}"
-    return None
+            cause = (f"{name} threshold: list entry {j} (Gaussian {int(ids[j])}) alpha*255 = {alpha[j] * 255.0:.9f}, power = {power[j]:.3e}, T' = {Tp[j]:.6e}, "
+                     f"arithmetic reach {r[j]:.1e}, accumulated in T {relT[j]:.1e}")
+            break
+    # noise of a chain that takes the same branches on both sides (entries before the stop only)
+    n = end if not stop.size else end - 1                              # the stopping entry itself does not contribute
+    k = keep[:n]
+    T_before = np.concatenate([[1.0], Tp[:-1]])[:n]
+    relT_before = np.concatenate([[0.0], relT[:-1]])[:n]
+    cmax = np.abs(st["rgb"][ids[:n]].astype(np.float64)).max(1) if "rgb" in st else np.ones(n)
+    noise_c = float(np.sum(np.where(k, cmax * alpha[:n] * T_before * (r[:n] + relT_before + 2 * EPS32), 0.0)))
+    T_fin = float(Tp[n - 1]) if n else 1.0
+    rel_fin = float(relT[n - 1]) if n else 0.0
+    noise_c += float(np.abs(st["bg"]).max()) * T_fin * rel_fin if "bg" in st else 0.0
+    return cause, noise_c, T_fin * rel_fin
 
 
-def flip_pixels(color_hip, final_T_hip, st, n_contrib_hip=None, justify=True):
-    """bool[H,W]: pixels whose colour, final transmittance or (reference lists only) contributor count differ from the oracle's by more
-    than float noise.  justify (the default): every such pixel must have a CAUSE -- flip_cause() finds a threshold-adjacent pair in the
-    float64 re-walk of its chain -- or the call fails: a pixel that is off with no such pair is a wrong blend, whatever the fraction
-    ('the flip rule excuses without proving cause')."""
+def flip_cause(st, y, x):
+    """The threshold-adjacent pair of pixel (y, x), or None (see pixel_account)."""
+    return pixel_account(st, y, x)[0]
+
+
+def flip_pixels(color_hip, final_T_hip, st, n_contrib_hip=None, justify=True, report=None):
+    """bool[H,W]: pixels whose colour, final transmittance or (reference lists only) contributor count differ from the oracle's because a
+    (pixel, splat) pair went the other way at one of the compositing loop's three thresholds -- PROVEN per pixel.  Every pixel that is off
+    by more than FLIP_DETECT is put through pixel_account(): it is a flip when its float64 chain holds a threshold-adjacent pair; it is
+    float noise (NOT in the returned mask: it answers to the 1e-4 bar like every other pixel, and relaxes no Gaussian's bound) when it has
+    no such pair but is off by no more than what two float32 evaluations of that chain can differ by; otherwise the call fails: a pixel
+    that is off with neither is a wrong blend, whatever the fraction ('the flip rule excuses without proving cause').
+    report: a dict that receives the counts (detected, flips, noise) and the largest noise bound used."""
     c = np.asarray(color_hip, dtype=np.float64); T = np.asarray(final_T_hip, dtype=np.float64)
-    px = (np.abs(c - st["color"]) > FLIP_DETECT * max(float(np.abs(st["color"]).max()), 1e-30)).any(0) | (np.abs(T - st["final_T"]) > FLIP_DETECT)
+    cscale = max(float(np.abs(st["color"]).max()), 1e-30)
+    dc = np.abs(c - st["color"]).max(0); dT = np.abs(T - st["final_T"])
+    px = (dc > FLIP_DETECT * cscale) | (dT > FLIP_DETECT)
     if n_contrib_hip is not None:
-        px = px | (np.asarray(n_contrib_hip) != st["n_contrib"])
-    if justify and px.any():
-        bad = []
-        for y, x in np.argwhere(px):
-            if flip_cause(st, int(y), int(x)) is None:
-                bad.append((int(y), int(x), float(np.abs(c[:, y, x] - st["color"][:, y, x]).max()), float(abs(T[y, x] - st["final_T"][y, x]))))
-        assert not bad, (f"{len(bad)} of {int(px.sum())} pixels differ from the oracle by more than float noise ({FLIP_DETECT:g} of the image maximum) with NO "
-                         f"threshold-adjacent pair in their float64 chain -- not flips: (y, x, colour diff, final_T diff) {bad[:8]}")
-    return px
+        dn = np.asarray(n_contrib_hip) != st["n_contrib"]
+        px = px | dn
+    if not justify or not px.any():
+        if report is not None:
+            report.update(detected=int(px.sum()), flips=int(px.sum()), noise=0, max_noise_bound=0.0)
+        return px
+    flips = np.zeros_like(px)
+    bad, n_noise, worst_bound = [], 0, 0.0
+    for y, x in np.argwhere(px):
+        cause, noise_c, noise_T = pixel_account(st, int(y), int(x))
+        if cause is not None:
+            flips[y, x] = True
+        elif (n_contrib_hip is None or not dn[y, x]) and dc[y, x] <= FLIP_DETECT * cscale + noise_c and dT[y, x] <= FLIP_DETECT + noise_T:
+            n_noise += 1
+            worst_bound = max(worst_bound, noise_c / cscale, noise_T)
+        else:
+            bad.append((int(y), int(x), float(dc[y, x]), float(dT[y, x]), f"float32 reach of this chain: colour {noise_c:.2e}, T {noise_T:.2e}"))
+    if report is not None:
+        report.update(detected=int(px.sum()), flips=int(flips.sum()), noise=n_noise, max_noise_bound=worst_bound)
+    assert not bad, (f"{len(bad)} of {int(px.sum())} pixels differ from the oracle by more than the detection level ({FLIP_DETECT:g} of the image maximum) AND by more than "
+                     f"two float32 evaluations of their chain can, with NO threshold-adjacent pair in the float64 chain -- neither flips nor float noise: "
+                     f"(y, x, colour diff, final_T diff, reach) {bad[:8]}")
+    return flips
 
 
 def check_images_isolating_flips(images, st, flip_px, tol=1e-4, share=2e-2, what=""):

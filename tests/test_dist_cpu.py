@@ -22,6 +22,7 @@ def _worker(rank, world, port, out):
     tot = d.reduce_scalars(local, "cpu", "sum")
     tmax = d.reduce_scalars([10.0 + rank], "cpu", "max")[0]
     d.barrier()
+    assert d.world_seen() == world                              # the all-reduce of ones bench.py prints as collective_world_seen
     out[rank] = (frames, tot, tmax)
     d.shutdown()
 
@@ -43,6 +44,7 @@ def test_single_process_is_identity():
     assert d.env_world() == (0, 1, 0) and d.shard_frames(7, 0, 1) == list(range(7))
     assert d.reduce_scalars([1.5, 2.0]) == [1.5, 2.0]
     d.barrier()
+    assert d.world_seen() == 0                                  # no process group: nothing was exchanged
 
 
 def test_bench_plain_launch_command():

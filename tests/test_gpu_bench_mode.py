@@ -87,8 +87,23 @@ def test_config_C_bench_mode_vs_oracle():
     from tests.common import flip_pixels, check_grads_isolating_flips, check_images_isolating_flips
     # (the transmittance plane of the REPLAYED frame: the captured forward's image buffer, which every replay rewrites)
     final_T_hip = _C.image_views(_C.stats["image_buffer"], W, H)["final_T"].cpu().numpy()
-    flip_px = flip_pixels(img_hip, final_T_hip, st)
-    print(f"\n  config C, benched mode: R = {st['R']}, image max rel err {e_img:.2e}, pixels off by more than float noise: {int(flip_px.sum())}")
+    rep_px = {}
+    flip_px = flip_pixels(img_hip, final_T_hip, st, report=rep_px)
+    # The loss has a threshold of its own: d|x - y| / dx = sign(x - y).  At a pixel-channel where the rendered value equals the ground truth to
+    # float noise, the two sides' images (equal to ~1e-7) give OPPOSITE signs, and that pixel's upstream gradient differs by 2 x 0.8 / n --
+    # in round 5 these rows were put down to "fp32 accumulation order", which the repeated replays below disprove (spread 1e-8).  Such a
+    # pixel is found directly (the signs differ), has to prove it (both sides within 1e-6 of the ground truth there), and then counts as
+    # a flipped pixel: its tile's Gaussians get the flipped pair's bound, everything else the bar.
+    gt = gts[1].cpu().numpy().astype(np.float64)
+    s_hip, s_or = np.sign(img_hip.astype(np.float64) - gt), np.sign(st["color"].astype(np.float64) - gt)
+    tie = s_hip != s_or                                               # per pixel-channel
+    sign_px = tie.any(0)
+    worst_gap = float(np.maximum(np.abs(img_hip - gt), np.abs(st["color"] - gt))[tie].max()) if tie.any() else 0.0
+    assert worst_gap <= 1e-6, f"the L1 term's sign differs at a pixel where an image is {worst_gap} away from the ground truth: not a tie"
+    print(f"\n  config C, benched mode: R = {st['R']}, image max rel err {e_img:.2e}, pixels off by more than {2e-6:g}: {rep_px.get('detected', 0)} "
+          f"({rep_px.get('flips', 0)} with a threshold-adjacent pair, {rep_px.get('noise', 0)} within their chain's float32 reach, largest {rep_px.get('max_noise_bound', 0.0):.1e}); "
+          f"L1 sign ties (|image - ground truth| <= {worst_gap:.1e} on both sides, opposite signs): {int(sign_px.sum())} pixels")
+    flip_px = flip_px | sign_px
     check_images_isolating_flips((("color", img_hip, st["color"]), ("final_T", final_T_hip, st["final_T"])), st, flip_px, TOL, what="config C benched mode")
     keys = list(grads_or)
     over = {}
@@ -215,6 +230,7 @@ def test_bench_two_ranks_plain_launch():
     line = [l for l in run.stdout.strip().splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["steps"] == 6 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["collective_world_seen"] == 2 and j["rccl_world_seen"] is None          # (gloo here: two ranks on one device)
     r0, r1 = sorted(j["ranks"], key=lambda r: r["rank"])
     assert (r0["rank"], r1["rank"]) == (0, 1)
     assert r0["frames"] == list(range(0, 16, 2)) and r1["frames"] == list(range(1, 16, 2))       # 8 frames each (warmup + steps), disjoint
@@ -244,6 +260,7 @@ def test_bench_eight_ranks_share_one_device():
     assert run.returncode == 0, run.stderr[-3000:]
     j = json.loads([l for l in run.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == W8 and j["steps"] == steps and j["scaling"] == "weak" and j["value"] > 0 and j["collective"] == "gloo"
+    assert j["collective_world_seen"] == W8
     ranks = sorted(j["ranks"], key=lambda r: r["rank"])
     assert [r["rank"] for r in ranks] == list(range(W8))
     seen = set()

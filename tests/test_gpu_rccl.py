@@ -58,6 +58,7 @@ def test_bench_single_gpu_line_says_rccl():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["collective"] == "rccl" and "collective_error" not in j and j["n_gpus"] == 1 and j["value"] > 0
+    assert j["rccl_world_seen"] == 1
 
 
 def test_bench_two_ranks_over_rccl_on_two_devices():
@@ -78,6 +79,7 @@ def test_bench_two_ranks_over_rccl_on_two_devices():
     j = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert j["collective"] == "rccl" and "collective_error" not in j
     assert j["n_gpus"] == 2 and j["steps"] == 10 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["rccl_world_seen"] == 2                             # RCCL itself saw both ranks (an all-reduce of ones on device tensors)
     r0, r1 = sorted(j["ranks"], key=lambda x: x["rank"])
     assert (r0["rank"], r1["rank"]) == (0, 1) and (r0["device"], r1["device"]) == ("cuda:0", "cuda:1")
     assert r0["frames"] == list(range(0, 30, 2)) and r1["frames"] == list(range(1, 30, 2))

@@ -163,6 +163,17 @@ def test_flip_rule_accepts_only_pixels_with_a_threshold_adjacent_pair():
     bad = st["color"].copy(); bad[:, y, x] += 1e-3
     with pytest.raises(AssertionError, match="NO threshold-adjacent pair"):
         flip_pixels(bad, st["final_T"], st, st["n_contrib"])
+    # the same pixel off by LESS than two float32 evaluations of its chain can differ by (pixel_account's bound, a few 1e-6 here): float
+    # noise -- accepted, and NOT marked: it stays under the 1e-4 bar like any other pixel and relaxes no Gaussian's bound
+    from tests.common import pixel_account, FLIP_DETECT
+    _, noise_c, noise_T = pixel_account(st, y, x)
+    assert 1e-8 < noise_c < 2e-5 and noise_T < 2e-5
+    hum = st["color"].copy(); hum[:, y, x] += FLIP_DETECT * float(np.abs(st["color"]).max()) + 0.5 * noise_c
+    rep = {}
+    assert not flip_pixels(hum, st["final_T"], st, st["n_contrib"], report=rep).any() and rep["noise"] == 1 and rep["flips"] == 0
+    hum[:, y, x] += noise_c                                          # ... and just beyond that reach: refused
+    with pytest.raises(AssertionError, match="NO threshold-adjacent pair"):
+        flip_pixels(hum, st["final_T"], st, st["n_contrib"])
     # put the first list entry of that pixel's tile that reaches the pixel at all exactly on the alpha threshold (alpha = (1 + 3e-6) / 255) by
     # editing its opacity
     t = (y // 16) * ((W + 15) // 16) + x // 16
