@@ -69,7 +69,8 @@ def algorithmic_bytes(stage, N, R, npix, sh_coeffs=1, fused_count=False, sort_in
 def _fuses_count(N, hw):
     """Does a forward of this size run the fused preprocess + count launch (include/egs_raster.h egs_forward_fuses_count)?"""
     from egogaussian_amd import lib as egs_lib
-    return bool(egs_lib.load().egs_forward_fuses_count(int(N), int(hw[1]), int(hw[0])))
+    from egogaussian_amd import _C as egs_C
+    return egs_C.forward_fuses_count(int(N), int(hw[1]), int(hw[0]))
 
 
 def spawn_command(gpus, argv, port=None):

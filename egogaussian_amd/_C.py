@@ -86,23 +86,56 @@ def binning_passes(P, W, H):
     return int(lay.index_passes) + 4
 
 
+# ---- per-call flags (include/egs_raster.h EGS_CALL_*, ABI 6) ----------------------------------------------------------------------
+# The library keeps no switches: every forward says in its own flags word whether it culls, fuses the count pass, sorts inside the blend.
+# A caller picks them per call -- rasterize_gaussians(..., debug=<bits>), or GaussianRasterizationSettings(debug=<bits>): the reference's
+# `debug` field is that word; True / 1 = CALL_SYNC, its old meaning -- and two trainers in one process with different settings do not
+# meet.  What follows is the DEFAULT this Python layer ORs into calls that do not say: the environment's A/B switches, and the
+# set_* helpers the tests use as context managers (tests/common.py) -- Python state of this module, not of the library.
+CALL_SYNC, CALL_KEEP_ALL_INSTANCES, CALL_SEPARATE_COUNT, CALL_SEPARATE_SORT, CALL_BALLOT_RANK = (
+    _lib.CALL_SYNC, _lib.CALL_KEEP_ALL_INSTANCES, _lib.CALL_SEPARATE_COUNT, _lib.CALL_SEPARATE_SORT, _lib.CALL_BALLOT_RANK)
+_env_on = lambda name: os.environ.get(name, "") not in ("", "0")
+default_call_flags = (CALL_SEPARATE_COUNT if _env_on("EGS_NO_FUSED_COUNT") else 0) | (CALL_SEPARATE_SORT if _env_on("EGS_NO_SORT_IN_BLEND") else 0)
+
+
+def call_flags(debug=0):
+    """The flags word of a forward: the caller's `debug` (bool: CALL_SYNC; int: EGS_CALL_* bits) OR this module's defaults."""
+    return (int(debug) if not isinstance(debug, bool) else (CALL_SYNC if debug else 0)) | default_call_flags
+
+
+def _set_default(bit, want_bit):
+    global default_call_flags
+    old = bool(default_call_flags & bit)
+    default_call_flags = (default_call_flags | bit) if want_bit else (default_call_flags & ~bit)
+    return old
+
+
 def set_tile_culling(on):
-    """Tile culling of never-contributing instances (include/egs_raster.h, egs_debug_set_tile_culling): on by default;
-    off keeps the reference's full rectangles so that the internal lists match the reference algorithm's bit for bit.
-    Returns the previous setting."""
-    return bool(_lib.load().egs_debug_set_tile_culling(int(bool(on))))
+    """Default of calls that do not say: tile culling of never-contributing instances on (the library's default) or off
+    (CALL_KEEP_ALL_INSTANCES: the reference's full rectangles, internal lists bit for bit the reference algorithm's).  -> the previous setting."""
+    return not _set_default(CALL_KEEP_ALL_INSTANCES, not on)
 
 
 def set_sort_in_blend(on):
-    """The per-tile sort inside the forward blend's launch (include/egs_raster.h, egs_debug_set_sort_in_blend): on by default; off = the
-    separate k_tile_sort launch.  Returns the previous setting."""
-    return bool(_lib.load().egs_debug_set_sort_in_blend(int(bool(on))))
+    """Default of calls that do not say: the per-tile sort inside the forward blend's launch (on) or as launches of its own
+    (CALL_SEPARATE_SORT).  -> the previous setting."""
+    return not _set_default(CALL_SEPARATE_SORT, not on)
 
 
 def set_fused_count(on):
-    """The count pass of the tile bucketing inside the preprocess launch (include/egs_raster.h, egs_debug_set_fused_count): on by default
-    whenever a forward has a placement buffer; off = the separate k_bin_count launch.  Returns the previous setting."""
-    return bool(_lib.load().egs_debug_set_fused_count(int(bool(on))))
+    """Default of calls that do not say: the count pass of the tile bucketing inside the preprocess launch whenever a forward has a
+    placement buffer (on) or as a launch of its own (CALL_SEPARATE_COUNT).  -> the previous setting."""
+    return not _set_default(CALL_SEPARATE_COUNT, not on)
+
+
+def force_ballot_rank(on):
+    """Default of calls that do not say: the per-tile sort's ballot-based ranking fallback (test hook).  -> the previous setting."""
+    return _set_default(CALL_BALLOT_RANK, bool(on))
+
+
+def forward_fuses_count(P, W, H, debug=0):
+    """Whether a forward of this size with a placement buffer and these flags folds the count pass into the preprocess launch."""
+    return bool(_lib.load().egs_forward_fuses_count(int(P), int(W), int(H), call_flags(debug)))
 
 
 def last_instance_count(device=None, P=None):
@@ -169,8 +202,8 @@ def placement_buffer(dev, W, H):
         # (never dropped: a captured hipGraph keeps the address; 40 KB per resolution and stream at 960x540)
         L = _lib.load()
         t = _placement[key] = torch.zeros((L.egs_placement_bytes(int(W), int(H)),), device=dev, dtype=torch.uint8)
-        # (ABI 5) registers the address: its sums region is zero, the first forward need not clear it again (under hipGraph capture that
-        # clearing launch would be captured into every replay)
+        # the owner's one-time initialisation (include/egs_raster.h: the sums region must be zero when a forward starts; the library keeps no
+        # record of buffers).  torch.zeros already cleared it; under hipGraph capture only that fill exists (and is replayed: harmless)
         if not torch.cuda.is_current_stream_capturing():
             _lib.check(L.egs_placement_init(t.data_ptr(), int(W), int(H), _hip.stream_of(dev)))
     return t
@@ -247,6 +280,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     sh_rest (extension): `sh` is then the DC block [P,1,3] and `sh_rest` the other coefficients [P,M-1,3] -- the two parameters the
     reference's GaussianModel stores, without the torch.cat of get_features (include/egs_raster.h: split spherical harmonics)."""
     L = _lib.load()
+    flags = call_flags(debug)
     means3D = _f32c(means3D, "means3D")
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -306,7 +340,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), _ptr(background), W, H,
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
                 _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), C.c_void_p(pin.data_ptr()), _ptr(guard.running_max),
-                _ptr(active_count), _ptr(guard.overflow), _ptr(place), rot_arg, _stream(dev)))
+                _ptr(active_count), _ptr(guard.overflow), _ptr(place), rot_arg, _stream(dev), flags))
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))             # behind the frame's last copy (egs_forward_enqueue queued it on this stream)
             guard._pending.append((pin, P, cap, key, ev))
@@ -323,7 +357,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _ptr(rotations), _ptr(cov3D_precomp), int(activation_flags), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), _ptr(background), W, H,
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img),
                 _ptr(out_color), _ptr(out_depth), _ptr(out_alpha), None, _ptr(None if guard is None else guard.running_max),
-                _ptr(active_count), _ptr(None if guard is None else guard.overflow), _ptr(place), rot_arg, _stream(dev)))
+                _ptr(active_count), _ptr(None if guard is None else guard.overflow), _ptr(place), rot_arg, _stream(dev), flags))
             R = C.c_int64(cap)                      # layout size; the true count is stats["total_view"] after a sync
             rc = 0
         else:
@@ -332,13 +366,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                _ptr(campos), _ptr(background), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                                _ptr(radii), _ptr(geom), cap, _ptr(binning), _ptr(img), _ptr(out_color), _ptr(out_depth),
                                _ptr(out_alpha), C.c_void_p(pinned.data_ptr()), C.byref(R), _ptr(active_count), _ptr(place), rot_arg, _stream(dev),
-                               int(bool(debug)))
+                               flags)
         if rc == _lib.RETRY_LARGER:
             cap = int(R.value * 1.25) + 65536
             total_off = _buffer_sizes(L, P, W, H, cap)[3]
             binning = torch.empty((_buffer_sizes(L, P, W, H, cap)[2],), device=dev, dtype=torch.uint8)
             rc = L.egs_forward_render(P, cap, _ptr(background), W, H, _ptr(geom), _ptr(binning), _ptr(img), _ptr(out_color),
-                                      _ptr(out_depth), _ptr(out_alpha), _stream(dev), int(bool(debug)))
+                                      _ptr(out_depth), _ptr(out_alpha), _stream(dev), flags)
             stats["retries"] += 1
         _lib.check(rc)
         if P and not capturing and not deferred:
@@ -406,7 +440,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
                 _ptr(imageBuffer), _ptr(g_color), None, None, None, _ptr(dcolors), None, None, None, None, None, None, None,
                 None, None, None, None, None, 1 if prologue_scratch is not None else 0, None, GRAD_COLORS, _ptr(scratch), _stream(dev),
-                int(bool(debug))))
+                (call_flags(debug) & CALL_SYNC)))
         return None, dcolors, None, None, None, None, None, None
     with _hip.device_ctx(dev):
         e = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
@@ -446,7 +480,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(dopacity), _ptr(dmeans3D_arg), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
                 _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
                 C.byref(sink.struct) if owned else None, 1 if prologue_scratch is not None else 0,
-                C.byref(rot_st) if rot_st is not None else None, 0, _ptr(scratch), _stream(dev), int(bool(debug))))
+                C.byref(rot_st) if rot_st is not None else None, 0, _ptr(scratch), _stream(dev), (call_flags(debug) & CALL_SYNC)))
             if owned:
                 sink.mark_stepped()
         elif P != 0 and (owned or prologue_scratch is not None or rot_st is not None):
@@ -459,7 +493,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(dopacity), _ptr(dmeans3D_arg), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
                 _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
                 C.byref(sink.struct) if owned else None, 1 if prologue_scratch is not None else 0,
-                C.byref(rot_st) if rot_st is not None else None, 0, _ptr(scratch), _stream(dev), int(bool(debug))))
+                C.byref(rot_st) if rot_st is not None else None, 0, _ptr(scratch), _stream(dev), (call_flags(debug) & CALL_SYNC)))
             if owned:
                 sink.mark_stepped()
         elif P != 0:
@@ -471,7 +505,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(imageBuffer), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(dmeans2D), _ptr(dcolors),
                 _ptr(dopacity), _ptr(dmeans3D), None if own_cov else _ptr(dcov3D), _ptr(dsh), _ptr(dsh_rest), _ptr(dscales) if own_cov else None,
                 _ptr(drots) if own_cov else None, *_stat_ptrs(densify_stats, P, dev), _ptr(None if guard is None else guard.overflow),
-                0, _ptr(scratch), _stream(dev), int(bool(debug))))
+                0, _ptr(scratch), _stream(dev), (call_flags(debug) & CALL_SYNC)))
     if sh_rest is not None:
         return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots, dsh_rest
     return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drots

@@ -54,7 +54,7 @@ def _selection(g, which_object):
     return cache["value"]
 
 
-def attach(gaussians, optimizer=True, capturable=False, fuse_optimizer=False):
+def attach(gaussians, optimizer=True, capturable=False, fuse_optimizer=False, provenance=True):
     """Install the hooks described in the module docstring on `gaussians` (any object with the reference's attribute names:
     _xyz, _features_dc, _features_rest, _scaling, _rotation, _opacity, _is_object, [trainable_object_move], [optimizer]).
     optimizer=True      replace a torch.optim.Adam in `gaussians.optimizer` by FusedAdam (same groups, state carried over);
@@ -63,6 +63,8 @@ def attach(gaussians, optimizer=True, capturable=False, fuse_optimizer=False):
                         the parameters it differentiates (no gradient arrays).  ONLY for trainers whose loss reaches the model
                         through that one render -- e.g. not while the entropy term of train_static.py:97-102 is active; FusedAdam
                         raises if a second gradient path shows up.  Needs capturable=True.
+    provenance=True     the activated tensors the model's getters return remember their raw parameters, so that the rasterizer can take
+                        those instead when the reference's own render() hands it the activated ones (see below); False: plain tensors.
     Returns `gaussians`."""
     g = gaussians
     missing = [a for a in _PARAMS if not hasattr(g, a)]
@@ -71,18 +73,41 @@ def attach(gaussians, optimizer=True, capturable=False, fuse_optimizer=False):
     if fuse_optimizer and not capturable:
         raise ValueError("fuse_optimizer=True needs capturable=True (the in-backward Adam step reads its step count and learning rates on the device)")
 
-    # ---- the reference's own render(): covariance producers ----
+    # ---- the reference's own render(): activations that remember where their result came from, covariance producers ----
+    # The reference's render() hands the rasterizer ACTIVATED tensors (get_opacity, get_covariance(get_scaling, ., _rotation), get_features:
+    # gaussian_renderer/__init__.py:56-82).  Each getter result made here carries `_egs_origin` = which raw parameter(s) it was computed from
+    # (a Python attribute of that very tensor object).  When the rasterizer is handed exactly these objects, unmodified, with the raw
+    # parameters unmodified since (provenance.py checks versions), it takes the RAW parameters instead -- activations and covariance inside its
+    # preprocess kernel, gradients straight to the leaves -- and the activation / covariance / concatenation backward launches and their
+    # autograd nodes never run.  Anyone else who reads the tensors gets ordinary tensors with ordinary autograd history.
+    from . import provenance as _prov
+    if provenance:
+        g.scaling_activation = _prov.tagging_activation(torch.exp, "scaling")                  # gaussian_model.py:36 (torch.exp)
+        g.opacity_activation = _prov.tagging_activation(torch.sigmoid, "opacity")              # :40 (torch.sigmoid)
+        g._egs_tag_features = True                                                             # get_features (:157-160) is a property of the class: patching.install wraps it
+
     def covariance_activation(scaling, scaling_modifier, rotation):
         if scaling.is_cuda:
-            return fused.covariance_from_scaling_rotation(scaling, scaling_modifier, rotation)
-        from .covariance import covariance_from_scaling_rotation
-        return covariance_from_scaling_rotation(scaling, scaling_modifier, rotation)
+            cov = fused.covariance_from_scaling_rotation(scaling, scaling_modifier, rotation)
+        else:
+            from .covariance import covariance_from_scaling_rotation
+            cov = covariance_from_scaling_rotation(scaling, scaling_modifier, rotation)
+        if provenance:
+            _prov.tag_covariance(cov, scaling, scaling_modifier, rotation)
+        return cov
 
     def build_covariance_w_rot(scaling, scaling_modifier, rotation, accum_R, which_object=None, during_training=False):
         build_covariance_w_rot.calls += 1
         if scaling.is_cuda:
-            return fused.rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation, accum_R, g._is_object, which_object,
-                                                                  _trainable_rotation(g, during_training), selection=_selection(g, which_object))
+            trot = _trainable_rotation(g, during_training)
+            cov = fused.rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation, accum_R, g._is_object, which_object,
+                                                                 trot, selection=_selection(g, which_object))
+            if provenance and trot is None and not (accum_R is not None and accum_R.requires_grad):
+                # (a rotation that is being trained needs the covariance path: its gradient; same rule as get_raw_parameters_rotated below)
+                M = torch.eye(3, device=g._xyz.device) if accum_R is None else accum_R.to(g._xyz.device, torch.float32)
+                sel, mult = _selection(g, which_object)
+                _prov.tag_covariance(cov, scaling, scaling_modifier, rotation, object_rotation=(M, sel, mult))
+            return cov
         from .covariance import rotated_covariance_from_scaling_rotation
         tom = getattr(g, "trainable_object_move", None) if during_training else None
         return rotated_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation, accum_R, g._is_object, which_object,

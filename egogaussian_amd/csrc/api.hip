@@ -103,7 +103,7 @@ int check_modes(const float* shs, const float* colors, const float* scales, cons
 }
 
 #define EGS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
-#define EGS_SYNC_IF_DEBUG(s) do { if (debug) { EGS_TRY(hipStreamSynchronize(s)); EGS_TRY(hipGetLastError()); } } while (0)
+#define EGS_SYNC_IF_DEBUG(s) do { if (debug & EGS_CALL_SYNC) { EGS_TRY(hipStreamSynchronize(s)); EGS_TRY(hipGetLastError()); } } while (0)
 
 // ---- stage timing pool -----------------------------------------------------------------------------
 struct ProfRec { int stage; hipEvent_t a, b; bool closed; };
@@ -165,27 +165,20 @@ int egs_abi_version(void) { return EGS_ABI_VERSION; }
 #endif
 const char* egs_source_hash(void) { return EGS_SOURCE_HASH; }
 
+#ifdef EGS_LG_CHECK
 // experiment hook: the next backward blends compute the image-loss gradient themselves (all NULL: off)
 int egs_debug_set_lossgrad(const float* img, const float* gt, const float* m0, const float* m1, const float* m2, const float* gate,
                            const float* upstream, float lambda_dssim) {
     egs_debug_lossgrad = EgsLossGradHost{ img, gt, m0, m1, m2, gate, upstream, nullptr, 1.f - lambda_dssim, lambda_dssim };
     return 0;
 }
-int egs_debug_set_tile_culling(int on) { const int old = egs_tile_culling; egs_tile_culling = on ? 1 : 0; return old; }
-static int g_fused_count = -1;       // -1: not decided yet (EGS_NO_FUSED_COUNT=1 in the environment turns it off)
-static bool fused_count_on() {
-    if (g_fused_count < 0) { const char* e = getenv("EGS_NO_FUSED_COUNT"); g_fused_count = (e && e[0] && e[0] != '0') ? 0 : 1; }
-    return g_fused_count != 0;
-}
-static int g_sort_in_blend = -1;     // -1: not decided yet (EGS_NO_SORT_IN_BLEND=1 in the environment turns it off)
-static bool sort_in_blend_on() {
-    if (g_sort_in_blend < 0) { const char* e = getenv("EGS_NO_SORT_IN_BLEND"); g_sort_in_blend = (e && e[0] && e[0] != '0') ? 0 : 1; }
-    return g_sort_in_blend != 0;
-}
-int egs_debug_set_sort_in_blend(int on) { const int old = sort_in_blend_on() ? 1 : 0; g_sort_in_blend = on ? 1 : 0; return old; }
-int egs_forward_fuses_count(int P, int width, int height) { return (fused_count_on() && egs_can_fuse_count(P, width, height)) ? 1 : 0; }
-int egs_debug_set_fused_count(int on) { const int old = fused_count_on() ? 1 : 0; g_fused_count = on ? 1 : 0; return old; }
-int egs_debug_force_ballot_rank(int on) { const int old = egs_force_ballot_rank; egs_force_ballot_rank = on ? 1 : 0; return old; }
+#endif
+// Per-call flags (include/egs_raster.h EGS_CALL_*, ABI 6): what used to be process-wide switches (egs_debug_set_tile_culling / _fused_count /
+// _sort_in_blend / egs_debug_force_ballot_rank through ABI 5) travels in the last argument of the call it applies to; the library keeps none of it.
+static inline bool fused_count_on(int flags) { return !(flags & EGS_CALL_SEPARATE_COUNT); }
+static inline bool sort_in_blend_on(int flags) { return !(flags & (EGS_CALL_SEPARATE_SORT | EGS_CALL_SYNC)); }     // (SYNC checks after every launch: keep them apart)
+static inline int cull_on(int flags) { return (flags & EGS_CALL_KEEP_ALL_INSTANCES) ? 0 : 1; }
+int egs_forward_fuses_count(int P, int width, int height, int flags) { return (fused_count_on(flags) && egs_can_fuse_count(P, width, height, cull_on(flags))) ? 1 : 0; }
 
 const char* egs_error_string(int code) {
     switch (code) {
@@ -229,33 +222,24 @@ size_t egs_placement_bytes(int width, int height) {
     const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
     return egs_align(placement_sums_offset(nt) + placement_sums_words(nt) * sizeof(uint32_t));
 }
-// Which placement buffers hold ZERO chunk sums (egs_placement_init, or a complete fused chain of this library): the first fused forward
-// that meets an unknown address clears the sums with a launch of its own.
-static std::mutex g_placement_mu;
-static std::unordered_map<const void*, uint64_t> g_placement_clean;       // address -> (width << 32 | height) it was cleared for: the sums region's offset depends on the tile count
+// The sums region of a placement buffer must be ZERO when a fused forward starts: egs_placement_init() once per (buffer, image size), the
+// chain itself leaves it zero again (include/egs_raster.h).  The library keeps no record of buffers (ABI 6; through ABI 5 a process-wide
+// map of "clean" addresses stood here, which a freed-and-reallocated address could fool).
 int egs_placement_init(void* placement, int width, int height, void* stream) {
     if (!placement || check_dims(0, width, height)) return EGS_ERR_ARG;
     const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
     EGS_TRY(egs_launch_zero_u32((uint32_t*)((char*)placement + placement_sums_offset(nt)), placement_sums_words(nt), (hipStream_t)stream));
-    std::lock_guard<std::mutex> lk(g_placement_mu);
-    g_placement_clean[placement] = ((uint64_t)(uint32_t)width << 32) | (uint32_t)height;
     return 0;
 }
-// A chain that fails between the fused count pass and the sort launch that clears the sums leaves them dirty: the address is forgotten, and
-// the next forward that is handed this buffer clears it first.
-struct PlacementDirtyOnError {
-    const void* p = nullptr;
-    ~PlacementDirtyOnError() { if (p) { std::lock_guard<std::mutex> lk(g_placement_mu); g_placement_clean.erase(p); } }
+// A chain that fails between the fused count pass and the launch that clears the sums would leave them dirty for the next frame: the failing
+// call clears them itself on its way out (best effort; the caller gets the error code either way).
+struct PlacementClearOnError {
+    void* p = nullptr; int w = 0, h = 0; hipStream_t s = nullptr;
+    ~PlacementClearOnError() { if (p) (void)egs_placement_init(p, w, h, (void*)s); }
 };
-// -> the sums region if the fused count pass may use it now (cleared first when the address is new)
-static int placement_sums(void* placement, int width, int height, hipStream_t s, uint32_t** sums, uint32_t* words) {
+static void placement_sums(void* placement, int width, int height, uint32_t** sums, uint32_t* words) {
     const size_t nt = (size_t)((width + EGS_TILE - 1) / EGS_TILE) * (size_t)((height + EGS_TILE - 1) / EGS_TILE);
-    bool known;
-    { std::lock_guard<std::mutex> lk(g_placement_mu); auto it = g_placement_clean.find(placement);
-      known = it != g_placement_clean.end() && it->second == (((uint64_t)(uint32_t)width << 32) | (uint32_t)height); }
-    if (!known) { const int rc = egs_placement_init(placement, width, height, (void*)s); if (rc) return rc; }
     *sums = (uint32_t*)((char*)placement + placement_sums_offset(nt)); *words = (uint32_t)placement_sums_words(nt);
-    return 0;
 }
 int egs_order_words(int width, int height) {
     if (width <= 0 || height <= 0) return 0;
@@ -368,14 +352,14 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
     placement_ptrs(placement, width, height, im_spec);
     // With a persistent placement buffer the count pass of the bucketing rides in the preprocess launch (k_preprocess_count) and adds its
     // chunk sums into that buffer's sums region, which is zero between frames (egs_common.h EgsBinPtrs); egs_debug_set_fused_count: A/B switch
-    const bool fuse = capacity > 0 && placement && fused_count_on() && egs_can_fuse_count(P, width, height);
-    PlacementDirtyOnError dirty_guard;
+    const bool fuse = capacity > 0 && placement && fused_count_on(debug) && egs_can_fuse_count(P, width, height, cull_on(debug));
+    PlacementClearOnError dirty_guard;
     if (fuse) {
-        dirty_guard.p = placement;                                   // (disarmed once the bucketing chain is enqueued)
-        rc = placement_sums(placement, width, height, s, &b_spec.chunk_sum, &b_spec.zero_after_n); if (rc) return rc;
+        dirty_guard.p = placement; dirty_guard.w = width; dirty_guard.h = height; dirty_guard.s = s;      // (disarmed once the bucketing chain is enqueued)
+        placement_sums(placement, width, height, &b_spec.chunk_sum, &b_spec.zero_after_n);
         b_spec.zero_after = b_spec.chunk_sum;
         EGS_TRY(egs_launch_preprocess_count(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
-                                            rotations, activation_flags, cov3D_precomp, cam, radii, g, b_spec, active_count, &im_spec, orot, s));
+                                            rotations, activation_flags, cov3D_precomp, cam, radii, g, b_spec, active_count, &im_spec, orot, cull_on(debug), s));
     } else
     EGS_TRY(egs_launch_preprocess(P, sh_degree, sh_coeffs, means3D, sh_apart ? nullptr : shs, colors_precomp, opacities, scales, scale_modifier,
                                   rotations, activation_flags, cov3D_precomp, cam, radii, g, capacity > 0 ? b_spec.chunk_sum : nullptr, n_sums,
@@ -391,7 +375,8 @@ static int forward_impl(int wait_for_count, int P, int sh_degree, int sh_coeffs,
         // the per-tile sort inside the forward blend's launch (render_fwd.hip SORT): egs_launch_binning then makes no sort launch and says what the
         // blend needs; with the sums of a fused count pass to clear, a failure before the blend is enqueued leaves them dirty (dirty_guard)
         EgsSortArgs sort_args = {};
-        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, overflow_flag, 1, fuse ? 1 : 0, sort_in_blend_on() ? &sort_args : nullptr, s, 0));
+        EGS_TRY(egs_launch_binning(P, capacity, width, height, g, b, im, running_max, overflow_flag, 1, fuse ? 1 : 0,
+                                   !(debug & EGS_CALL_SEPARATE_SORT) ? &sort_args : nullptr, s, debug & ~EGS_CALL_SYNC));      // (speculative chain: never synchronised mid-way)
         egs_prof_start(EGS_K_RENDER_FWD, s);
         EGS_TRY(egs_launch_render_forward(width, height, background, g, b.point_list, im, out_color, out_depth, out_alpha, placement ? 1 : 0, &sort_args, s));
         dirty_guard.p = nullptr;
@@ -435,12 +420,12 @@ int egs_forward_enqueue(int P, int sh_degree, int sh_coeffs, const float* means3
                         const float* background, int width, int height, float tan_fovx, float tan_fovy, int prefiltered,
                         int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
                         float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
-                        const int32_t* active_count, uint32_t* overflow_flag, void* placement, const egs_object_rotation* rot, void* stream) {
+                        const int32_t* active_count, uint32_t* overflow_flag, void* placement, const egs_object_rotation* rot, void* stream, int flags) {
     int64_t unused = 0;
     return forward_impl(0, P, sh_degree, sh_coeffs, means3D, shs, shs_rest, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, activation_flags, viewmatrix, projmatrix, campos, background, width, height, tan_fovx, tan_fovy, prefiltered,
                         radii, geom_buffer, capacity, binning_buffer, image_buffer, out_color, out_depth, out_alpha,
-                        pinned_host_counts, running_max, &unused, active_count, overflow_flag, placement, rot, stream, 0);
+                        pinned_host_counts, running_max, &unused, active_count, overflow_flag, placement, rot, stream, flags & ~EGS_CALL_SYNC);      // (nothing may wait: capturable)
 }
 
 int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts) {
@@ -464,7 +449,7 @@ int egs_forward_render(int P, int64_t R, const float* background, int width, int
     EgsBinPtrs b = bin_ptrs(binning_buffer, P, R, width, height);
     EgsImgPtrs im = img_ptrs(image_buffer, width, height);
     EgsSortArgs sort_args = {};
-    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, nullptr, nullptr, 0, 0, (sort_in_blend_on() && !debug) ? &sort_args : nullptr, s, debug));
+    EGS_TRY(egs_launch_binning(P, R, width, height, g, b, im, nullptr, nullptr, 0, 0, sort_in_blend_on(debug) ? &sort_args : nullptr, s, debug));
     const uint32_t* point_list = b.point_list;
     egs_prof_start(EGS_K_RENDER_FWD, s);
     EGS_TRY(egs_launch_render_forward(width, height, background, g, point_list, im, out_color, out_depth, out_alpha, 0, &sort_args, s));

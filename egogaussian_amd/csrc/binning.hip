@@ -29,8 +29,6 @@
 #include "bin_walk.h"
 #include <atomic>
 
-int egs_tile_culling = 1;           // egs_debug_set_tile_culling: 0 keeps every instance of the reference's rectangles
-int egs_force_ballot_rank = 0;      // test hook (egs_debug_force_ballot_rank): exercise the fallback ranking
 
 namespace {
 
@@ -323,11 +321,10 @@ int egs_bin_gpb(int P) { const int k = (P + 256 * EGS_BIN_TARGET_BLOCKS - 1) / (
 uint32_t egs_bin_blocks(int P) { const int g = egs_bin_gpb(P); return (uint32_t)((P + g - 1) / g); }
 
 // Launch geometry of the bucketing kernels for a model of P Gaussians at W x H (also used by preprocess.hip's fused count pass).
-EgsBinGeometry egs_bin_geometry(int P, int W, int H) {
+EgsBinGeometry egs_bin_geometry(int P, int W, int H, int cull) {
     EgsBinGeometry q;
     q.gx = (W + EGS_TILE - 1) / EGS_TILE; q.n_tiles = q.gx * ((H + EGS_TILE - 1) / EGS_TILE);
     q.nblocks = egs_bin_blocks(P);
-    int cull = egs_tile_culling;
     // per-tile counters, then (16-byte aligned) the round's set-up block; fewer groups per round, then no culling, when
     // the counters leave too little of the 160 KiB (beyond ~28k tiles)
     const size_t counters = (size_t)((q.n_tiles + 3) & ~3) * sizeof(uint32_t), room = 160 * 1024 - counters;
@@ -357,9 +354,10 @@ EgsBinGeometry egs_bin_geometry(int P, int W, int H) {
 // sort_in_blend (may be NULL): filled with what the forward blend needs to sort its tiles itself -- then no sort launch is made here
 // (table_scanned == NULL in it: not taken, e.g. a second sort instantiation would be needed)
 hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
-                              uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, int counted, EgsSortArgs* sort_in_blend, hipStream_t s, int debug) {
+                              uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, int counted, EgsSortArgs* sort_in_blend, hipStream_t s, int call_flags) {
+    const int debug = call_flags & EGS_CALL_SYNC;
     if (sort_in_blend) sort_in_blend->table_scanned = nullptr;
-    const EgsBinGeometry q = egs_bin_geometry(P, W, H);
+    const EgsBinGeometry q = egs_bin_geometry(P, W, H, (call_flags & EGS_CALL_KEEP_ALL_INSTANCES) ? 0 : 1);
     const int gx = q.gx, n_tiles = q.n_tiles;
     if (R64 == 0 || P == 0) {
         if (overflow_flag) { hipError_t e = egs_launch_zero_u32(overflow_flag, 2, s); if (e != hipSuccess) return e; }
@@ -410,7 +408,7 @@ hipError_t egs_launch_binning(int P, int64_t R64, int W, int H, EgsGeomPtrs g, E
         fast = bad == 0 ? 1 : 0;
         lds_rank_ok.store(fast);
     }
-    if (egs_force_ballot_rank) fast = 0;
+    if (call_flags & EGS_CALL_BALLOT_RANK) fast = 0;
     const int ip = (index_bits + TS_DBITS - 1) / TS_DBITS;
     // A launch costs ~4.5 us of GPU time even when every workgroup returns at once.  When the buffer holds on average at most 2048
     // instances per tile (R is the capacity: >= 1.25 x the rectangle count, itself ~1.5 x what survives culling) no tile is expected

@@ -112,7 +112,7 @@ static inline size_t egs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 uint32_t egs_bin_blocks(int P);
 int egs_bin_gpb(int P);                                          // Gaussians per bucketing workgroup for a model of P Gaussians
 struct EgsBinGeometry { uint32_t nblocks, stride, n_chunks; int gpr, cull, use_map, n_tiles, gx; size_t lds; };
-EgsBinGeometry egs_bin_geometry(int P, int W, int H);           // launch geometry of the bucketing kernels (binning.hip)
+EgsBinGeometry egs_bin_geometry(int P, int W, int H, int cull);  // launch geometry of the bucketing kernels (binning.hip); cull: tile culling wanted (EGS_CALL_KEEP_ALL_INSTANCES clear)
 #define EGS_SCAN_THREADS 256
 #define EGS_SCAN_ITEMS 8
 #define EGS_SCAN_EPB (EGS_SCAN_THREADS * EGS_SCAN_ITEMS)      // elements per block
@@ -207,14 +207,14 @@ struct EgsSortArgs {
 // counted: b.table and b.chunk_sum were filled by egs_launch_preprocess_count (the count pass is not launched)
 // sort_in_blend (may be NULL): see binning.hip
 hipError_t egs_launch_binning(int P, int64_t R, int W, int H, EgsGeomPtrs g, EgsBinPtrs b, EgsImgPtrs im,
-                              uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, int counted, EgsSortArgs* sort_in_blend, hipStream_t s, int debug);
+                              uint64_t* running_max, uint32_t* overflow_flag, int sums_zeroed, int counted, EgsSortArgs* sort_in_blend, hipStream_t s, int call_flags /* EGS_CALL_* */);
 // k_preprocess + the count pass of the tile bucketing in ONE launch (preprocess.hip); b.chunk_sum must be ZERO (see EgsBinPtrs).
 // -> false when the launch geometry does not allow it (fewer than four groups per round: very large images)
-bool egs_can_fuse_count(int P, int W, int H);
+bool egs_can_fuse_count(int P, int W, int H, int cull);
 hipError_t egs_launch_preprocess_count(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
                                        const float* opac, const float* scales, float mod, const float* rots, int act,
                                        const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, EgsBinPtrs b,
-                                       const int32_t* active_count, const EgsImgPtrs* place, EgsObjRot rot, hipStream_t s);
+                                       const int32_t* active_count, const EgsImgPtrs* place, EgsObjRot rot, int cull, hipStream_t s);
 // placed: im.fwd_order holds this frame's placement (the preprocess launch carried the ordering job); else the static mapping
 // sort (may be NULL, or table_scanned == NULL in it): the blend sorts every tile's bucket itself first (egs_launch_binning made no sort launch)
 hipError_t egs_launch_render_forward(int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
@@ -230,7 +230,9 @@ hipError_t egs_launch_backward_prologue(int P, int W, int H, EgsImgPtrs im, floa
 struct EgsLossGradHost { const float* img; const float* gt; const float* dm_dmu1; const float* dm_dexx; const float* dm_dexy; const float* gate;
                          const float* upstream; const float* upstream_ssim; float w_l1_n, w_ssim_n;
                          const float* fin_partial; size_t fin_n; float fin_lambda; float* fin_loss; float* fin_running; };
+#ifdef EGS_LG_CHECK
 extern EgsLossGradHost egs_debug_lossgrad;
+#endif
 hipError_t egs_launch_loss_finish(const EgsLossGradHost& lg, int W, int H, hipStream_t s);     // the deferred value alone (a frame with no instance)
 // lg (may be NULL): the blend computes dL/dcolour itself (k_render_backward<1, true>); dL_dcolor, dL_ddepth, dL_dalpha are then not read
 hipError_t egs_launch_render_backward(int P, int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
@@ -248,5 +250,3 @@ hipError_t egs_launch_zero_u32(uint32_t* p, size_t n, hipStream_t s);
 // optional stage timing (api.hip); no-ops unless egs_profile_begin() was called
 void egs_prof_start(int stage, hipStream_t s);
 void egs_prof_stop(int stage, hipStream_t s);
-extern int egs_force_ballot_rank;
-extern int egs_tile_culling;

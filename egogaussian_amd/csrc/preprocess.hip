@@ -1284,9 +1284,9 @@ hipError_t egs_launch_preprocess(int P, int D, int M, const float* means3D, cons
     return hipGetLastError();
 }
 
-bool egs_can_fuse_count(int P, int W, int H) {
+bool egs_can_fuse_count(int P, int W, int H, int cull) {
     if (P <= 0) return false;
-    const EgsBinGeometry q = egs_bin_geometry(P, W, H);
+    const EgsBinGeometry q = egs_bin_geometry(P, W, H, cull);
     // one round only: the looped instantiation holds the projection's inputs through the walk and spills (1M @ 1080p, four rounds of eight
     // groups: 116 + 151 us against 34 + 214 with the separate count pass) -- EGS_FUSE_MULTI_ROUND=1 lets it run all the same (measurements)
     static const bool multi = getenv("EGS_FUSE_MULTI_ROUND") != nullptr;
@@ -1296,8 +1296,8 @@ bool egs_can_fuse_count(int P, int W, int H) {
 hipError_t egs_launch_preprocess_count(int P, int D, int M, const float* means3D, const float* shs, const float* colors,
                                        const float* opac, const float* scales, float mod, const float* rots, int act,
                                        const float* cov3D, EgsCamera cam, int32_t* radii, EgsGeomPtrs g, EgsBinPtrs b,
-                                       const int32_t* active_count, const EgsImgPtrs* place, EgsObjRot rot, hipStream_t s) {
-    const EgsBinGeometry q = egs_bin_geometry(P, cam.W, cam.H);
+                                       const int32_t* active_count, const EgsImgPtrs* place, EgsObjRot rot, int cull, hipStream_t s) {
+    const EgsBinGeometry q = egs_bin_geometry(P, cam.W, cam.H, cull);
     EgsPreArgs a = { P, D, M, means3D, shs, colors, opac, scales, mod, rots, cov3D, act, cam.view, cam.proj, cam.campos, cam.W, cam.H, cam.tanfovx, cam.tanfovy,
                      radii, g.rec, g.rect, g.offsets, g.clamped, g.visible, g.scan_scratch, g.block_hot, active_count };
     EgsCountArgs c = { q.gpr, q.gx, q.n_tiles, q.nblocks, q.cull, q.use_map, b.table, q.stride, b.chunk_sum };

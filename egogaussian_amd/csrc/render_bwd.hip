@@ -349,7 +349,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 }  // namespace
 
-EgsLossGradHost egs_debug_lossgrad = {};
+#ifdef EGS_LG_CHECK
+EgsLossGradHost egs_debug_lossgrad = {};       // (debug build only, tools/dev/lg_check.py: the product library keeps no such state)
+#endif
 namespace {
 __global__ __launch_bounds__(64) void k_loss_finish(size_t n, const float* __restrict__ partial, float w_l1, float w_ssim, float lambda, float* loss, float* running) {
     wave_finish_loss(n, partial, w_l1, w_ssim, lambda, loss, running, threadIdx.x);
@@ -383,7 +385,9 @@ hipError_t egs_launch_backward_prologue(int P, int W, int H, EgsImgPtrs im, floa
 hipError_t egs_launch_render_backward(int P, int W, int H, const float* bg, EgsGeomPtrs g, const uint32_t* point_list,
                                       EgsImgPtrs im, const float* dL_dcolor, const float* dL_ddepth,
                                       const float* dL_dalpha, float* grad_acc, int colors_only, const EgsLossGradHost* lg, hipStream_t s) {
+#ifdef EGS_LG_CHECK
     if (!lg && egs_debug_lossgrad.img) lg = &egs_debug_lossgrad;      // (experiment hook: egs_debug_set_lossgrad)
+#endif
     const int gx = (W + EGS_TILE - 1) / EGS_TILE, gy = (H + EGS_TILE - 1) / EGS_TILE;
     const int n_tiles = gx * gy;
     if (n_tiles == 0) return hipSuccess;

@@ -198,7 +198,7 @@ def _apply(gaussians, plan, reset_stats, z=None, curr_gen=None, during_training=
 def densify_and_prune(gaussians, max_grad, min_opacity, extent, max_screen_size, clone=True, split=True, curr_gen=None,
                       prune_prev_gen=True, split_prev_gen=True, which_object=None, z=None, generator=None):
     """Same arguments as GaussianModel.densify_and_prune (:678).  `z` ([2 * n_split, 3] standard-normal draws, first children
-    first) makes the split deterministic; by default it is drawn here with `generator`.  Returns (n_before, n_after)."""
+    first -- or a callable rows -> such a tensor) makes the split deterministic; by default it is drawn here with `generator`.  Returns (n_before, n_after)."""
     if not split_prev_gen and split:
         raise NotImplementedError("split_prev_gen=False: the reference raises here (curr_gen lands in densify_and_split's N slot, "
                                   "gaussian_model.py:698 vs :588); there is no behaviour to reproduce")
@@ -226,6 +226,8 @@ def densify_and_prune(gaussians, max_grad, min_opacity, extent, max_screen_size,
     if plan.n_split:
         if z is None:
             z = torch.randn((2 * plan.n_split, 3), device=dev, generator=generator)
+        elif callable(z):
+            z = z(2 * plan.n_split).to(dev)                          # z(rows) -> [rows, 3]: the caller's draws, sized once the plan is known
         z = _hip(z, "z").float().contiguous()
         if tuple(z.shape) != (2 * plan.n_split, 3):
             raise ValueError(f"z must be [{2 * plan.n_split}, 3] (two children per split Gaussian), got {tuple(z.shape)}")

@@ -8,8 +8,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EGS_RASTER_LIB", os.path.join(_HERE, "libegs_raster.so"))      # override for A/B builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 RETRY_LARGER = -100
+# per-call flags (include/egs_raster.h EGS_CALL_*, ABI 6): bits of the `debug` / `flags` word of the forwards
+CALL_SYNC, CALL_KEEP_ALL_INSTANCES, CALL_SEPARATE_COUNT, CALL_SEPARATE_SORT, CALL_BALLOT_RANK = 1, 2, 4, 8, 16
 
 vp, f32, i32, i64 = C.c_void_p, C.c_float, C.c_int, C.c_int64
 
@@ -72,7 +74,7 @@ SIGNATURES = {
     "egs_forward": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, i64,
                                vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp, vp, C.POINTER(ObjectRotation), vp, i32]),
     "egs_forward_enqueue": (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp,
-                                       i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(ObjectRotation), vp]),
+                                       i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(ObjectRotation), vp, i32]),
     "egs_placement_bytes": (C.c_size_t, [i32, i32]),
     "egs_placement_init": (C.c_int, [vp, i32, i32, vp]),
     "egs_sum_counts": (C.c_int64, [i32, vp]),
@@ -110,11 +112,7 @@ SIGNATURES = {
     "egs_knn3_mean_dist2": (C.c_int, [i32, vp, vp, vp]),
     "egs_knn3_grid_scratch_bytes": (C.c_size_t, [i32]),
     "egs_knn3_grid": (C.c_int, [i32, vp, vp, vp, vp]),
-    "egs_debug_force_ballot_rank": (C.c_int, [i32]),
-    "egs_debug_set_tile_culling": (C.c_int, [i32]),
-    "egs_debug_set_fused_count": (C.c_int, [i32]),
-    "egs_forward_fuses_count": (C.c_int, [i32, i32, i32]),
-    "egs_debug_set_sort_in_blend": (C.c_int, [i32]),
+    "egs_forward_fuses_count": (C.c_int, [i32, i32, i32, i32]),
     "egs_profile_begin": (C.c_int, [i32]),
     "egs_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "egs_profile_stage_name": (C.c_char_p, [i32]),

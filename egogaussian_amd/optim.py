@@ -14,6 +14,12 @@ from . import lib as _lib
 from . import _hip
 
 
+
+def _touched(p):
+    """A kernel of this library wrote parameter `p` in place through its raw pointer: tell autograd (the tensor's version counter is what
+    saved-tensor checks, and provenance.py's "raw parameters unchanged since the activation" test, go by)."""
+    torch.autograd.graph.increment_version(p)
+
 class AdamSink:
     """The per-Gaussian leaves of a FusedAdam(capturable=True) that ONE rasterizer backward steps itself (include/egs_raster.h,
     egs_backward_adam): built by FusedAdam.make_sink() for the tensors of one render call, consumed by that call's backward.
@@ -32,6 +38,7 @@ class AdamSink:
         if self._opt is not None:
             for p in self._params:
                 self._opt._sunk[p] = bool(self.keep_grads)
+                _touched(p)
             # k_adam's own per-workgroup step counters do not follow a step taken here (only state["step"] advances): the next
             # plain step() of this parameter re-seeds them.  Set on EVERY fused backward -- a cached sink (make_sink hit) after a
             # plain step() cleared the flag would otherwise leave the counters one behind.
@@ -272,6 +279,8 @@ class FusedAdam(torch.optim.Optimizer):
                 _lib.check(L.egs_adam_step_capturable(n, arr(0), arr(1), arr(2), arr(3), NN, arr(4), arr(5), arr(6), float(betas[0]),
                                                       float(betas[1]), float(eps), skip, rows, RF if rows is not None else None,
                                                       _hip.stream_of(dev)))
+            for t in items:
+                _touched(t[0])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -325,4 +334,6 @@ class FusedAdam(torch.optim.Optimizer):
             with _hip.device_ctx(dev):
                 _lib.check(L.egs_adam_step(n, PP, GG, MM, VV, NN, LR, ST, float(betas[0]), float(betas[1]), float(eps),
                                            _hip.stream_of(dev)))
+            for t in items:
+                _touched(t[0])
         return loss

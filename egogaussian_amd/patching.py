@@ -127,7 +127,20 @@ def install(loss=True, model=True, optimizer=True, capturable=False):
             training_setup.__wrapped__ = orig_train
             cls.training_setup = training_setup
             report["model"].append("scene.gaussian_model.GaussianModel.training_setup")
-        saved["model"] = (cls, orig_setup, orig_train)
+        # get_features (gaussian_model.py:157-160) is a property of the class: its concatenation remembers its two halves for models that
+        # adapter.attach() marked (provenance.py: the rasterizer then takes the halves, no copy either way)
+        orig_feat = cls.__dict__.get("get_features")
+        if model and isinstance(orig_feat, property):
+            from .provenance import tag_features
+
+            def get_features(self, _fget=orig_feat.fget):
+                f = _fget(self)
+                if getattr(self, "_egs_tag_features", False):
+                    tag_features(f, self._features_dc, self._features_rest)
+                return f
+            cls.get_features = property(get_features)
+            report["model"].append("scene.gaussian_model.GaussianModel.get_features")
+        saved["model"] = (cls, orig_setup, orig_train, orig_feat)
     _STATE.update(installed=True, saved=saved, report=report)
     return report
 
@@ -141,6 +154,8 @@ def uninstall():
         lu.l1_loss, lu.ssim = orig_l1, orig_ssim
         _rebind(l1_new, orig_l1, (lu,)); _rebind(ssim_new, orig_ssim, (lu,))
     if "model" in saved:
-        cls, orig_setup, orig_train = saved["model"]
+        cls, orig_setup, orig_train, orig_feat = saved["model"]
         cls.setup_functions, cls.training_setup = orig_setup, orig_train
+        if isinstance(orig_feat, property):
+            cls.get_features = orig_feat
     _STATE.clear()

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
+from . import provenance as _provenance
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -195,6 +196,16 @@ class GaussianRasterizer(nn.Module):
         # whose loss reads the colour image only)
         # After the call `self.visible` holds radii > 0 as a bool view the preprocess kernel wrote (no compare launch); it aliases
         # state saved for the backward and, under hipGraph replay, follows every replay -- clone it to keep or edit it.
+        # The reference's own render() hands over ACTIVATED tensors (opacities = get_opacity, cov3D_precomp = get_covariance(...), shs =
+        # get_features).  When those are the untouched results of getters installed by adapter.attach() (provenance.py), the raw parameters
+        # they were computed from are rasterized instead: same image and gradients to float rounding, without the activation / covariance /
+        # concatenation backward launches and their autograd nodes.
+        if cov3D_precomp is not None and scales is None and rotations is None and not raw_parameters and object_rotation is None:
+            sub = _provenance.substitute(opacities, cov3D_precomp, shs, self.raster_settings.scale_modifier)
+            if sub is not None:
+                scales, rotations, opacities, shs, object_rotation = sub["scales"], sub["rotations"], sub["opacities"], sub["shs"], sub["object_rotation"]
+                cov3D_precomp, raw_parameters = None, True
+                _provenance.substitutions += 1
         shs_rest = None
         if isinstance(shs, (tuple, list)):
             shs, shs_rest = shs

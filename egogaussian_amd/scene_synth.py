@@ -140,6 +140,7 @@ class SynthGaussians:
         self.denom = torch.zeros((n, 1), device=device)
         self.percent_dense = 0.01
         self.optimizer = None
+        self.scaling_activation, self.opacity_activation, self.rotation_activation = torch.exp, torch.sigmoid, torch.nn.functional.normalize
         self.active_sh_degree = sh_degree
         self.max_sh_degree = sh_degree
         self.trainable_object_move = None
@@ -163,17 +164,23 @@ class SynthGaussians:
 
     @property
     def get_xyz(self): return self._xyz
+    # (the activations are attributes, as setup_functions leaves them on the reference's model, gaussian_model.py:36-44: what
+    # adapter.attach() replaces)
     @property
-    def get_scaling(self): return torch.exp(self._scaling)
+    def get_scaling(self): return self.scaling_activation(self._scaling)
     @property
-    def get_rotation(self): return torch.nn.functional.normalize(self._rotation)
+    def get_rotation(self): return self.rotation_activation(self._rotation)
     @property
-    def get_opacity(self): return torch.sigmoid(self._opacity)
+    def get_opacity(self): return self.opacity_activation(self._opacity)
     @property
     def get_features(self):
         if self._features_rest.shape[1] == 0:                # SH degree 0: nothing to concatenate (torch.cat would still copy)
             return self._features_dc
-        return torch.cat((self._features_dc, self._features_rest), dim=1)
+        f = torch.cat((self._features_dc, self._features_rest), dim=1)
+        if getattr(self, "_egs_tag_features", False):        # adapter.attach(provenance=True); patching.install() does this for the reference's class
+            from .provenance import tag_features
+            tag_features(f, self._features_dc, self._features_rest)
+        return f
     @property
     def get_label(self): return self._label
     @property

@@ -28,11 +28,11 @@
  *   - The opaque geometry / binning / image buffers must start at 256-byte-aligned addresses (hipMalloc and the PyTorch allocator
  *     give at least that); a misaligned one is refused with EGS_ERR_ARG.  Their layouts place every array at a 256-byte offset.
  *   - Process-wide state, all of it: (1) the optional profiling pool (egs_profile_begin / egs_profile_end), off by
- *     default; (2) the two debug switches egs_debug_set_tile_culling / egs_debug_force_ballot_rank (plain ints read
- *     by every subsequent forward of the process; neither changes an output value); (3) the result of the one-time
- *     device check behind the tile sort's ranker (an atomic int); (4) one hipEvent per calling thread inside
- *     egs_forward (thread_local).  Nothing else is kept between calls; concurrent calls on different streams /
- *     threads are safe as long as they do not flip the debug switches meanwhile.
+ *     default; (2) the result of the one-time device check behind the tile sort's ranker (an atomic int: a property of
+ *     the hardware, the same for every caller); (3) one hipEvent per calling thread inside egs_forward (thread_local).
+ *     Nothing else is kept between calls -- no switches, no registry of buffers (ABI 6: what were process-wide debug
+ *     switches through ABI 5 are bits of the call's own flags word, EGS_CALL_* below; a placement buffer is initialised
+ *     by its owner, egs_placement_init).  Concurrent calls on different streams / threads with different settings are safe.
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it.  egs_forward_geometry is
  *     the only call that waits on the stream (one 8-byte device->host read of R).
  *   - Matrices use the reference's row-vector layout (/root/reference/scene/cameras.py:67-69):
@@ -41,7 +41,8 @@
  *     {cov3D_precomp, (scales, rotations)} must be non-NULL.
  *   - Return value: 0 on success; EGS_ERR_* (negative) for argument errors; a positive hipError_t if
  *     the HIP runtime reported one.  Nothing throws across this boundary.
- *   - debug != 0 synchronises the stream and checks for errors after every kernel.
+ *   - The last argument of every compute entry point (`debug`; `flags` on egs_forward_enqueue) is a set of EGS_CALL_* bits.  Bit 0
+ *     (EGS_CALL_SYNC -- what debug != 0 meant through ABI 5) synchronises the stream and checks for errors after every kernel.
  */
 #ifndef EGS_RASTER_H
 #define EGS_RASTER_H
@@ -53,10 +54,27 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 5          /* 5: the placement buffer grew a sums region (egs_placement_bytes) that must be ZERO when the buffer is first handed over:
+#define EGS_ABI_VERSION 6          /* 6: per-call flags (EGS_CALL_*) instead of the process-wide egs_debug_set_* switches, egs_forward_enqueue takes a flags word,
+                                         egs_placement_init is the ONLY thing that clears a placement buffer's sums region (no registry of addresses);
+                                         5: the placement buffer grew a sums region (egs_placement_bytes) that must be ZERO when the buffer is first handed over:
                                          egs_placement_init;  4: grad_mask on the backwards, egs_l1_ssim_pair_*, out_depth / out_alpha may both be NULL on every
                                          forward (colour only) */
 #define EGS_TILE 16                 /* tile edge in pixels; part of the parity contract */
+
+/* Per-call flags (ABI 6).  None of them changes an output value: colour, depth, alpha, radii, final transmittance and every gradient are
+ * bit-identical whatever the bits; they select which launches produce them (and, for KEEP_ALL_INSTANCES, what the internal lists hold). */
+#define EGS_CALL_SYNC               0x01   /* synchronise the stream and check for errors after every kernel (debugging) */
+#define EGS_CALL_KEEP_ALL_INSTANCES 0x02   /* no tile culling.  By default an instance (splat, tile) of the reference's 3-sigma rectangle is dropped
+                                              when no pixel of the tile can receive alpha >= 1/255 from the splat (exact, conservative ellipse-vs-tile
+                                              test): the reference skips such an instance at every pixel, so only the internal lists (binning buffer,
+                                              per-pixel contributor positions) get shorter; `num_rendered` stays the reference's count.  With this bit
+                                              every instance is kept and the lists are comparable bit for bit with the reference algorithm's (parity
+                                              tests).  Give the SAME bit to the forward and to nothing else: the backward reads the lists as they are. */
+#define EGS_CALL_SEPARATE_COUNT     0x04   /* the count pass of the tile bucketing as a launch of its own even when a placement buffer would let it
+                                              ride in the preprocess launch (A/B measurements, tests) */
+#define EGS_CALL_SEPARATE_SORT      0x08   /* the per-tile sort as launch(es) of its own instead of inside the forward blend's launch */
+#define EGS_CALL_BALLOT_RANK        0x10   /* the per-tile sort ranks keys with the ballot-based fallback instead of the LDS atomic whose lane-order
+                                              behaviour is verified on the device once per process (test hook: covers the fallback) */
 #define EGS_MAX_SH_DEGREE 3
 
 #define EGS_ERR_ARG        (-1)     /* NULL / inconsistent arguments */
@@ -210,11 +228,12 @@ int egs_forward(
  * otherwise.  One buffer per concurrently running forward (it is read and written by the call).  NULL: the static tile mapping.
  * ABI 5: given a placement buffer, the forward also folds the count pass of its tile bucketing into the preprocess launch (one launch and
  * one round of set-up loads less per frame); that pass accumulates per-chunk instance sums in the tail of the buffer, which the chain
- * itself clears again before it ends.  Those words must therefore be ZERO when a buffer is handed over for the first time -- a zero-filled
- * allocation, or egs_placement_init() -- and the memory must not be used for anything else between calls.  (The first forward that meets
- * an address it has not seen -- or has seen with another image size: the region's offset follows the tile count -- clears the words with a
- * launch of its own, and so does the first one after a forward that failed half way; the tile-order words in front of them may hold anything -- they
- * decide when a quadrant is blended, never what is computed.)  Results are identical with and without a placement buffer. */
+ * itself clears again before it ends.  Those words must therefore be ZERO when a forward starts: the owner calls egs_placement_init()
+ * (one small launch on `stream`) ONCE per buffer and image size -- after allocating it, and again before using it for another image size
+ * (the region's offset follows the tile count) -- and does not use the memory for anything else between calls.  The library keeps no
+ * record of buffers (ABI 6): a forward that finds stale sums counts wrongly.  A forward that fails half way clears the words itself before
+ * it returns its error.  The cost and tile-order words in front of the sums may hold anything -- they decide when a quadrant is blended,
+ * never what is computed.  Results are identical with and without a placement buffer. */
 size_t egs_placement_bytes(int width, int height);
 int egs_placement_init(void* placement, int width, int height, void* stream);
 
@@ -236,7 +255,7 @@ int egs_forward_enqueue(
     int32_t* radii, void* geom_buffer, int64_t capacity, void* binning_buffer, void* image_buffer,
     float* out_color, float* out_depth, float* out_alpha, uint32_t* pinned_host_counts, uint64_t* running_max,
     const int32_t* active_count /*device int32[1] or NULL*/, uint32_t* overflow_flag /*device uint32[2] out or NULL*/,
-    void* placement /*or NULL*/, const egs_object_rotation* rot /*HOST or NULL*/, void* stream);
+    void* placement /*or NULL*/, const egs_object_rotation* rot /*HOST or NULL*/, void* stream, int flags /*EGS_CALL_*; EGS_CALL_SYNC is ignored: nothing may wait*/);
 int64_t egs_sum_counts(int P, const uint32_t* pinned_host_counts /*HOST*/);
 
 /* ---- backward  (upstream: render backward + computeCov2D backward + preprocess backward) ------- */
@@ -528,26 +547,9 @@ int egs_knn3_mean_dist2(int N, const float* points /*[N,3]*/, float* mean_dist2 
 size_t egs_knn3_grid_scratch_bytes(int N);
 int egs_knn3_grid(int N, const float* points /*[N,3]*/, float* mean_dist2 /*[N] out*/, void* scratch, void* stream);
 
-/* Test hook: the per-tile sort ranks keys with an LDS atomic whose lane-order behaviour is verified on the device once per
- * process; on != 0 forces the ballot-based fallback so that tests can cover it.  Returns the previous setting. */
-int egs_debug_force_ballot_rank(int on);
-
-/* Tile culling (default on): an instance (splat, tile) of the reference's 3-sigma rectangle is dropped when no pixel of the
- * tile can receive alpha >= 1/255 from the splat (exact, conservative ellipse-vs-tile test).  The reference skips such an
- * instance at every pixel, so colour, depth, alpha, final transmittance and all gradients are bit-identical either way;
- * only the internal lists (binning buffer, per-pixel contributor positions) get shorter.  `num_rendered` stays the
- * reference's count.  on == 0 keeps every instance, which makes the internal lists comparable bit for bit with the
- * reference algorithm's (used by the parity tests).  Returns the previous setting; applies to subsequent forwards. */
-int egs_debug_set_tile_culling(int on);
-/* 1 (default): a forward given a placement buffer folds the count pass of its bucketing into the preprocess launch (see the placement
- * buffer above); 0: the two launches of ABI <= 4.  Lists, images and gradients are the same either way (tests/test_gpu_parity.py).
- * -> the previous setting.  EGS_NO_FUSED_COUNT=1 in the environment starts a process with it off. */
-int egs_debug_set_fused_count(int on);
-int egs_forward_fuses_count(int P, int width, int height);
-/* 1 (default): the forward blend's workgroups sort their own tile's bucket (no per-tile sort launch; whenever one sort instantiation
- * suffices: capacity <= 2048 x tiles); 0: the separate k_tile_sort launch(es).  Lists and outputs are the same either way.
- * -> the previous setting.  EGS_NO_SORT_IN_BLEND=1 in the environment starts a process with it off. */
-int egs_debug_set_sort_in_blend(int on);      /* 1: a forward of this size given a placement buffer runs the fused pass */
+/* Whether a forward of this size, given a placement buffer and these EGS_CALL_* flags, folds the count pass of its bucketing into the
+ * preprocess launch (1) or not (0: very large images, or EGS_CALL_SEPARATE_COUNT). */
+int egs_forward_fuses_count(int P, int width, int height, int flags);
 
 /* ---- optional per-stage timing with HIP events on the caller's stream (bench / profiling aid) ------
  * The only process-wide state in the library; off by default.  egs_profile_begin allocates an event pool and

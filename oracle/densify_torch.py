@@ -72,6 +72,8 @@ def densify_and_prune(st, max_grad, min_opacity, extent, max_screen_size, percen
         if which_object is not None:
             sel &= (st["is_object"] == which_object).squeeze(1)
         scale = torch.exp(st["scaling"][sel]).repeat(2, 1)
+        if callable(z):
+            z = z(scale.shape[0])                                           # z(rows) -> [rows, 3] draws, as egogaussian_amd.densify accepts
         samples = scale * z                                               # torch.normal(mean=0, std=scale) with the recorded draw
         R = _rotmat(st["rotation"][sel]).repeat(2, 1, 1)
         new = {k: st[k][sel].repeat(2, *([1] * (st[k].dim() - 1))) for k in PARAMS}

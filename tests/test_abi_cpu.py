@@ -45,23 +45,23 @@ def test_sizes_and_layouts():
     assert L.egs_get_binning_layout(200, 5000, 64, 64, C.byref(b)) == 0 and b.key_bits == 37 and b.index_passes == 1 and b.bin_blocks == 1     # workgroups of whole 256-Gaussian blocks, sized by P (binning.hip egs_bin_gpb)
     i = lib.ImageLayout(); assert L.egs_get_image_layout(100, 70, C.byref(i)) == 0 and i.ranges < i.final_T < i.n_contrib
     assert i.n_contrib < i.quad_work < i.tile_order < i.quad_pairs and i.quad_pairs + 7 * 5 * 8 * 4 <= L.egs_image_bytes(100, 70)
-    assert L.egs_abi_version() == 5 and L.egs_knn3_grid_scratch_bytes(0) == 0 and L.egs_knn3_grid_scratch_bytes(100000) > 100000 * 20
+    assert L.egs_abi_version() == 6 and L.egs_knn3_grid_scratch_bytes(0) == 0 and L.egs_knn3_grid_scratch_bytes(100000) > 100000 * 20
     assert L.egs_knn3_grid(5, None, None, None, None) == -1 and L.egs_knn3_grid(0, None, None, None, None) == 0
     # ABI 5: the placement buffer = 4 cost words per tile + the tile-order words + (256-byte aligned) eight sums words per tile;
     # which forwards fold the count pass of the bucketing into the preprocess launch (one round of <= 16 groups per workgroup)
     nt = 60 * 34
     assert L.egs_placement_bytes(960, 540) == ((nt * 4 + L.egs_order_words(960, 540)) * 4 + 255) // 256 * 256 + 8 * nt * 4
     assert L.egs_placement_bytes(0, 540) == 0 and L.egs_placement_init(None, 960, 540, None) == -1
-    fuses = L.egs_forward_fuses_count
+    fuses = lambda P, W, H, flags=0: L.egs_forward_fuses_count(P, W, H, flags)
     assert fuses(500000, 960, 540) == 1 and fuses(100000, 960, 540) == 1 and fuses(253202, 960, 540) == 1 and fuses(1, 64, 64) == 1
     assert fuses(1000000, 1920, 1080) == 0        # four rounds of eight groups per workgroup: the separate count launch
     assert fuses(0, 960, 540) == 0
-    old = L.egs_debug_set_fused_count(0)
-    try:
-        assert fuses(500000, 960, 540) == 0
-    finally:
-        L.egs_debug_set_fused_count(old)
-    assert fuses(500000, 960, 540) == 1
+    # ABI 6: a per-call flag, not a process-wide switch -- the answer for one call's flags says nothing about the next call's
+    assert fuses(500000, 960, 540, lib.CALL_SEPARATE_COUNT) == 0 and fuses(500000, 960, 540) == 1
+    assert fuses(500000, 960, 540, lib.CALL_KEEP_ALL_INSTANCES | lib.CALL_SYNC | lib.CALL_SEPARATE_SORT | lib.CALL_BALLOT_RANK) == 1
+    # ... and the library exports no setter of process-wide behaviour any more
+    for gone in ("egs_debug_set_tile_culling", "egs_debug_set_fused_count", "egs_debug_set_sort_in_blend", "egs_debug_force_ballot_rank", "egs_debug_set_lossgrad"):
+        assert not hasattr(L, gone), gone
 
 
 def test_argument_errors_precede_device_work():

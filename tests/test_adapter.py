@@ -25,16 +25,24 @@ class RefShaped:
         self._is_object = torch.zeros((n, 1), device=device)
         self.active_sh_degree = self.max_sh_degree = sh_degree
         self.trainable_object_move = None
+        self.scaling_activation, self.opacity_activation, self.rotation_activation = torch.exp, torch.sigmoid, torch.nn.functional.normalize
         self.covariance_activation = covariance_from_scaling_rotation
         self._rot_cov = rotated_covariance_from_scaling_rotation
         self.covariance_activation_w_rot = self.build_covariance_from_scaling_rotation_w_rot     # bound at __init__, gaussian_model.py:39
         self.optimizer = None
 
     get_xyz = property(lambda s: s._xyz)
-    get_scaling = property(lambda s: torch.exp(s._scaling))
-    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
-    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
-    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+    get_scaling = property(lambda s: s.scaling_activation(s._scaling))                    # gaussian_model.py:36-44,142-160: activations are attributes
+    get_rotation = property(lambda s: s.rotation_activation(s._rotation))
+    get_opacity = property(lambda s: s.opacity_activation(s._opacity))
+
+    @property
+    def get_features(self):
+        f = torch.cat((self._features_dc, self._features_rest), dim=1)
+        if getattr(self, "_egs_tag_features", False):                                       # what patching.install() wraps around the class's property
+            from egogaussian_amd.provenance import tag_features
+            tag_features(f, self._features_dc, self._features_rest)
+        return f
     get_is_object = property(lambda s: s._is_object)
 
     def get_covariance(self, scaling_modifier=1):

@@ -555,14 +555,13 @@ def test_ballot_rank_fallback_sorts_identically():
     dev = _dev()
     d = make_inputs(6000, 96, 128, 9, 0, "sh_cov", scale_mul=3.0)
     o, st = oracle_forward(d)
-    L = lib.load()
     res = []
     for force in (0, 1):
-        old = L.egs_debug_force_ballot_rank(force)
+        old = _C.force_ballot_rank(force)                            # (the default of calls that do not say: EGS_CALL_BALLOT_RANK in their flags word)
         try:
             g, out = hip_forward(d, dev)
         finally:
-            L.egs_debug_force_ballot_rank(old)
+            _C.force_ballot_rank(old)
         bv = _C.binning_views(out[6], 6000, out[0], 128, 96, _C.stats["capacity"])
         res.append(bv["point_list"].cpu().numpy().view(np.uint32).copy())
     assert np.array_equal(res[0], st["point_list"]) and np.array_equal(res[1], st["point_list"])

@@ -49,3 +49,16 @@ pr = cProfile.Profile(); pr.enable()
 for k in range(200): step(k)
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+# the backward runs on autograd's device thread, which cProfile does not see: once more with autograd on the calling thread
+torch.autograd.set_multithreading_enabled(False)
+for k in range(20): step(k)
+torch.cuda.synchronize(); t = time.perf_counter()
+for k in range(200): step(k)
+torch.cuda.synchronize(); print(f"wall per step, autograd on the calling thread {1e6 * (time.perf_counter() - t) / 200:.1f} us")
+pr = cProfile.Profile(); pr.enable()
+for k in range(200): step(k)
+pr.disable(); torch.cuda.synchronize()
+print("---- autograd on the calling thread, by internal time"); pstats.Stats(pr).sort_stats("tottime").print_stats(45)
+print("---- by cumulative time"); pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+from egogaussian_amd import provenance
+print("provenance substitutions so far:", provenance.substitutions)
