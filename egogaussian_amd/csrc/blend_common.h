@@ -89,7 +89,7 @@ __device__ __forceinline__ bool egs_ellipse_hits_prepped(const float4& e0 /*x, y
 __device__ __forceinline__ bool egs_block_hits(const float4& c0, const float4& c1, const float4& c2, uint32_t qx0,
                                                uint32_t qx1, uint32_t qy0, uint32_t qy1) {
     const uint32_t bx = __float_as_uint(c2.z), by = __float_as_uint(c2.w);
-    const uint32_t x0 = bx & EGS_BOX_MASK, x1 = (bx >> 16) & EGS_BOX_MASK, y0 = by & EGS_BOX_MASK, y1 = (by >> 16) & EGS_BOX_MASK;     // (the other bits: egs_hot_code, EGS_FAR_BIT)
+    const uint32_t x0 = bx & EGS_BOX_MASK, x1 = (bx >> 16) & EGS_BOX_MASK, y0 = by & EGS_BOX_MASK, y1 = (by >> 16) & EGS_BOX_MASK;     // (the other bits: egs_hot_code)
     if (!(x0 <= qx1 && x1 >= qx0 && y0 <= qy1 && y1 >= qy0)) return false;
     return egs_ellipse_hits(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, qx0, qx1, qy0, qy1);
 }

@@ -12,8 +12,7 @@
 // Packed per-Gaussian record produced by preprocess and gathered by the blend kernels:
 //   f4[0] = (x, y, qa, qb)   f4[1] = (qc, opacity, red, green)
 //   f4[2] = (blue, depth, bits(bbox_x = x0 | x1<<16 | hot bits), bits(bbox_y = y0 | y1<<16 | hot bit))
-//           box coordinates are 15 bits (image sides <= 32767); bits 15 and 31 of bbox_x and bit 15 of bbox_y hold the HOT code,
-//           bit 31 of bbox_y the FAR flag (below)
+//           box coordinates are 15 bits (image sides <= 32767); bits 15 and 31 of bbox_x and bit 15 of bbox_y hold the HOT code
 // (qa, qb, qc) = (-0.5 A, -B, -0.5 C) * log2(e): the conic pre-scaled so that
 //   log2(G) = qa dx^2 + qb dx dy + qc dy^2   feeds v_exp_f32 directly (5 VALU instead of 8).
 // The blend loop reads f4[0], f4[1] and the first half of f4[2] (ds_read_b128 x2 + ds_read_b64).
@@ -25,18 +24,11 @@
 // (pixel, splat) pair and d = splat centre - pixel:
 //   [0]=sum gd dx  [1]=sum gd dy  [2]=sum gd dx^2  [3]=sum gd dx dy  [4]=sum gd dy^2  [5]=sum gd = dL/dopacity
 //   [6..8]=dL/dcolor rgb  [9]=dL/ddepth
-//   [10]=sum gd (2 qa dx + qb dy)  [11]=sum gd (qb dx + 2 qc dy)   -- FAR splats only (below), in place of [0] and [1]
-// k_preprocess_backward converts the five moments into dL/dmean2D and dL/dconic with the Gaussian's own opacity and conic.
-//
-// FAR splats.  dL/dmean2D = -o (A Sx + B Sy, B Sx + C Sy) from the first moments cancels AFTER the sums; the published algorithm
-// cancels per pixel (A dx + B dy, then the sum).  For a splat whose pixels all lie hundreds of pixels from its centre -- a large
-// splat centred far outside the frame -- |A Sx| and |B Sy| are orders of magnitude above their sum and the float32 moments lose what
-// the per-pixel form keeps (the one recorded parity miss: a 423 px splat centred 270 px outside a 3 x 105 image, dL/dmeans3D 6.7e-4
-// of the array's maximum off).  k_preprocess therefore flags a splat whose alpha >= 1/255 box reaches EGS_FAR_REACH pixels or more
-// from its centre (bit 31 of bbox_y), and for such a splat the backward blend accumulates the per-pixel combination itself --
-// gd (2 qa dx + qb dy) and gd (qb dx + 2 qc dy), from the intermediates of the falloff it has in registers -- into slots 10 and 11
-// instead of the first moments: five more vector instructions on the flagged visits only (none at config C, whose largest splat
-// reaches 61 px).
+// k_preprocess_backward converts the five moments into dL/dmean2D and dL/dconic with the Gaussian's own opacity and conic, the
+// conic -> cov2D step in float64 (preprocess.hip: the one place where float32 lost a recorded parity case).  Slots 10 and 11 of the
+// 48-byte line are spare.  (Round 6 tried "FAR" splats here -- a per-pixel cancelled form of dL/dmean2D for splats whose pixels all lie
+// far from the centre, accumulated into the two spare slots: 7 more vector instructions per visit of the backward blend and no change
+// in any gradient of the off-screen family, whose loss turned out to sit in the chain behind the sums; experiments/far_mean2d.patch.)
 #define EGS_GRAD_STRIDE 12
 
 // Hot Gaussians.  A splat whose alpha >= 1/255 box covers EGS_HOT_MIN_TILES tiles or more is visited by hundreds to thousands of
@@ -58,10 +50,6 @@
 #define EGS_HOT_REPLICAS 8u
 #define EGS_HOT_LINE 16u            // floats between replica lines (64 B: two per 128-byte line)
 #define EGS_BOX_MASK 0x7fffu
-#define EGS_FAR_BIT 0x80000000u     // of bbox_y
-#ifndef EGS_FAR_REACH
-#define EGS_FAR_REACH 64.f          // pixels between the centre and the farthest edge of the on-screen alpha >= 1/255 box
-#endif
 __host__ __device__ __forceinline__ uint32_t egs_hot_code(uint32_t bbx, uint32_t bby) {
     return ((bbx >> 15) & 1u) | ((bbx >> 30) & 2u) | ((bby >> 13) & 4u);
 }

@@ -224,9 +224,6 @@ __device__ __forceinline__ uint32_t preprocess_one(
                 bby = (uint32_t)fy0 | ((uint32_t)fy1 << 16);
                 // a box over this many tiles: its accumulator line would be hit by every quadrant-wave of all of them (egs_common.h)
                 hot = (((uint32_t)fx1 >> 4) - ((uint32_t)fx0 >> 4) + 1u) * (((uint32_t)fy1 >> 4) - ((uint32_t)fy0 >> 4) + 1u) >= EGS_HOT_MIN_TILES;
-                // every pixel of the box far from the centre along x or y: the backward blend keeps the per-pixel cancellation of
-                // dL/dmean2D for this splat (egs_common.h, FAR splats)
-                if (fmaxf(fmaxf(px - fx0, fx1 - px), fmaxf(py - fy0, fy1 - py)) >= EGS_FAR_REACH) bby |= EGS_FAR_BIT;
             } else if (!(ex == ex) || !(ey == ey) || !(px == px) || !(py == py)) {   // NaN: never cull
                 bbx = 0u | ((uint32_t)(W - 1) << 16); bby = 0u | ((uint32_t)(H - 1) << 16);
             }
@@ -428,9 +425,7 @@ __device__ __forceinline__ void pp_bwd_one(
         }
         const float cA = r0.z * (-2.f * EGS_LN2), cB = r0.w * (-EGS_LN2), cC = r1.x * (-2.f * EGS_LN2);
         const float o = r1.y;
-        // (acc[10], acc[11]: the per-pixel combinations gd (2 qa dx + qb dy), gd (qb dx + 2 qc dy) of the visits that took the FAR path
-        // instead of the first moments, egs_common.h;  A dx + B dy = -ln2 (2 qa dx + qb dy))
-        gmx = -o * ((cA * acc[0] + cB * acc[1]) - EGS_LN2 * acc[10]); gmy = -o * ((cC * acc[1] + cB * acc[0]) - EGS_LN2 * acc[11]);
+        gmx = -o * (cA * acc[0] + cB * acc[1]); gmy = -o * (cC * acc[1] + cB * acc[0]);
         acc[2] *= -0.5f * o; acc[3] *= -0.5f * o; acc[4] *= -0.5f * o;
     }
     acc[0] = gmx * (0.5f * (float)W); acc[1] = gmy * (0.5f * (float)H);

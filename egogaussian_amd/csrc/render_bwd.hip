@@ -216,7 +216,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const unsigned rv = lane >> 2, rg = lane & 3;
     const float4* red_src = reinterpret_cast<const float4*>(myred + (rv < (unsigned)NV ? (rv >> 1) * 64 + (rv & 1) * 32 + rg * 8 : 0));
     const int slot = (rg == 0 && rv < (unsigned)NV) ? (int)rv + (MODE == 0 ? 6 : 0) : -1;      // (MODE 0: the three colour slots of the line)
-    const int slot_far = (MODE != 0 && slot >= 0 && rv < 2u) ? slot + 10 : slot;                 // FAR splats (egs_common.h): slots 10, 11 instead of the first moments
 
     // S = the blended colour-gradient term of everything BEHIND the splat being processed (U of the header), kept "ready for the
     // next contributor": after a splat with (a, u) it becomes a u + (1 - a) S -- one state word and one select instead of three
@@ -259,13 +258,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #else
         const uint64_t hot_mask = __ballot(have && my_code != 0u);
 #endif
-#if defined(EGS_FAR_ALL)                   // A/B switches: every visit / no visit keeps the per-pixel cancellation of dL/dmean2D
-        const uint64_t far_mask = ~0ull;
-#elif defined(EGS_FAR_NONE)
-        const uint64_t far_mask = 0ull;
-#else
-        const uint64_t far_mask = MODE == 0 ? 0ull : __ballot(have && (__float_as_uint(c2.w) & EGS_FAR_BIT) != 0u);
-#endif
         const uint32_t lastb = last > base ? last - base : 0u;       // this pixel uses entries j < lastb of the batch
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
@@ -300,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if (MODE == 0) {
                 T = Tn;
                 const float v6 = w * g_r, v7 = w * g_g, v8 = w * g_b;
-                (void)t; (void)m; (void)nn; (void)S; (void)bg_term;
+                (void)S; (void)bg_term;
                 myred[0 * 64 + lane] = fold32(v6, v7); myred[1 * 64 + lane] = fold32(v8, 0.f);
             } else {
             const float u = HAS_DA ? fmaf(s1.z, g_r, fmaf(s1.w, g_g, fmaf(s2.x, g_b, fmaf(s2.y, g_d, g_a))))
@@ -314,11 +306,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             // k_preprocess_backward turns them into d/d mean2D and d/d conic with the Gaussian's own opacity and conic
             // (they are linear in these moments), which keeps that algebra out of the per-pixel loop.
             const float gd = G * dLda;                                  // d/d opacity
-            float v0 = gd * dx, v1 = gd * dy;
+            const float v0 = gd * dx, v1 = gd * dy;
             const float v2 = v0 * dx, v3 = v0 * dy, v4 = v1 * dy;
             const float v5 = gd;
-            const bool far = (far_mask >> j) & 1ull;                    // (wave-uniform, rare: egs_common.h FAR splats)
-            if (far) { v0 = gd * (t + m); v1 = gd * fmaf(s0.w, dx, nn + nn); }      // gd (2 qa dx + qb dy), gd (qb dx + 2 qc dy): cancelled per pixel
             const float v6 = w * g_r, v7 = w * g_g, v8 = w * g_b, v9 = HAS_DA ? w * g_d : 0.f;
 
             EGS_BWD_ABL5(abl_sink += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)) + (v8 + v9); continue;)
@@ -338,8 +328,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 // replica = the XCD this workgroup runs on (b % 8); the replicas of a Gaussian lie hot_slots lines apart (egs_common.h)
                 line = hot_base + ((blockIdx.x % EGS_HOT_REPLICAS) * hot_slots + (gid >> 8) * EGS_HOT_PER_BLOCK + code - 1u) * EGS_HOT_LINE;
             }
-            const int sl = (MODE != 0 && ((far_mask >> j) & 1ull)) ? slot_far : slot;
-            if (sl >= 0) EGS_BWD_ACCUM(grad_acc + (line + (uint32_t)sl), out);
+            if (slot >= 0) EGS_BWD_ACCUM(grad_acc + (line + (uint32_t)slot), out);
         }
         __builtin_amdgcn_wave_barrier();
     }
