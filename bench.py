@@ -261,6 +261,7 @@ def unchanged_trainer_legs(dev, N, H, W, steps, warmup):
     for mode in ("installed", "import_swap_only"):
         model = SynthGaussians(perturb_student(teacher), device=dev, fused=False)                 # fused=False: PyTorch ops behind every getter
         model.training_setup(optimizer_cls=torch.optim.Adam)
+        torch.autograd.set_multithreading_enabled(mode != "installed")                              # what install() sets (patching.py): backward on the calling thread
         if mode == "installed":
             l1_loss, ssim = patching.make_loss_functions()
             model.covariance_activation = None
@@ -282,14 +283,19 @@ def unchanged_trainer_legs(dev, N, H, W, steps, warmup):
             loss.backward()
             loss.item()
             opt.step(); opt.zero_grad(set_to_none=True)
+        from egogaussian_amd import provenance as _prov
+        n_sub0 = _prov.substitutions
         el, st = timed(train_step)
+        n_sub = _prov.substitutions - n_sub0
         key = "reference_shaped_step" if mode == "installed" else "import_swap_only_step"
         out[key] = {"value": round(steps / el, 2), "unit": "iters/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": warmup,
                     "host_ops": ("egogaussian_amd.install(): HIP l1_loss / ssim, HIP covariance producer, FusedAdam behind the reference's names" if mode == "installed"
                                  else "PyTorch ops (only the two import names swapped)"),
                     "loop": "the reference's, unchanged: render() through the reference's attribute surface, hand-mask hook, l1_loss + ssim, backward, loss.item() "
                             "every iteration, optimizer.step(), zero_grad (/root/reference/trainers/train_static.py:67-138)",
-                    "rasterizer_stage_ms": {k_: v[0] for k_, v in st.items()}}
+                    "rasterizer_stage_ms": {k_: v[0] for k_, v in st.items()},
+                    "raw_parameter_route": (f"{n_sub} of the leg's renders reached the rasterizer's raw-parameter path through the tagged getter results "
+                                            "(egogaussian_amd/provenance.py): no activation / covariance backward launches")}
         if mode == "installed":
             # ---- label phase on the same model ----
             model._label = torch.zeros(N, 1, device=dev).requires_grad_(True)

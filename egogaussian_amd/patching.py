@@ -91,14 +91,22 @@ def make_loss_functions(orig_l1=None, orig_ssim=None):
     return l1_loss, ssim
 
 
-def install(loss=True, model=True, optimizer=True, capturable=False):
-    """loss: replace utils.loss_utils.{l1_loss, ssim}; model: wrap GaussianModel.setup_functions (covariance producers);
-    optimizer: wrap GaussianModel.training_setup (FusedAdam; capturable as adapter.attach).  Returns a dict of what was replaced."""
+def install(loss=True, model=True, optimizer=True, capturable=False, autograd_on_calling_thread=True):
+    """loss: replace utils.loss_utils.{l1_loss, ssim}; model: wrap GaussianModel.setup_functions (covariance producers, activations that
+    remember their raw parameters: provenance.py) and the class's get_features; optimizer: wrap GaussianModel.training_setup (FusedAdam;
+    capturable as adapter.attach); autograd_on_calling_thread: torch.autograd.set_multithreading_enabled(False) -- loss.backward() then
+    runs on the trainer's own thread instead of being handed to autograd's device thread and waited for, which is worth 0.1-0.15 ms per
+    iteration of a loop whose every kernel is a few microseconds of host work (the reference trains on ONE device from one thread; a
+    process that also drives other devices from other threads should pass False).  Returns a dict of what was replaced."""
     if _STATE.get("installed"):
         return _STATE["report"]
     from .adapter import attach
     report = {"loss": [], "model": [], "rebound": []}
     saved = {}
+    if autograd_on_calling_thread:
+        saved["autograd_mt"] = torch.autograd.is_multithreading_enabled()
+        torch.autograd.set_multithreading_enabled(False)
+        report["autograd"] = "backward on the calling thread (torch.autograd.set_multithreading_enabled(False))"
     if loss:
         lu = importlib.import_module("utils.loss_utils")             # the reference's module: its root must be on sys.path
         orig_l1, orig_ssim = lu.l1_loss, lu.ssim
@@ -149,6 +157,8 @@ def uninstall():
     if not _STATE.get("installed"):
         return
     saved = _STATE["saved"]
+    if "autograd_mt" in saved:
+        torch.autograd.set_multithreading_enabled(saved["autograd_mt"])
     if "loss" in saved:
         lu, orig_l1, orig_ssim, l1_new, ssim_new = saved["loss"]
         lu.l1_loss, lu.ssim = orig_l1, orig_ssim

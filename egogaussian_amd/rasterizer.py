@@ -85,7 +85,19 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha, grad_visible=None):
         rs = ctx.raster_settings
-        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, alpha, sh_rest = ctx.saved_tensors
+        try:
+            colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, alpha, sh_rest = ctx.saved_tensors
+        except RuntimeError as exc:
+            # A leaf this backward differentiates was written in place since the forward saved it.  With an optimizer fused into rasterizer
+            # backwards that is the second of two such backwards in one iteration (the first one's Adam step moved the leaf; FusedAdam tells
+            # autograd about its writes, optim._touched) -- say so in this library's words as well; autograd's own message follows.
+            if ctx.sink is not None and "modified by an inplace operation" in str(exc):
+                raise RuntimeError("FusedAdam: a parameter would take its Adam step inside a second rasterizer backward since the last "
+                                   "optimizer.step() / zero_grad() (two renders with optimizer= feed one loss, or an iteration ran backward "
+                                   "without step() or zero_grad()); render all but one of them without optimizer=, or call "
+                                   "optimizer.step() / zero_grad() between them.  Nothing was enqueued by this backward: the state is as the "
+                                   f"first one left it.  [autograd: {exc}]") from exc
+            raise
         H, W = int(rs.image_height), int(rs.image_width)
         dev = means3D.device
         if grad_color is None:

@@ -266,10 +266,16 @@ def test_sort_inside_the_forward_blend_changes_nothing(N, H, W, seed, mode, smul
         assert res["longest"] > 1792, "this case is meant to take the slab path"
 
 
+def _init_placement(t, W, H, dev):
+    from egogaussian_amd import lib, _hip
+    lib.check(lib.load().egs_placement_init(t.data_ptr(), int(W), int(H), _hip.stream_of(dev)))
+
+
 def test_placement_buffer_first_seen_dirty():
-    """A placement buffer the library has never seen may hold anything in its tile-order words, but its sums region must be zero: the
-    first forward that meets the address clears it (include/egs_raster.h).  Hand over a buffer full of 0xAB through the C ABI path the
-    Python layer uses and compare with the regular one."""
+    """A placement buffer may hold anything in its cost and tile-order words, but its sums region must be zero when a forward starts:
+    the OWNER clears it once with egs_placement_init (include/egs_raster.h; ABI 6: the library keeps no record of buffers and never
+    clears behind the caller's back).  Hand over a buffer full of 0xAB, initialised, through the C ABI path the Python layer uses and
+    compare with the regular one."""
     from egogaussian_amd import _C
     dev = _dev()
     N, H, W = 6000, 135, 240
@@ -281,7 +287,10 @@ def test_placement_buffer_first_seen_dirty():
     assert key, "no placement buffer for this size"
     saved = _C._placement[key[0]]
     try:
-        _C._placement[key[0]] = torch.full_like(saved, 0xAB)          # a different address, never registered, dirty
+        dirty = torch.full_like(saved, 0xAB)                          # a different address, dirty everywhere
+        _init_placement(dirty, W, H, dev)                             # ... the owner's one call: only the sums region is cleared
+        assert int((dirty == 0xAB).sum()) > 0 and int((dirty == 0).sum()) > 0
+        _C._placement[key[0]] = dirty
         g, out = hip_forward(d, dev)
         g, out2 = hip_forward(d, dev)
     finally:
@@ -294,7 +303,8 @@ def test_placement_buffer_first_seen_dirty():
 
 def test_one_placement_buffer_two_image_sizes():
     """A C caller may hand ONE placement allocation to forwards of different sizes: the sums region sits behind a size-dependent number of
-    cost words, so the library clears it again whenever the size it last saw for that address differs (api.hip placement registry)."""
+    cost words, so the owner calls egs_placement_init again whenever it changes the size it uses the buffer for (the contract of ABI 6;
+    through ABI 5 a process-wide registry of addresses did this behind the caller's back)."""
     from egogaussian_amd import _C
     dev = _dev()
     sizes = [(6000, 135, 240, 4), (9000, 270, 480, 7)]
@@ -311,7 +321,8 @@ def test_one_placement_buffer_two_image_sizes():
         for k in keys:
             _C._placement[k] = shared
         for rnd in range(3):
-            for d, ref in zip(ins, refs):
+            for (N, H, W, _), d, ref in zip(sizes, ins, refs):
+                _init_placement(shared, W, H, dev)                    # the size changes: the owner re-initialises
                 out = hip_forward(d, dev)[1]
                 assert out[0] == ref[0] and all(torch.equal(x, y) for x, y in zip(out[1:5], ref[1:5])), f"round {rnd}"
     finally:

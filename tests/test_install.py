@@ -41,8 +41,11 @@ def test_install_repoints_what_the_reference_trainers_call():
         # a module that bound the names BEFORE install() (a trainer imported too early) is re-pointed too
         early = types.ModuleType("early_trainer"); early.l1_loss, early.ssim = orig_l1, orig_ssim
         sys.modules["early_trainer"] = early
+        assert torch.autograd.is_multithreading_enabled()
         rep = egogaussian_amd.install()
         assert egogaussian_amd.install() is rep                                  # idempotent
+        assert not torch.autograd.is_multithreading_enabled() and "autograd" in rep   # backward on the trainer's thread while installed
+        assert "scene.gaussian_model.GaussianModel.get_features" in rep["model"]      # the class's concatenation remembers its halves (provenance.py)
         assert ("early_trainer", "l1_loss") in rep["rebound"] and ("early_trainer", "ssim") in rep["rebound"]
         import trainers.train_static as ts                                        # the reference's trainer module, as it is
         assert ts.l1_loss is lu.l1_loss is early.l1_loss and ts.l1_loss is not orig_l1 and ts.l1_loss.__wrapped__ is orig_l1
@@ -83,12 +86,23 @@ def test_install_repoints_what_the_reference_trainers_call():
             names = [gr["name"] for gr in g.optimizer.param_groups]
             assert names[:6] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"], names
             assert g.optimizer.param_groups[0]["params"][0] is g._xyz
+            # the reference's OWN getters now return results that remember their raw parameters (provenance.py): what its render() hands the
+            # rasterizer can be traced back to the leaves (the rasterizer's raw-parameter path takes them on a HIP device)
+            from egogaussian_amd import provenance as prov
+            o_op, o_cov, o_f = prov.origin(g.get_opacity, "opacity"), prov.origin(g.get_covariance(1.0), "covariance"), prov.origin(g.get_features, "features")
+            assert o_op is not None and o_op.raws[0] is g._opacity
+            assert o_cov is not None and o_cov.raws[0] is g._scaling and o_cov.raws[1] is g._rotation and o_cov.extra == (1.0, None)
+            assert o_f is not None and o_f.raws[0] is g._features_dc and o_f.raws[1] is g._features_rest
+            assert torch.equal(g.get_opacity, torch.sigmoid(g._opacity)) and g.get_scaling is g.get_scaling
             # the reference's covariance entry point runs the installed producer
             c0 = g.covariance_activation_w_rot.calls
             g._is_object = torch.zeros(n, 1)
             g.get_rotated_covariance(torch.eye(3), 1, False, 1.0)
             assert g.covariance_activation_w_rot.calls == c0 + 1
         egogaussian_amd.uninstall()
+        assert torch.autograd.is_multithreading_enabled()
+        assert isinstance(GaussianModel.__dict__["get_features"], property) and GaussianModel.__dict__["get_features"].fget.__name__ == "get_features" \
+            and "_fget" not in GaussianModel.__dict__["get_features"].fget.__code__.co_varnames
         assert lu.l1_loss is orig_l1 and lu.ssim is orig_ssim and ts.l1_loss is orig_l1 and early.ssim is orig_ssim
         assert not hasattr(GaussianModel.setup_functions, "__wrapped__")
     finally:

@@ -9,7 +9,8 @@ from egogaussian_amd.scene_synth import make_scene, make_camera, perturb_student
 from egogaussian_amd.renderer import render
 dev = torch.device("cuda:0"); N, H, W = 500000, 540, 960
 teacher = make_scene(N, H, W, 0); bg = torch.zeros(3, device=dev)
-cams = [make_camera(k, H, W, device=dev) for k in range(8)]
+NF = int(os.environ.get("FRAMES", "8"))
+cams = [make_camera(k, H, W, device=dev) for k in range(NF)]
 with torch.no_grad():
     tpc = SynthGaussians(teacher, device=dev, requires_grad=False)
     gts = [render(c, tpc, Pipe, bg)["render"].clone() for c in cams]
@@ -21,10 +22,10 @@ model.get_covariance = lambda m=1, _g=model: _g.covariance_activation(_g.get_sca
 pc = bench._ReferenceSurface(model); opt = model.optimizer
 hm = (torch.rand(1, H, W) < 0.1).float().to(dev)
 def step(k):
-    pkg = render(cams[k % 8], pc, Pipe, bg)
+    pkg = render(cams[k % NF], pc, Pipe, bg)
     img = pkg["render"]
     img.register_hook(lambda grad: grad * (1 - hm))
-    loss = 0.8 * l1_loss(img, gts[k % 8]) + 0.2 * (1.0 - ssim(img, gts[k % 8]))
+    loss = 0.8 * l1_loss(img, gts[k % NF]) + 0.2 * (1.0 - ssim(img, gts[k % NF]))
     loss.backward(); loss.item()
     opt.step(); opt.zero_grad(set_to_none=True)
 for k in range(20): step(k)
