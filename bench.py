@@ -118,6 +118,46 @@ def stage_table(stages, N, R_kept, npix, sh_coeffs=1, hw=None):
     return rows
 
 
+def preprocess_split_leg(dev, N, H, W, sh_coeffs=1, iters=40):
+    """SURVEY.md 8d holds streaming stages to >= 0.40 of the HBM roofline -- but since ABI 5 the `preprocess` launch of a forward with a
+    placement buffer also walks the tile rectangles (the count pass of the bucketing), which is no streaming work.  The two are told apart
+    here with the per-call flag EGS_CALL_SEPARATE_COUNT (ABI 6): the same forwards with the count pass as a launch of its own give the
+    projection alone (k_preprocess: the streaming kernel the bar is about); the fused launch's duration minus that is what the walk costs
+    where it now runs.  HIP events recorded by the library on the launch stream, eager forwards of S(N,H,W,seed 0), no gradient."""
+    from egogaussian_amd import lib as egs_lib, _C
+    from egogaussian_amd.scene_synth import make_scene, make_camera, SynthGaussians, Pipe
+    from egogaussian_amd.renderer import render
+    pc = SynthGaussians(make_scene(N, H, W, seed=0), device=dev, requires_grad=False)
+    cams = [make_camera(k, H, W, device=dev) for k in range(4)]
+    bg = torch.zeros(3, device=dev)
+    out = {}
+    for name, fused in (("fused", True), ("separate", False)):
+        old = _C.set_fused_count(fused)
+        try:
+            with torch.no_grad():
+                for k in range(6):
+                    render(cams[k % 4], pc, Pipe, bg)
+                torch.cuda.synchronize()
+                egs_lib.profile_begin(max_records=32 * (iters + 8))
+                for k in range(iters):
+                    render(cams[k % 4], pc, Pipe, bg)
+                torch.cuda.synchronize()
+                st = egs_lib.profile_end()
+        finally:
+            _C.set_fused_count(old)
+        out[name] = {k: ms / n for k, (ms, n) in st.items() if n}
+    proj_ms, fused_ms = out["separate"]["preprocess"], out["fused"]["preprocess"]
+    ab = (44 + 12 * sh_coeffs) * N + 48 * N
+    del pc
+    torch.cuda.empty_cache()
+    return {"projection_only_us": round(proj_ms * 1e3, 2), "projection_alg_MB": round(ab / 1e6, 1),
+            "projection_frac_hbm": round(ab / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "fused_projection_and_count_walk_us": round(fused_ms * 1e3, 2), "count_walk_inside_the_fused_launch_us": round((fused_ms - proj_ms) * 1e3, 2),
+            "bucketing_us": {"fused (scan + scatter launches)": round(out["fused"].get("tile_bucket", 0.0) * 1e3, 2),
+                             "separate (count + scan + scatter launches)": round(out["separate"].get("tile_bucket", 0.0) * 1e3, 2)},
+            "how": "eager forwards with and without EGS_CALL_SEPARATE_COUNT in their flags word; HIP events recorded by the library on the launch stream"}
+
+
 def config_leg(dev, N, H, W, forward_only, iters=30, log_scale_shift=0.0, scene=None, what=""):
     """One of BASELINE.json's other configurations on this GPU (parity cases elsewhere; here their timings): the rasterizer alone on
     S(N, H, W, seed 0), forward only (config 2) or forward + backward with seeded upstream gradients on colour, depth and alpha
@@ -803,6 +843,33 @@ def main():
                     f"kernel sources ({budget['steps']} steps), NOT measured in this run",
                     "frac": round(alg_8d / t_rep / 1e9 / HBM_PEAK_GBS, 5),
                     **({"frac_incl_loss_gradient_bytes": round((alg_8d + lg_bytes) / t_rep / 1e9 / HBM_PEAK_GBS, 5)} if lg_bytes else {})}
+    # Every launch of the REPLAYED step: duration from the rocprofv3 kernel trace on file for these kernel sources,
+    # algorithmic bytes, HBM bytes from the PMC passes on file where a pass covers exactly that launch.
+    step_table = None
+    if budget and key == "500000@960x540":
+        n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        stride = 4
+        while stride < (N + 1023) // 1024:
+            stride <<= 1
+        M1 = (D + 1) ** 2
+        rows_def = [
+            ("k_preprocess_count", "projection + count walk of the bucketing (one launch, ABI 5)", (44 + 12 * M1) * N + 48 * N + 48 * N, "preprocess"),
+            ("k_table_scan", "scan of the (tile, workgroup) count table", 2 * 4 * n_tiles * stride, None),
+            ("k_bin_scatter", "scatter walk of the bucketing", 48 * N + 8 * R_kept, None),
+            ("k_render_forward", "per-tile sort + forward blend", 4 * R_kept + 48 * R_kept + 28 * npix + 12 * R_kept, "render_forward"),
+            ("k_l1_ssim_forward", "image loss forward (value + three derivative maps)", 60 * npix, "loss"),
+            ("k_render_backward", "backward blend + the image loss's gradient for its tile", 84 * R_kept + 32 * npix + 60 * npix, "render_backward"),
+            ("k_preprocess_backward", "per-Gaussian backward + Adam step of five parameters", (48 + 32 + 56 + 56 + 112 + 112) * N, None),
+        ]
+        step_table = []
+        for kname, what, ab, pmc_key in rows_def:
+            us = next((v for k_, v in budget["kernels_us"].items() if kname in k_), None)
+            if us is None:
+                continue
+            cnt = (pmc or {}).get(pmc_key, {}).get("hbm_bytes_per_launch") if (pmc and pmc_key) else None
+            step_table.append({"kernel": kname, "what": what, "us": round(us, 2), "alg_MB": round(ab / 1e6, 1),
+                               "frac_hbm": round(ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                               "counter_MB": None if cnt is None else round(cnt / 1e6, 1), "counter_over_alg": None if cnt is None else round(cnt / ab, 2)})
     issue_frac = None
     if sq_dom and sq_dom.get("valu_wave_instructions"):
         # share of the chip's VALU issue capacity the kernel's vector instructions account for: wave-instructions x measured
@@ -897,7 +964,12 @@ def main():
         **({"host_us_per_forward": round(head["host_us"][0], 1), "host_us_per_backward": round(head["host_us"][1], 1),
             "host_us_note": "host time inside render() and inside loss.backward() per step (Python, ctypes, launches, the wait for the instance count), "
                             "GPU not waited for"} if head.get("host_us") else {}),
-        "roofline": roofline, "stages": stage_rows, "cpu_baseline": cpu,
+        "roofline": roofline, "stages": stage_rows,
+        **({"replayed_step_kernels": step_table,
+            "replayed_step_kernels_note": f"profiles/graph_step_budget.json (rocprofv3 --kernel-trace, {budget['steps']} replayed steps, same kernel sources: {src_hash}); "
+                                          "counter_MB = (2 FETCH_SIZE + WRITE_SIZE) x 1024 per launch from profiles/pmc_traffic.json where a PMC pass covers exactly that launch "
+                                          "(the bucketing's scan + scatter were counted together: 'tile_bucket' there)"} if step_table else {}),
+        "cpu_baseline": cpu,
         **({"eager_frames_voided": head["eager_overflows"]} if head.get("eager_overflows") is not None else {}),
         **({"valid": False, "invalid_reason": f"{head['eager_overflows']} frame(s) of the timed loop exceeded the instance capacity and were voided on the device: "
                                               "`value` counts steps that did no update"} if head.get("eager_overflows") else {}),
@@ -983,6 +1055,10 @@ def main():
                                           "/root/reference/gaussian_renderer/__init__.py:90-98 with depth + alpha gradients, BASELINE.json config 5")
             except Exception as exc:
                 out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        try:
+            out["preprocess_split"] = preprocess_split_leg(dev, N, H, W, (D + 1) ** 2)
+        except Exception as exc:
+            out["preprocess_split"] = {"error": f"{type(exc).__name__}: {exc}"}
         # A TRAINED scene: what the reference's trainers and its evaluation actually render (densified every 100 iterations,
         # /root/reference/trainers/train_static.py:129-133; rendered by trainers/fine_all.py:93 and trainers/eval_metric.py:107) -- a few
         # screen-filling splats among many small, faint ones.  The committed model of bench_data/ (tools/make_trained_scene.py).
