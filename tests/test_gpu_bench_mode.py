@@ -186,7 +186,9 @@ def test_training_psnr_parity_300_steps_float_and_8bit():
         return OracleRasterize.apply(pc.get_xyz, pc.get_opacity, pc.get_features, pc.get_covariance(), const_of(cam))
 
     res = {}
+    nt = torch.get_num_threads()
     for side in ("gpu", "cpu"):
+        torch.set_num_threads(min(nt, 8) if side == "cpu" else nt)      # (10 000-row tensors on a 256-core host: thread wake-ups, not arithmetic)
         d = dev if side == "gpu" else "cpu"
         bg = torch.zeros(3, device=d)
         rend = (lambda c, p: render(c, p, Pipe, bg)["render"]) if side == "gpu" else cpu_render
@@ -210,6 +212,7 @@ def test_training_psnr_parity_300_steps_float_and_8bit():
             p8 = float(np.mean([psnr(quantize_8bit(i)[None], quantize_8bit(g)[None]).item() for i, g in zip(imgs, egts)]))
             p0 = float(np.mean([psnr(rend(c, SynthGaussians(student, device=d, requires_grad=False))[None], g[None]).item() for c, g in zip(ecams, egts)]))
         res[side] = (pf, p8, p0, egts[0].cpu())
+    torch.set_num_threads(nt)
     print(f"\n  PSNR on 4 held-out views after {K} steps (start {res['gpu'][2]:.2f} dB): float gpu {res['gpu'][0]:.4f} / oracle chain {res['cpu'][0]:.4f} dB; "
           f"8-bit gpu {res['gpu'][1]:.4f} / oracle chain {res['cpu'][1]:.4f} dB")
     assert rel_err(res["gpu"][3].numpy(), res["cpu"][3].numpy()) < 1e-4            # same ground truth on both sides

@@ -405,7 +405,12 @@ def test_training_psnr_parity_2000_steps_with_densification():
         p, n, e_gpu = product_chain_with_densification(teacher, student, dev, glog)
         runs.append((p, n, glog))
     clog = []
-    p_cpu, n_cpu, e_cpu = oracle_chain_with_densification(teacher, student, clog)
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(nt, 8))             # (a 256-core host spends its time waking threads for 4 000-row tensors: 500 s -> what 8 cores take)
+    try:
+        p_cpu, n_cpu, e_cpu = oracle_chain_with_densification(teacher, student, clog)
+    finally:
+        torch.set_num_threads(nt)
     ps = [r[0] for r in runs]
     spread = max(ps) - min(ps)
     print(f"\n  {SLICE['K']} iterations with densification: held-out PSNR gpu {', '.join(f'{p:.4f}' for p in ps)} dB (three runs of the same chain: spread {spread:.4f} dB) / "
