@@ -84,6 +84,9 @@ def attach(gaussians, optimizer=True, capturable=False, fuse_optimizer=False, pr
     if provenance:
         g.scaling_activation = _prov.tagging_activation(torch.exp, "scaling")                  # gaussian_model.py:36 (torch.exp)
         g.opacity_activation = _prov.tagging_activation(torch.sigmoid, "opacity")              # :40 (torch.sigmoid)
+        # :44 (normalize: three launches).  Nothing substitutes a "rotation" tag; the point is the memo -- the label render asks for
+        # get_rotation every iteration of a phase that does not move the rotations (render_helper.py:38-54, train_static.py:105-109)
+        g.rotation_activation = _prov.tagging_activation(torch.nn.functional.normalize, "rotation")
         g._egs_tag_features = True                                                             # get_features (:157-160) is a property of the class: patching.install wraps it
 
     def covariance_activation(scaling, scaling_modifier, rotation):

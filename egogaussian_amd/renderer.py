@@ -127,7 +127,7 @@ def gaussians_to_label_rendervar(gaussians):
     xyz = gaussians.get_xyz.detach()
     return {"means3D": xyz, "colors_precomp": get_pts_label_as_rgb(gaussians.get_label),
             "rotations": gaussians.get_rotation.detach(), "opacities": gaussians.get_opacity.detach(),
-            "scales": gaussians.get_scaling.detach(), "means2D": torch.zeros_like(xyz) + 0}
+            "scales": gaussians.get_scaling.detach(), "means2D": _screenspace_leaf(xyz).detach()}      # (the reference: zeros_like(xyz) + 0, two launches; nothing reads the values)
 
 
 def get_render_label(viewpoint_camera, pc, bg_color):
