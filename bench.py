@@ -298,12 +298,11 @@ def unchanged_trainer_legs(dev, N, H, W, steps, warmup):
         st = egs_lib.profile_end()
         return el, {k: (round(ms / n, 4), n) for k, (ms, n) in st.items() if n}
 
-    for mode in ("installed", "installed_deferred_check", "import_swap_only"):
+    for mode in ("installed", "import_swap_only"):
         model = SynthGaussians(perturb_student(teacher), device=dev, fused=False)                 # fused=False: PyTorch ops behind every getter
         model.training_setup(optimizer_cls=torch.optim.Adam)
-        torch.autograd.set_multithreading_enabled(not mode.startswith("installed"))                # what install() sets (patching.py): backward on the calling thread
-        _C.deferred_overflow_check(mode == "installed_deferred_check")                              # install(deferred_overflow_check=True): opt-in, off by default
-        if mode.startswith("installed"):
+        torch.autograd.set_multithreading_enabled(mode != "installed")                              # what install() sets (patching.py): backward on the calling thread
+        if mode == "installed":
             l1_loss, ssim = patching.make_loss_functions()
             model.covariance_activation = None
             attach(model)                                                                          # covariance producers + FusedAdam (what install() does per model)
@@ -328,18 +327,16 @@ def unchanged_trainer_legs(dev, N, H, W, steps, warmup):
         n_sub0 = _prov.substitutions
         el, st = timed(train_step)
         n_sub = _prov.substitutions - n_sub0
-        key = {"installed": "reference_shaped_step", "installed_deferred_check": "reference_shaped_step_deferred_check"}.get(mode, "import_swap_only_step")
+        key = "reference_shaped_step" if mode == "installed" else "import_swap_only_step"
         out[key] = {"value": round(steps / el, 2), "unit": "iters/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": warmup,
-                    "host_ops": ("egogaussian_amd.install(): HIP l1_loss / ssim, HIP covariance producer, getter results that remember their raw parameters, FusedAdam "
-                                 "behind the reference's names; backward on the trainer's thread" + ("; deferred_overflow_check=True (opt-in): no host wait for the instance "
-                                 "count, a clipped frame raises at the next render()" if mode == "installed_deferred_check" else "") if mode.startswith("installed")
+                    "host_ops": ("egogaussian_amd.install(): HIP l1_loss / ssim, HIP covariance producer, FusedAdam behind the reference's names" if mode == "installed"
                                  else "PyTorch ops (only the two import names swapped)"),
                     "loop": "the reference's, unchanged: render() through the reference's attribute surface, hand-mask hook, l1_loss + ssim, backward, loss.item() "
                             "every iteration, optimizer.step(), zero_grad (/root/reference/trainers/train_static.py:67-138)",
                     "rasterizer_stage_ms": {k_: v[0] for k_, v in st.items()},
                     "raw_parameter_route": (f"{n_sub} of the leg's renders reached the rasterizer's raw-parameter path through the tagged getter results "
                                             "(egogaussian_amd/provenance.py): no activation / covariance backward launches")}
-        if mode.startswith("installed"):
+        if mode == "installed":
             # ---- label phase on the same model ----
             model._label = torch.zeros(N, 1, device=dev).requires_grad_(True)
             lab_opt = type(opt)([{"params": [model._label], "lr": 0.01, "name": "label"}], lr=0.0, eps=1e-15)
@@ -374,13 +371,13 @@ def unchanged_trainer_legs(dev, N, H, W, steps, warmup):
                     model._label.grad = None
                 return tot / n
             fast, full = bwd_ms(1), bwd_ms(0)
-            out["label_phase_shape" if mode == "installed" else "label_phase_shape_deferred_check"] = {"value": round(steps / el, 2), "unit": "iters/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": warmup,
+            out["label_phase_shape"] = {"value": round(steps / el, 2), "unit": "iters/s", "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": warmup,
                                         "step": "render() fwd + get_render_label() fwd + channel mean + hand-mask hook + BCEWithLogits + backward (colours only) + "
                                                 "loss.item() + Adam on the labels; eager, the reference's loop",
                                         "label_backward_ms": round(fast, 4), "label_backward_full_path_ms": round(full, 4),
                                         "label_backward_ratio": round(fast / full, 3),
                                         "label_backward_kernels_ms": round(st.get("render_backward", (0, 0))[0] + st.get("preprocess_backward", (0, 0))[0], 4),
-                                        "full_backward_kernels_ms": round(sum(out[key]["rasterizer_stage_ms"].get(k_, 0.0)
+                                        "full_backward_kernels_ms": round(sum(out["reference_shaped_step"]["rasterizer_stage_ms"].get(k_, 0.0)
                                                                               for k_ in ("render_backward", "preprocess_backward")), 4),
                                         "label_backward_kernels_note": "blend + per-Gaussian kernel by the library's HIP events: k_render_backward<0> + k_colors_from_acc "
                                                                        "in this leg, k_render_backward<1> + k_preprocess_backward in reference_shaped_step (same scene, "

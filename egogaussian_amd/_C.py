@@ -31,11 +31,7 @@ class StepGuard:
     for such a frame.  `running_max` int64[1] -- raised to the instance count of every forward, so one host read tells whether
     ANY replay overflowed and by how much."""
 
-    def __init__(self, device, deferred=False, on_overflow="void"):
-        # on_overflow (deferred guards): "void" -- a clipped frame is counted and voided on the device by whoever honours the overflow word
-        # (fused statistics, FusedAdam(capturable=True)); "raise" -- the forward that FINDS a clipped frame raises: for loops this library
-        # does not own (install(deferred_overflow_check=True)), where nothing could void the step that frame already fed
-        self.on_overflow = on_overflow
+    def __init__(self, device, deferred=False):
         self.overflow = torch.zeros(2, dtype=torch.int32, device=device)      # [0] flag, [1] instance count of the latest frame
         self.running_max = torch.zeros(1, dtype=torch.int64, device=device)
         # deferred=True (EAGER loops): forwards that carry this guard are enqueued against the capacity hint WITHOUT the host wait for
@@ -54,29 +50,6 @@ class StepGuard:
         """Settle every frame that has not been checked yet (waits for them).  -> True when no frame of this guard has been clipped."""
         _settle(self, wait=True)
         return self.overflows == 0
-
-
-_default_guards = {}                  # device index -> the deferred, raising StepGuard of forwards that name no guard (deferred_overflow_check)
-_deferred_default = False
-
-
-def deferred_overflow_check(on):
-    """Forwards that name no guard skip the host's wait for the instance count and are checked at the NEXT forward, which raises if the frame
-    was clipped (StepGuard(deferred=True, on_overflow="raise")).  The capacity a frame is laid out for is 1.25 x the largest count seen
-    plus 65 536, so a clipped frame needs the count to jump by a quarter between two consecutive frames.  -> the previous setting."""
-    global _deferred_default
-    old, _deferred_default = _deferred_default, bool(on)
-    return old
-
-
-def default_guard(dev):
-    if not _deferred_default or torch.cuda.is_current_stream_capturing():
-        return None
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    g = _default_guards.get(key)
-    if g is None:
-        g = _default_guards[key] = StepGuard(dev, deferred=True, on_overflow="raise")
-    return g
 
 
 _DEFER_RING = 8                       # deferred frames in flight before a forward waits for the oldest (a host that runs far ahead)
@@ -103,11 +76,6 @@ def _settle(guard, wait=False):
             stats["retries"] += 1
         if clipped or R > cap:
             _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(max(R, kept) * 1.25) + 65536)
-        if clipped and guard.on_overflow == "raise":
-            raise RuntimeError(f"a rendered frame needed {max(R, kept)} tile instances but its buffers were laid out for {cap}: its image was clipped and everything "
-                               "computed from it since (loss, gradients, an optimizer step) is invalid.  The check ran one forward late because "
-                               "install(deferred_overflow_check=True) / _C.deferred_overflow_check(True) trades the host's wait for the instance count "
-                               "against exactly this; the capacity has been raised -- restore the last checkpoint, or run without the deferred check")
 
 
 def binning_passes(P, W, H):

@@ -91,25 +91,18 @@ def make_loss_functions(orig_l1=None, orig_ssim=None):
     return l1_loss, ssim
 
 
-def install(loss=True, model=True, optimizer=True, capturable=False, autograd_on_calling_thread=True, deferred_overflow_check=False):
+def install(loss=True, model=True, optimizer=True, capturable=False, autograd_on_calling_thread=True):
     """loss: replace utils.loss_utils.{l1_loss, ssim}; model: wrap GaussianModel.setup_functions (covariance producers, activations that
     remember their raw parameters: provenance.py) and the class's get_features; optimizer: wrap GaussianModel.training_setup (FusedAdam;
     capturable as adapter.attach); autograd_on_calling_thread: torch.autograd.set_multithreading_enabled(False) -- loss.backward() then
     runs on the trainer's own thread instead of being handed to autograd's device thread and waited for, which is worth 0.1-0.15 ms per
     iteration of a loop whose every kernel is a few microseconds of host work (the reference trains on ONE device from one thread; a
-    process that also drives other devices from other threads should pass False); deferred_overflow_check (OFF by default): every
-    render() skips the host's wait for its instance count (~0.07 ms during which the host enqueues nothing) and is checked at the next
-    render(), which RAISES if the frame was clipped -- one iteration late, after that frame's optimizer step (_C.deferred_overflow_check).
-    Returns a dict of what was replaced."""
+    process that also drives other devices from other threads should pass False).  Returns a dict of what was replaced."""
     if _STATE.get("installed"):
         return _STATE["report"]
     from .adapter import attach
     report = {"loss": [], "model": [], "rebound": []}
     saved = {}
-    if deferred_overflow_check:
-        from . import _C
-        saved["deferred"] = _C.deferred_overflow_check(True)
-        report["overflow_check"] = "deferred to the next render(), which raises (_C.deferred_overflow_check)"
     if autograd_on_calling_thread:
         saved["autograd_mt"] = torch.autograd.is_multithreading_enabled()
         torch.autograd.set_multithreading_enabled(False)
@@ -166,9 +159,6 @@ def uninstall():
     saved = _STATE["saved"]
     if "autograd_mt" in saved:
         torch.autograd.set_multithreading_enabled(saved["autograd_mt"])
-    if "deferred" in saved:
-        from . import _C
-        _C.deferred_overflow_check(saved["deferred"])
     if "loss" in saved:
         lu, orig_l1, orig_ssim, l1_new, ssim_new = saved["loss"]
         lu.l1_loss, lu.ssim = orig_l1, orig_ssim

@@ -43,10 +43,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 activation_flags=0, sh_rest=None, densify_stats=None, active_count=None, guard=None, optimizer=None,
                 object_rotation=None, color_only=False):
         rs = raster_settings
-        if guard is None and means3D.is_cuda:
-            guard = _C.default_guard(means3D.device)      # None unless _C.deferred_overflow_check(True) (install(deferred_overflow_check=True))
         if guard is not None and getattr(guard, "deferred", False) and any(ctx.needs_input_grad) and not getattr(optimizer, "capturable", False) \
-                and getattr(guard, "on_overflow", "void") != "raise" and not getattr(guard, "_warned", False):
+                and not getattr(guard, "_warned", False):
             # a deferred frame that turns out clipped is voided ON THE DEVICE -- by the statistics and the Adam step that read the overflow
             # word, i.e. a FusedAdam(capturable=True) taking its step inside this backward or launched with this guard.  Any other optimizer
             # would apply the clipped frame's gradient unnoticed.

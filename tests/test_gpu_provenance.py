@@ -94,38 +94,3 @@ def test_a_touched_tensor_takes_the_route_it_was_given():
         m._opacity.add_(1.0)                                            # the parameter moved after the getter ran: the old result is stale
     stale = rast(means3D=m.get_xyz, means2D=z, opacities=torch.sigmoid(m._opacity - 1.0), shs=m.get_features, cov3D_precomp=m.get_covariance(1.0))[0]
     assert provenance.substitutions == n0 + 1 and float((stale - full).abs().max()) < 1e-5
-
-
-def test_deferred_overflow_check_raises_one_render_late():
-    """_C.deferred_overflow_check(True) (install(deferred_overflow_check=True), opt-in): forwards that name no guard skip the host's wait for the
-    instance count; a frame that did not fit its buffers is found by the NEXT forward, which raises -- never silently."""
-    from egogaussian_amd import _C
-    from egogaussian_amd.renderer import render
-    from egogaussian_amd.scene_synth import make_camera, SynthGaussians, Pipe
-    dev = torch.device("cuda:0")
-    H, W, N = 96, 128, 20000
-    scene = _scene(N, H, W, seed=5)
-    pc = SynthGaussians(scene, device=dev, requires_grad=False)
-    bg = torch.zeros(3, device=dev)
-    cams = [make_camera(k, H, W, device=dev) for k in range(3)]
-    with torch.no_grad():
-        ref = render(cams[1], pc, Pipe, bg)["render"].clone()             # (the waiting way: establishes the capacity)
-    R = _C.stats["num_rendered"]
-    old = _C.deferred_overflow_check(True)
-    try:
-        with torch.no_grad():
-            a = render(cams[0], pc, Pipe, bg)["render"]                    # deferred, fits
-            b = render(cams[1], pc, Pipe, bg)["render"]                    # deferred, fits; frame 0 is checked here
-            torch.cuda.synchronize()
-            assert torch.equal(b, ref)
-            _C.set_capacity_hint(max(R // 4, 1024))                        # the next frame cannot fit
-            c = render(cams[1], pc, Pipe, bg)["render"]                    # clipped -- nobody knows yet
-            torch.cuda.synchronize()
-            with pytest.raises(RuntimeError, match="its image was clipped"):
-                render(cams[2], pc, Pipe, bg)                              # ... found here
-            d = render(cams[1], pc, Pipe, bg)["render"]                    # the capacity was raised: renders again, correctly
-            torch.cuda.synchronize()
-            assert torch.equal(d, ref)
-    finally:
-        _C.deferred_overflow_check(old)
-        _C._default_guards.clear()
