@@ -122,6 +122,42 @@ def test_fused_loss_matches_torch(C, H, W):
     assert _close(a.grad, a2.grad * gate[None], 2e-4)
 
 
+@pytest.mark.parametrize("kind", ["black", "constant", "tiny-variance", "equal", "black-with-islands"])
+def test_fused_loss_on_flat_and_small_variance_images(kind):
+    """The SSIM map's 1 / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2)) is a v_rcp_f32 + one Newton step here (loss.hip), an IEEE division in the
+    reference (/root/reference/utils/loss_utils.py:92-102).  Where it matters most is where the denominator is smallest: flat regions
+    (zero variance: the denominator is C1 C2-sized) -- and with a black background most of a rendered frame is exactly that.
+    Value and gradient against the torch formulation evaluated in FLOAT64, at the north star's 1e-4 (max-norm relative)."""
+    from egogaussian_amd.fused import l1_ssim_loss
+    from egogaussian_amd.losses import training_loss
+    C, H, W = 3, 96, 160
+    gen = torch.Generator().manual_seed(7)
+    if kind == "black":
+        a, b = torch.zeros(C, H, W), torch.zeros(C, H, W)
+    elif kind == "constant":
+        a, b = torch.full((C, H, W), 0.5), torch.full((C, H, W), 0.25)
+    elif kind == "tiny-variance":
+        a = 0.3 + 1e-4 * torch.randn(C, H, W, generator=gen); b = 0.3 + 1e-4 * torch.randn(C, H, W, generator=gen)
+    elif kind == "equal":
+        a = torch.rand(C, H, W, generator=gen); b = a.clone()
+    else:
+        a = torch.zeros(C, H, W); a[:, 20:40, 30:70] = torch.rand(C, 20, 40, generator=gen)
+        b = torch.zeros(C, H, W); b[:, 22:41, 28:66] = torch.rand(C, 19, 38, generator=gen)
+    x = a.to(DEV).requires_grad_(True)
+    l = l1_ssim_loss(x, b.to(DEV), 0.2)
+    l.backward()
+    x64 = a.double().requires_grad_(True)
+    l64 = training_loss(x64, b.double(), 0.2)
+    l64.backward()
+    assert abs(l.item() - l64.item()) <= 1e-5 * max(1.0, abs(l64.item())), (kind, l.item(), l64.item())
+    g, g64 = x.grad.cpu().double(), x64.grad
+    # the unit: the largest true entry, but never less than one pixel's share of the L1 term (0.8 / n) -- at the optimum ("equal", "black") the
+    # true gradient is zero and both sides hold rounding noise (1e-20 in float64, 1e-11 in float32), which says nothing relative to itself
+    # (sign(x - y) of the L1 term at x == y: torch gives 0 and so does the kernel; nothing to set aside)
+    scale = max(float(g64.abs().max()), 0.8 / (C * H * W))
+    assert float((g - g64).abs().max()) <= 1e-4 * scale, (kind, float((g - g64).abs().max()) / scale)
+
+
 def test_fused_loss_matches_reference_fixture():
     from egogaussian_amd.fused import l1_ssim_loss
     g = np.load(os.path.join(GOLD, "losses.npz"))
