@@ -77,3 +77,37 @@ def test_large_offscreen_centred_splats_vs_float64_oracle(N, H, W, seed, deg, mo
             bad.append(f"{name} row {int(m)} (radius {int(r[m])}, centre {xy[m].tolist()}): hip-f64 {e_h64[m]:.2e} > max(1e-4, 2 x oracle32-f64 {e_o[m]:.2e}); hip {hh[m][:3]}, f64 {a64[m][:3]}")
     print(f"\n[{N}@{W}x{H} {mode} x{smul} frame {frame}] {family.size} family splats, {int(flip_px.sum())} flipped pixels\n   " + "\n   ".join(rep))
     assert not bad, "rows further from the float64 oracle than the bar AND than twice the float32 oracle's own distance:\n   " + "\n   ".join(bad)
+
+
+def test_single_symmetric_splat_where_every_float32_evaluation_is_off():
+    """The other miss the randomised sweep recorded (seed 9001, draw 10962, round 6): ONE Gaussian, 15 px radius, well inside a 128 x 239 image.
+    Its footprint is symmetric about its centre, so dL/dmean2D is what is left of terms that cancel between pixels -- sum |gd dx| is ~7 000 x
+    the sum -- and the rounding of the float32 TERMS (not of their summation: the same float32 terms added in float64 land in the same
+    place) moves the result by 5-8e-4: float32 oracle 0.55225 with one thread and 0.55207 with eight, float64 oracle 0.55254.  No float32
+    implementation can meet 1e-4 of the float64 result here; what is asserted is the rule of this file -- no further from the float64
+    oracle than the bar or than twice the float32 oracle's own distance -- with the three distances printed."""
+    from oracle.oracle import Oracle
+    dev = torch.device("cuda:0")
+    N, H, W, seed, deg, mode, frame, smul, oshift = 1, 239, 128, 728, 3, "sh_cov", 265, 8.0, -2.0
+    d = make_inputs(N, H, W, seed, deg, mode, frame=frame, scale_mul=smul, opacity_shift=oshift)
+    o, st = oracle_forward(d)
+    assert int(st["radii"][0]) == 15
+    o64 = Oracle(np.float64, nthreads=8)
+    st64 = o64.forward(**{k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()})
+    grads = seeded_grads(H, W, 7)
+    gb, gb64 = o.backward(st, *grads), o64.backward(st64, *[g.double() for g in grads])
+    g, out = hip_forward(d, dev)
+    hb = hip_backward(g, out, grads, dev)
+    torch.cuda.synchronize()
+    bad = []
+    for name, h in zip(NAMES, hb):
+        if gb.get(name) is None or h.numel() == 0:
+            continue
+        a32, a64 = np.asarray(gb[name], dtype=np.float64).reshape(N, -1), np.asarray(gb64[name], dtype=np.float64).reshape(N, -1)
+        hh = h.cpu().numpy().astype(np.float64).reshape(N, -1)
+        scale = float(np.abs(a64).max()) + 1e-30
+        e_h64, e_o, e_h32 = np.abs(hh - a64).max() / scale, np.abs(a32 - a64).max() / scale, np.abs(hh - a32).max() / scale
+        print(f"   {name}: hip-f64 {e_h64:.1e}, oracle32-f64 {e_o:.1e}, hip-oracle32 {e_h32:.1e}")
+        if e_h64 > max(TOL, 2.0 * e_o):
+            bad.append(name)
+    assert not bad, bad
